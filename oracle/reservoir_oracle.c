@@ -1,0 +1,231 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reservoir hot path
+ * (src/mod_reservoir.f90, src/mod_linalg.f90).  See sml_oracle.h for scope.
+ *
+ * PARITY UNPINNED: mod_reservoir.f90 imports mod_io (NetCDF), mpires (MPI) and MKL_SPBLAS, none of which
+ * can be compiled in this image without writing stand-ins, and the reference's tests hold no vectors for
+ * predict/synchronize/chunking_matmul/fit_chunk_hybrid.  This file follows the
+ * Fortran statement by statement in "reference-faithful mode": COO SpMV in storage order, dense
+ * column-major W_in product, dense column-major W_out product, per-call temporaries.  The third-party
+ * arithmetic is restated from its published semantics:
+ *   - MKL inspector-executor mkl_sparse_d_mv on a 1-based COO handle (version unpinned, "intel 2020",
+ *     README.md:12): y <- alpha*A*x + beta*y, duplicate (row,col) entries accumulate;
+ *   - LAPACK dgesv: LU with partial (row) pivoting, then forward/back substitution.
+ * tests/test_oracle_reservoir.py cross-checks it against an independent numpy/scipy evaluation.
+ */
+#include "sml_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* mkl_sparse_d_mv semantics at src/mod_reservoir.f90:1444 (alpha=1, beta=0), src/mod_linalg.f90:10-25 */
+void ro_coo_mv(int n, int k, const int32_t *rows, const int32_t *cols, const double *vals, const double *x, double *y)
+{
+    for (int i = 0; i < n; ++i) y[i] = 0.0;
+    for (int e = 0; e < k; ++e) y[rows[e] - 1] += vals[e] * x[cols[e] - 1];
+}
+
+/* Fortran matmul(a(m,ncol), x(ncol)) with a column-major: column-sweep accumulation */
+void ro_dense_mv_colmajor(int m, int ncol, const double *a, const double *x, double *y)
+{
+    for (int i = 0; i < m; ++i) y[i] = 0.0;
+    for (int j = 0; j < ncol; ++j) {
+        const double xj = x[j];
+        const double *col = a + (size_t)j * m;
+        for (int i = 0; i < m; ++i) y[i] += col[i] * xj;
+    }
+}
+
+/* src/mod_reservoir.f90:1371-1377 / 1444-1448 */
+void ro_advance(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals,
+                const double *win, double leakage, const double *u, double *x)
+{
+    double *y = (double *)malloc(sizeof(double) * n), *temp = (double *)malloc(sizeof(double) * n);
+    ro_coo_mv(n, k, rows, cols, vals, x, y);
+    ro_dense_mv_colmajor(n, d, win, u, temp);
+    for (int i = 0; i < n; ++i) {
+        double x_ = tanh(y[i] + temp[i]);
+        x[i] = (1.0 - leakage) * x[i] + leakage * x_;
+    }
+    free(y); free(temp);
+}
+
+/* src/mod_reservoir.f90:1354-1381 */
+void ro_synchronize(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals,
+                    const double *win, double leakage, const double *input, int length, double *x)
+{
+    for (int i = 0; i < length; ++i) ro_advance(n, d, k, rows, cols, vals, win, leakage, input + (size_t)i * d, x);
+}
+
+/* src/mod_reservoir.f90:1418-1456 (predict) ; with n_model==0 this is predict_ml (:1491-1525) */
+void ro_predict_raw(int n, int d, int k, int n_model, int n_out,
+                    const int32_t *rows, const int32_t *cols, const double *vals,
+                    const double *win, const double *wout, double leakage,
+                    const double *feedback, const double *local_model, double *x, double *outvec)
+{
+    ro_advance(n, d, k, rows, cols, vals, win, leakage, feedback, x);
+    int n_aug = n_model + n;
+    double *x_augment = (double *)malloc(sizeof(double) * n_aug);
+    for (int i = 0; i < n_model; ++i) x_augment[i] = local_model[i];
+    for (int i = 0; i < n; ++i) {
+        double v = x[i];
+        if ((i + 1) % 2 == 0) v = v * v;      /* x_temp(2:n:2) = x_temp(2:n:2)**2 */
+        x_augment[n_model + i] = v;
+    }
+    ro_dense_mv_colmajor(n_out, n_aug, wout, x_augment, outvec);
+    free(x_augment);
+}
+
+/* src/mod_utilities.f90:1598-1636 */
+int ro_find_closest_divisor(int target, int number)
+{
+    if (((number % target) + target) % target == 0) return target;
+    int radius = 2;
+    for (;;) {
+        for (int i = target - radius; i <= target + radius; ++i)
+            if (i != 0 && number % i == 0) return i;
+        radius += 1;
+    }
+}
+
+/* chunking_matmul (src/mod_reservoir.f90:1645-1701): aug = [model ; states];
+ * B(n_out,n_aug) += Y * aug^T ; C(n_aug,n_aug) += aug * aug^T.  All column-major. */
+void ro_chunking_matmul(int n, int n_model, int n_out, int m, const double *states, const double *model, const double *y,
+                        double *c, double *b)
+{
+    int n_aug = n + n_model;
+    double *aug = (double *)malloc(sizeof(double) * (size_t)n_aug * m);
+    for (int t = 0; t < m; ++t) {
+        memcpy(aug + (size_t)t * n_aug, model + (size_t)t * n_model, sizeof(double) * n_model);
+        memcpy(aug + (size_t)t * n_aug + n_model, states + (size_t)t * n, sizeof(double) * n);
+    }
+    /* temp = matmul(targetdata, transpose(aug)) accumulated over t, then added */
+    double *tb = (double *)calloc((size_t)n_out * n_aug, sizeof(double));
+    for (int t = 0; t < m; ++t)
+        for (int j = 0; j < n_aug; ++j) {
+            double a = aug[(size_t)t * n_aug + j];
+            for (int i = 0; i < n_out; ++i) tb[(size_t)j * n_out + i] += y[(size_t)t * n_out + i] * a;
+        }
+    for (size_t e = 0; e < (size_t)n_out * n_aug; ++e) b[e] += tb[e];
+    free(tb);
+    /* DGEMM('N','N', n,n,m, 1, aug, n, transpose(aug), m, 0, temp, n); C += temp */
+    double *tc = (double *)calloc((size_t)n_aug * n_aug, sizeof(double));
+    for (int t = 0; t < m; ++t) {
+        const double *at = aug + (size_t)t * n_aug;
+        for (int j = 0; j < n_aug; ++j) {
+            double aj = at[j];
+            double *col = tc + (size_t)j * n_aug;
+            for (int i = 0; i < n_aug; ++i) col[i] += at[i] * aj;
+        }
+    }
+    for (size_t e = 0; e < (size_t)n_aug * n_aug; ++e) c[e] += tc[e];
+    free(tc); free(aug);
+}
+
+/* dgesv semantics (src/mod_linalg.f90:109-151): A (n,n) col-major overwritten by LU, B (n,nrhs) by X */
+static int lu_solve(int n, int nrhs, double *a, double *b)
+{
+    int *ipiv = (int *)malloc(sizeof(int) * n);
+    int info = 0;
+    for (int j = 0; j < n; ++j) {
+        int p = j; double best = fabs(a[(size_t)j * n + j]);
+        for (int i = j + 1; i < n; ++i) { double v = fabs(a[(size_t)j * n + i]); if (v > best) { best = v; p = i; } }
+        ipiv[j] = p;
+        if (a[(size_t)j * n + p] == 0.0) { if (!info) info = j + 1; continue; }
+        if (p != j) for (int c = 0; c < n; ++c) { double t = a[(size_t)c * n + j]; a[(size_t)c * n + j] = a[(size_t)c * n + p]; a[(size_t)c * n + p] = t; }
+        double inv = 1.0 / a[(size_t)j * n + j];
+        for (int i = j + 1; i < n; ++i) a[(size_t)j * n + i] *= inv;
+        for (int c = j + 1; c < n; ++c) {
+            double f = a[(size_t)c * n + j];
+            if (f != 0.0) { double *cc = a + (size_t)c * n; const double *lj = a + (size_t)j * n;
+                for (int i = j + 1; i < n; ++i) cc[i] -= lj[i] * f; }
+        }
+    }
+    if (!info)
+        for (int r = 0; r < nrhs; ++r) {
+            double *x = b + (size_t)r * n;
+            for (int j = 0; j < n; ++j) if (ipiv[j] != j) { double t = x[j]; x[j] = x[ipiv[j]]; x[ipiv[j]] = t; }
+            for (int j = 0; j < n; ++j) { double xj = x[j]; if (xj != 0.0) for (int i = j + 1; i < n; ++i) x[i] -= a[(size_t)j * n + i] * xj; }
+            for (int j = n - 1; j >= 0; --j) { x[j] /= a[(size_t)j * n + j]; double xj = x[j]; for (int i = 0; i < j; ++i) x[i] -= a[(size_t)j * n + i] * xj; }
+        }
+    free(ipiv);
+    return info;
+}
+
+/* fit_chunk_hybrid (src/mod_reservoir.f90:1235-1334): regularise diag, solve C^T Z = (B+prior)^T, wout = Z^T */
+int ro_fit_chunk_hybrid(int n, int n_model, int n_out, double beta_res, double beta_model, double prior_val, int using_prior,
+                        const double *c_in, const double *b_in, double *wout)
+{
+    int n_aug = n + n_model;
+    double *a_trans = (double *)malloc(sizeof(double) * (size_t)n_aug * n_aug);
+    double *b_trans = (double *)malloc(sizeof(double) * (size_t)n_aug * n_out);
+    for (int j = 0; j < n_aug; ++j)
+        for (int i = 0; i < n_aug; ++i) {
+            double v = c_in[(size_t)j * n_aug + i];
+            if (i == j) {
+                if (using_prior) v += (i < n_model) ? pow(beta_model, 2.0) : pow(beta_res, 2.0);
+                else v += (i < n_model) ? beta_model : beta_res;
+            }
+            a_trans[(size_t)i * n_aug + j] = v;          /* transpose */
+        }
+    for (int j = 0; j < n_aug; ++j)
+        for (int i = 0; i < n_out; ++i) {
+            double v = b_in[(size_t)j * n_out + i];
+            if (using_prior && i == j && i < n_model) v += prior_val * pow(beta_model, 2.0);
+            b_trans[(size_t)i * n_aug + j] = v;
+        }
+    int info = lu_solve(n_aug, n_out, a_trans, b_trans);
+    for (int j = 0; j < n_aug; ++j)
+        for (int i = 0; i < n_out; ++i) wout[(size_t)j * n_out + i] = b_trans[(size_t)i * n_aug + j];
+    free(a_trans); free(b_trans);
+    return info;
+}
+
+/* reservoir_layer_chunking_hybrid (src/mod_reservoir.f90:1067-1175) for one pass over T columns whose noise has
+ * already been applied (the compiler RNG is not reproducible, so noise realisations are inputs).
+ * discard = discardlength/timestep, batch = reservoir%batch_size.  Returns number of batches flushed. */
+int ro_train_states(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals, const double *win,
+                    double leakage, const double *noisy_inputs, int T, int discard, int batch,
+                    int n_model, int n_out, const double *model, const double *targets, double *c, double *b)
+{
+    double *x = (double *)calloc(n, sizeof(double));
+    double *states = (double *)calloc((size_t)n * batch, sizeof(double));
+    double *saved = (double *)calloc(n, sizeof(double));
+    double *src = (double *)malloc(sizeof(double) * n);
+    for (int i = 1; i <= discard; ++i) ro_advance(n, d, k, rows, cols, vals, win, leakage, noisy_inputs + (size_t)(i - 1) * d, x);
+    memcpy(states, x, sizeof(double) * n);                 /* states(:,1) = x */
+    int batch_number = 0;
+    int training_length = T - discard;
+#define COL(c1) (states + (size_t)((c1) - 1) * n)
+    for (int i = 1; i <= training_length - 1; ++i) {
+        const double *u = noisy_inputs + (size_t)(discard + i - 1) * d;
+        if ((i + 1) % batch == 0) {
+            ++batch_number;
+            /* y = A*states(:,mod(i,batch)); the leak term uses the running x (:1118-1129) */
+            memcpy(src, COL(i % batch), sizeof(double) * n);
+            {   /* tanh(A*src + Win*u), leak against x */
+                double *tmpx = (double *)malloc(sizeof(double) * n);
+                memcpy(tmpx, src, sizeof(double) * n);
+                ro_advance(n, d, k, rows, cols, vals, win, 1.0, u, tmpx);       /* tmpx = x_ */
+                for (int r = 0; r < n; ++r) x[r] = (1.0 - leakage) * x[r] + leakage * tmpx[r];
+                free(tmpx);
+            }
+            memcpy(COL(batch), x, sizeof(double) * n);
+            memcpy(saved, x, sizeof(double) * n);
+            for (int t = 0; t < batch; ++t)
+                for (int r = 1; r < n; r += 2) states[(size_t)t * n + r] *= states[(size_t)t * n + r];
+            int c0 = discard + (batch_number - 1) * batch;   /* 0-based first column of the batch */
+            ro_chunking_matmul(n, n_model, n_out, batch, states, model + (size_t)c0 * n_model, targets + (size_t)c0 * n_out, c, b);
+        } else {
+            const double *s = (i % batch == 0) ? saved : COL(i % batch);
+            double *tmpx = (double *)malloc(sizeof(double) * n);
+            memcpy(tmpx, s, sizeof(double) * n);
+            ro_advance(n, d, k, rows, cols, vals, win, 1.0, u, tmpx);
+            for (int r = 0; r < n; ++r) x[r] = (1.0 - leakage) * x[r] + leakage * tmpx[r];
+            free(tmpx);
+            memcpy((i % batch == 0) ? COL(1) : COL((i + 1) % batch), x, sizeof(double) * n);
+        }
+    }
+#undef COL
+    free(x); free(states); free(saved); free(src);
+    return batch_number;
+}

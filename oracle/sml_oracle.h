@@ -1,0 +1,148 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the SPEEDY-ML hybrid-step hot path.
+ *
+ * Plain C99, fp64 / int32, single-threaded, no FMA contraction (build with -ffp-contract=off).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (speedy-ml_amd/, libspeedyml_hip.so) never links, loads or calls it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - spectral_oracle.c : PINNED against the compiled reference (oracle/_ref/libref_spectral.so,
+ *                         built from /root/reference/src in place) via tests/golden/spectral_*.npz.
+ *   - domain_oracle.c   : pinned only by the reference's one usable known answer
+ *                         (tests/mod_unit_test.f90:63-96, x-extent/chunk) and the reference-run facts
+ *                         recorded in SURVEY.md Appendix A; otherwise PARITY UNPINNED.
+ *   - reservoir_oracle.c: PARITY UNPINNED (mod_reservoir.f90 cannot be built here without stand-ins
+ *                         for MKL_SPBLAS/mpi/NetCDF); line-by-line restatement, cross-checked in
+ *                         tests against an independent numpy/scipy evaluation.
+ * All file:line citations are relative to /root/reference/.
+ */
+#ifndef SML_ORACLE_H
+#define SML_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- spectral (src/mod_atparam.f90:9-14) ---------------- */
+enum { SO_IX = 96, SO_IY = 24, SO_IL = 48, SO_NX = 32, SO_MX = 31, SO_MX2 = 62,
+       SO_NTRUN = 30, SO_NTRUN1 = 31, SO_NXP = 33, SO_MXP = 31 };
+
+typedef struct so_tables {
+    double a;
+    double sia[SO_IY], coa[SO_IY], wt[SO_IY], wght[SO_IY];
+    double cosg[SO_IL], cosgr[SO_IL], cosgr2[SO_IL];
+    double el2[SO_NX][SO_MX], elm2[SO_NX][SO_MX], el4[SO_NX][SO_MX], trfilt[SO_NX][SO_MX];
+    int    nsh2[SO_NX];
+    double epsi[SO_NXP][SO_MXP], repsi[SO_NXP][SO_MXP], consq[SO_MXP], sqrhlf;
+    double gradx[SO_MX], gradym[SO_NX][SO_MX], gradyp[SO_NX][SO_MX];
+    double uvdx[SO_NX][SO_MX], uvdym[SO_NX][SO_MX], uvdyp[SO_NX][SO_MX];
+    double vddym[SO_NX][SO_MX], vddyp[SO_NX][SO_MX];
+    double cpol[SO_IY][SO_NX][SO_MX2];      /* Fortran cpol(mx2,nx,iy) */
+    double dftc[SO_IX], dfts[SO_IX];        /* cos/sin(2*pi*t/96) for the DFT restatement */
+} so_tables;
+
+/* All spectral fields use the Fortran storage order: vorm(mx2,nx) -> v[n*62+c], varm(mx2,il) -> [j*62+c],
+ * vorg(ix,il) -> g[j*96+i]. */
+void so_parmtr(so_tables *t, double a);                                   /* spe_spectral.f90:45-192 */
+void so_get_table(const so_tables *t, int which, double *out);            /* same numbering as ref_get_table */
+void so_gridy(const so_tables *t, const double *v, double *varm);         /* :454-495 */
+void so_gridx(const so_tables *t, const double *varm, double *vorg, int kcos); /* spe_subfft_fftpack.f90:15-51 */
+void so_specx(const so_tables *t, const double *vorg, double *varm);      /* :55-87 */
+void so_specy(const so_tables *t, const double *varm, double *vorm);      /* spe_spectral.f90:497-538 */
+void so_grid(const so_tables *t, const double *vorm, double *vorg, int kcos);  /* :389-401 */
+void so_spec(const so_tables *t, const double *vorg, double *vorm);       /* :403-414 */
+void so_vdspec(const so_tables *t, const double *ug, const double *vg, double *vorm, double *divm, int kcos); /* :416-452 */
+void so_uvspec(const so_tables *t, const double *vorm, const double *divm, double *ucosm, double *vcosm);    /* :351-387 */
+void so_vds(const so_tables *t, const double *ucosm, const double *vcosm, double *vorm, double *divm);       /* :307-349 */
+void so_grad(const so_tables *t, const double *psi, double *psdx, double *psdy);                              /* :271-305 */
+void so_lap(const so_tables *t, const double *strm, double *vorm);        /* :244-254 */
+void so_invlap(const so_tables *t, const double *vorm, double *strm);     /* :256-269 */
+void so_trunct(const so_tables *t, double *vor);                          /* :540-551 */
+void so_rfftf(const so_tables *t, double *r);   /* FFTPACK rfftf semantics, n=96 (spe_subfft_fftpack2.f90:24-34) */
+void so_rfftb(const so_tables *t, double *r);   /* FFTPACK rfftb semantics, n=96 (:13-22) */
+so_tables *so_tables_new(void);
+void so_tables_free(so_tables *t);
+
+/* ---------------- resdomain (src/res_domain.f90) ---------------- */
+enum { RD_XGRID = 96, RD_YGRID = 48, RD_ZGRID = 8, RD_GRIDNUM = 96 * 48 }; /* src/mod_utilities.f90:17-20 */
+
+typedef struct rd_grid {      /* subset of grid_type, src/mod_utilities.f90 (fields set by initializedomain) */
+    int res_xstart, res_xend, res_ystart, res_yend, resxchunk, resychunk;
+    int res_zstart, res_zend, reszchunk;
+    int input_xstart, input_xend, input_ystart, input_yend, inputxchunk, inputychunk;
+    int input_zstart, input_zend, inputzchunk;
+    int pole, periodicboundary, top, bottom;
+    int tdata_xstart, tdata_xend, tdata_ystart, tdata_yend, tdata_zstart, tdata_zend;
+    int overlap, num_vert_levels, vert_overlap, number_of_regions;
+} rd_grid;
+
+typedef struct rd_sizes {     /* integer results of allocate_res_new + trained_reservoir_prediction */
+    int logp_size_input, sst_size_input, precip_size_input, tisr_size_input;
+    int logp_size_res, precip_size_res;
+    int chunk_size, chunk_size_prediction, chunk_size_speedy, locality;
+    int nodes_per_input, n, k, reservoir_numinputs;
+    int atmo3d_start, atmo3d_end, logp_start, logp_end, precip_start, precip_end,
+        sst_start, sst_end, tisr_start, tisr_end;      /* 1-based inclusive, 0/0 if absent */
+} rd_sizes;
+
+/* returns number of regions written; region_indices needs room for number_of_regions/numprocs+1 */
+int  rd_processor_decomposition(int proc, int numprocs, int number_of_regions, int *region_indices); /* :64-94 */
+void rd_domaindecomposition(int numregions, int *factorx, int *factory);                              /* :258-280 */
+void rd_getworkerlower_leftcorner(int region_num, int factory, int *row, int *col);                   /* :282-292 */
+void rd_getxyresextent(int num_regions, int region_num, int *xs, int *xe, int *ys, int *ye, int *xchunk, int *ychunk); /* :123-141 */
+void rd_initializedomain(int num_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
+                         int vert_overlap, rd_grid *g);                                               /* :96-121 */
+void rd_allocate_sizes(const rd_grid *g, int m, int deg, int local_predictvars, int logp_bool, int precip_bool,
+                       int sst_bool_input, int tisr_input_bool, int ml_only, rd_sizes *s);  /* mod_reservoir.f90:80-180,1859-1885 */
+/* tilers; grids are Fortran-ordered: grid4d(4,96,48,8) -> [((z*48+y)*96+x)*4+v], grid2d(96,48) -> [y*96+x] */
+void rd_tile_input(int num_regions, int region_num, int overlap, int num_vert_levels, int vert_level, int vert_overlap,
+                   int precip_bool, const double *grid4d, const double *grid2d, const double *precip,
+                   double *inputvec);                               /* tile_4d_and_logp_to_local_state_input :1081-1125 */
+void rd_tile_input2d(int num_regions, int region_num, int overlap, const double *grid2d, double *out); /* tileoverlapgrid2d */
+void rd_scatter_res(int num_regions, int num_vert_levels, int region_num, int vert_level, int precip_bool, int length,
+                    const double *statevec, double *grid4d, double *grid2d, double *precip);  /* tile_full_grid_with_local_state_vec_res1d :791-826 */
+void rd_tile_res(int num_regions, int num_vert_levels, int region_num, int vert_level,
+                 const double *grid4d, const double *grid2d, double *statevec);  /* tile_4d_and_logp_full_grid_to_local_res_vec :1022-1053 */
+void rd_standardize_input(const rd_grid *g, const rd_sizes *s, int local_predictvars, int logp_bool,
+                          const double *mean, const double *std, double *state_vec);  /* standardize_state_vec_input :1211-1268 */
+void rd_standardize_res(const rd_grid *g, int local_predictvars, int heightlevels_input, int logp_bool,
+                        const double *mean, const double *std, double *state_vec);    /* standardize_state_vec_res :1270-1315 */
+void rd_unstandardize_res(const rd_grid *g, int local_predictvars, int heightlevels_input, int logp_bool, int precip_bool,
+                          int logp_idx, int precip_idx, const double *mean, const double *std, double *state_vec); /* :1424-1475 */
+double rd_get_radius_by_lat(double startlat, double endlat);       /* :1630-1660 */
+
+/* ---------------- reservoir (src/mod_reservoir.f90, src/mod_linalg.f90) ---------------- */
+/* y = beta*y + alpha*A*x with A in 1-based COO, entries applied in storage order (MKL_SPARSE_D_MV semantics as
+ * used at mod_reservoir.f90:1444 with alpha=1,beta=0; duplicates accumulate). */
+void ro_coo_mv(int n, int k, const int32_t *rows, const int32_t *cols, const double *vals, const double *x, double *y);
+/* temp = matmul(win, u): win(n,d) column-major dense (mod_reservoir.f90:1445) */
+void ro_dense_mv_colmajor(int m, int ncol, const double *a, const double *x, double *y);
+/* one reservoir step without readout: x <- (1-leak)*x + leak*tanh(A x + Win u)  (:1371-1377, :1444-1448) */
+void ro_advance(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals,
+                const double *win, double leakage, const double *u, double *x);
+/* synchronize (:1354-1381): input(d,length) column-major */
+void ro_synchronize(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals,
+                    const double *win, double leakage, const double *input, int length, double *x);
+/* predict (:1418-1489) up to and including matmul(wout,x_augment); outvec is still standardised */
+void ro_predict_raw(int n, int d, int k, int n_model, int n_out,
+                    const int32_t *rows, const int32_t *cols, const double *vals,
+                    const double *win, const double *wout /* (n_out, n_model+n) col-major */, double leakage,
+                    const double *feedback, const double *local_model, double *x, double *outvec);
+/* predict_ml (:1491-1535): no model rows (n_model must be 0 in wout) */
+
+/* training (K7/K8/K9), see reservoir_oracle.c */
+void ro_chunking_matmul(int n, int n_model, int n_out, int m, const double *states /* (n,m) already squared */,
+                        const double *model /* (n_model,m) */, const double *y /* (n_out,m) */,
+                        double *states_x_states_aug /* (n_aug,n_aug) += */, double *states_x_trainingdata_aug /* (n_out,n_aug) += */); /* :1645-1701 */
+int  ro_fit_chunk_hybrid(int n, int n_model, int n_out, double beta_res, double beta_model, double prior_val, int using_prior,
+                         const double *c_in, const double *b_in, double *wout); /* :1235-1334 -> mldivide mod_linalg.f90:109-151 */
+int  ro_train_states(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals, const double *win,
+                     double leakage, const double *noisy_inputs /* (d,T) already noised */, int T, int discard, int batch,
+                     int n_model, int n_out, const double *model /* (n_model,T) */, const double *targets /* (n_out,T) */,
+                     double *c /* (n_aug,n_aug) += */, double *b /* (n_out,n_aug) += */);   /* :1067-1175, Appendix D */
+int  ro_find_closest_divisor(int approx, int number);   /* mod_utilities.f90:1598-1636 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,353 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so) and, when present, the compiled
+reference spectral core (oracle/_ref/libref_spectral.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+IX, IY, IL, NX, MX, MX2, NXP, MXP = 96, 24, 48, 32, 31, 62, 33, 31
+REARTH = 6.371e6  # src/mod_dyncon1.f90:13
+
+TABLES = {  # which -> (name, shape in Fortran order)
+    1: ("sia", (IY,)), 2: ("coa", (IY,)), 3: ("wt", (IY,)), 4: ("wght", (IY,)),
+    5: ("cosg", (IL,)), 6: ("cosgr", (IL,)), 7: ("cosgr2", (IL,)),
+    8: ("el2", (MX, NX)), 9: ("elm2", (MX, NX)), 10: ("el4", (MX, NX)), 11: ("trfilt", (MX, NX)),
+    12: ("nsh2", (NX,)), 13: ("epsi", (MXP, NXP)), 14: ("repsi", (MXP, NXP)), 15: ("consq", (MXP,)),
+    16: ("gradx", (MX,)), 17: ("gradym", (MX, NX)), 18: ("gradyp", (MX, NX)),
+    19: ("uvdx", (MX, NX)), 20: ("uvdym", (MX, NX)), 21: ("uvdyp", (MX, NX)),
+    22: ("vddym", (MX, NX)), 23: ("vddyp", (MX, NX)), 24: ("cpol", (MX2, NX, IY)), 26: ("sqrhlf", (1,)),
+}
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip)
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in
+            ("spectral_oracle.c", "domain_oracle.c", "reservoir_oracle.c", "sml_oracle.h")]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class RdGrid(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "res_xstart", "res_xend", "res_ystart", "res_yend", "resxchunk", "resychunk",
+        "res_zstart", "res_zend", "reszchunk",
+        "input_xstart", "input_xend", "input_ystart", "input_yend", "inputxchunk", "inputychunk",
+        "input_zstart", "input_zend", "inputzchunk",
+        "pole", "periodicboundary", "top", "bottom",
+        "tdata_xstart", "tdata_xend", "tdata_ystart", "tdata_yend", "tdata_zstart", "tdata_zend",
+        "overlap", "num_vert_levels", "vert_overlap", "number_of_regions")]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RdSizes(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "logp_size_input", "sst_size_input", "precip_size_input", "tisr_size_input",
+        "logp_size_res", "precip_size_res",
+        "chunk_size", "chunk_size_prediction", "chunk_size_speedy", "locality",
+        "nodes_per_input", "n", "k", "reservoir_numinputs",
+        "atmo3d_start", "atmo3d_end", "logp_start", "logp_end", "precip_start", "precip_end",
+        "sst_start", "sst_end", "tisr_start", "tisr_end")]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Oracle:
+    """Thin numpy-facing wrapper over liboracle.so."""
+
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        L.so_tables_new.restype = C.c_void_p
+        L.so_parmtr.argtypes = [C.c_void_p, C.c_double]
+        L.so_get_table.argtypes = [C.c_void_p, C.c_int, _dp]
+        for name, nargs in (("so_gridy", 2), ("so_specx", 2), ("so_specy", 2), ("so_spec", 2), ("so_lap", 2),
+                            ("so_invlap", 2), ("so_trunct", 1), ("so_rfftf", 1), ("so_rfftb", 1),
+                            ("so_grad", 3), ("so_uvspec", 4), ("so_vds", 4)):
+            getattr(L, name).argtypes = [C.c_void_p] + [_dp] * nargs
+        L.so_gridx.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.so_grid.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.so_vdspec.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.c_int]
+        L.rd_get_radius_by_lat.restype = C.c_double
+        L.rd_get_radius_by_lat.argtypes = [C.c_double, C.c_double]
+        self.t = C.c_void_p(L.so_tables_new())
+        L.so_parmtr(self.t, REARTH)
+
+    # ---- spectral ----
+    def table(self, which):
+        name, shape = TABLES[which]
+        out = np.zeros(int(np.prod(shape)))
+        self.lib.so_get_table(self.t, which, _p(out))
+        return out.reshape(shape, order="F")
+
+    def tables(self):
+        return {TABLES[w][0]: self.table(w) for w in TABLES}
+
+    def _call(self, fn, ins, out_shapes, *extra):
+        ins = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F")) for a in ins]
+        outs = [np.zeros(int(np.prod(s))) for s in out_shapes]
+        getattr(self.lib, fn)(self.t, *[_p(a) for a in ins], *[_p(o) for o in outs], *extra)
+        outs = [o.reshape(s, order="F") for o, s in zip(outs, out_shapes)]
+        return outs[0] if len(outs) == 1 else outs
+
+    def grid(self, vorm, kcos):
+        return self._call("so_grid", [vorm], [(IX, IL)], kcos)
+
+    def spec(self, vorg):
+        return self._call("so_spec", [vorg], [(MX2, NX)])
+
+    def gridy(self, v):
+        return self._call("so_gridy", [v], [(MX2, IL)])
+
+    def gridx(self, varm, kcos):
+        return self._call("so_gridx", [varm], [(IX, IL)], kcos)
+
+    def specx(self, vorg):
+        return self._call("so_specx", [vorg], [(MX2, IL)])
+
+    def specy(self, varm):
+        return self._call("so_specy", [varm], [(MX2, NX)])
+
+    def vdspec(self, ug, vg, kcos):
+        return self._call("so_vdspec", [ug, vg], [(MX2, NX), (MX2, NX)], kcos)
+
+    def uvspec(self, vorm, divm):
+        return self._call("so_uvspec", [vorm, divm], [(MX2, NX), (MX2, NX)])
+
+    def vds(self, u, v):
+        return self._call("so_vds", [u, v], [(MX2, NX), (MX2, NX)])
+
+    def grad(self, psi):
+        return self._call("so_grad", [psi], [(MX2, NX), (MX2, NX)])
+
+    def lap(self, s):
+        return self._call("so_lap", [s], [(MX2, NX)])
+
+    def invlap(self, v):
+        return self._call("so_invlap", [v], [(MX2, NX)])
+
+    def trunct(self, v):
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel(order="F")).copy()
+        self.lib.so_trunct(self.t, _p(a))
+        return a.reshape((MX2, NX), order="F")
+
+    def rfftf(self, r):
+        a = np.array(r, dtype=np.float64).copy()
+        self.lib.so_rfftf(self.t, _p(a))
+        return a
+
+    def rfftb(self, r):
+        a = np.array(r, dtype=np.float64).copy()
+        self.lib.so_rfftb(self.t, _p(a))
+        return a
+
+    # ---- domain ----
+    def processor_decomposition(self, proc, numprocs, nregions):
+        buf = np.zeros(nregions // numprocs + 2, dtype=np.int32)
+        n = self.lib.rd_processor_decomposition(proc, numprocs, nregions, _pi(buf))
+        return buf[:n].copy()
+
+    def getxyresextent(self, num_regions, region):
+        v = [C.c_int() for _ in range(6)]
+        self.lib.rd_getxyresextent(num_regions, region, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)  # xs, xe, ys, ye, xchunk, ychunk
+
+    def initializedomain(self, num_regions, region, overlap=1, num_vert_levels=1, vert_level=1, vert_overlap=0):
+        g = RdGrid()
+        self.lib.rd_initializedomain(num_regions, region, overlap, num_vert_levels, vert_level, vert_overlap, C.byref(g))
+        return g
+
+    def allocate_sizes(self, g, m=6000, deg=6, local_predictvars=4, logp=1, precip=1, sst_input=1, tisr=1, ml_only=0):
+        s = RdSizes()
+        self.lib.rd_allocate_sizes(C.byref(g), m, deg, local_predictvars, logp, precip, sst_input, tisr, ml_only, C.byref(s))
+        return s
+
+    def tile_input(self, num_regions, region, grid4d, grid2d, precip, nout, overlap=1, nvl=1, vl=1, vo=0, precip_bool=1):
+        out = np.zeros(nout)
+        self.lib.rd_tile_input(num_regions, region, overlap, nvl, vl, vo, precip_bool,
+                               _p(grid4d), _p(grid2d), _p(precip), _p(out))
+        return out
+
+    def tile_input2d(self, num_regions, region, grid2d, nout, overlap=1):
+        out = np.zeros(nout)
+        self.lib.rd_tile_input2d(num_regions, region, overlap, _p(grid2d), _p(out))
+        return out
+
+    def scatter_res(self, num_regions, region, statevec, grid4d, grid2d, precip, nvl=1, vl=1, precip_bool=1):
+        sv = np.ascontiguousarray(statevec, dtype=np.float64)
+        self.lib.rd_scatter_res(num_regions, nvl, region, vl, precip_bool, sv.size, _p(sv), _p(grid4d), _p(grid2d), _p(precip))
+
+    def tile_res(self, num_regions, region, grid4d, grid2d, nout, nvl=1, vl=1):
+        out = np.zeros(nout)
+        self.lib.rd_tile_res(num_regions, nvl, region, vl, _p(grid4d), _p(grid2d), _p(out))
+        return out
+
+    def standardize_input(self, g, s, mean, std, vec, local_predictvars=4, logp=1):
+        v = np.array(vec, dtype=np.float64).copy()
+        self.lib.rd_standardize_input(C.byref(g), C.byref(s), local_predictvars, logp, _p(mean), _p(std), _p(v))
+        return v
+
+    def standardize_res(self, g, mean, std, vec, local_predictvars=4, heightlevels_input=8, logp=1):
+        v = np.array(vec, dtype=np.float64).copy()
+        self.lib.rd_standardize_res(C.byref(g), local_predictvars, heightlevels_input, logp, _p(mean), _p(std), _p(v))
+        return v
+
+    def unstandardize_res(self, g, mean, std, vec, logp_idx=33, precip_idx=35, local_predictvars=4,
+                          heightlevels_input=8, logp=1, precip=1):
+        v = np.array(vec, dtype=np.float64).copy()
+        self.lib.rd_unstandardize_res(C.byref(g), local_predictvars, heightlevels_input, logp, precip,
+                                      logp_idx, precip_idx, _p(mean), _p(std), _p(v))
+        return v
+
+    def radius_by_lat(self, a, b):
+        return self.lib.rd_get_radius_by_lat(a, b)
+
+    # ---- reservoir ----
+    def coo_mv(self, n, rows, cols, vals, x):
+        y = np.zeros(n)
+        self.lib.ro_coo_mv(n, len(vals), _pi(rows), _pi(cols), _p(vals), _p(x), _p(y))
+        return y
+
+    def synchronize(self, n, d, rows, cols, vals, win, leakage, inputs, x):
+        """inputs: (d, length) Fortran-ordered; win: (n, d) Fortran-ordered; returns new x."""
+        x = np.array(x, dtype=np.float64).copy()
+        inp = np.asfortranarray(inputs)
+        self.lib.ro_synchronize(n, d, len(vals), _pi(rows), _pi(cols), _p(vals), _p(np.asfortranarray(win)),
+                                C.c_double(leakage), _p(inp), inp.shape[1], _p(x))
+        return x
+
+    def predict_raw(self, n, d, n_model, n_out, rows, cols, vals, win, wout, leakage, feedback, local_model, x):
+        x = np.array(x, dtype=np.float64).copy()
+        out = np.zeros(n_out)
+        lm = np.zeros(1) if local_model is None else local_model
+        self.lib.ro_predict_raw(n, d, len(vals), n_model, n_out, _pi(rows), _pi(cols), _p(vals),
+                                _p(np.asfortranarray(win)), _p(np.asfortranarray(wout)), C.c_double(leakage),
+                                _p(feedback), _p(lm), _p(x), _p(out))
+        return x, out
+
+    def chunking_matmul(self, states, model, y, c, b):
+        n, m = states.shape
+        self.lib.ro_chunking_matmul(n, model.shape[0], y.shape[0], m, _p(np.asfortranarray(states)),
+                                    _p(np.asfortranarray(model)), _p(np.asfortranarray(y)), _p(c), _p(b))
+
+    def fit_chunk_hybrid(self, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, c, b):
+        wout = np.zeros((n_out, n + n_model), order="F")
+        self.lib.ro_fit_chunk_hybrid.restype = C.c_int
+        info = self.lib.ro_fit_chunk_hybrid(n, n_model, n_out, C.c_double(beta_res), C.c_double(beta_model),
+                                            C.c_double(prior_val), int(using_prior), _p(c), _p(b), _p(wout))
+        return info, wout
+
+    def train_states(self, n, d, rows, cols, vals, win, leakage, noisy_inputs, discard, batch, model, targets, c, b):
+        T = noisy_inputs.shape[1]
+        return self.lib.ro_train_states(n, d, len(vals), _pi(rows), _pi(cols), _p(vals), _p(np.asfortranarray(win)),
+                                        C.c_double(leakage), _p(np.asfortranarray(noisy_inputs)), T, discard, batch,
+                                        model.shape[0], targets.shape[0], _p(np.asfortranarray(model)),
+                                        _p(np.asfortranarray(targets)), _p(c), _p(b))
+
+    def find_closest_divisor(self, approx, number):
+        return self.lib.ro_find_closest_divisor(approx, number)
+
+
+class RefSpectral:
+    """The compiled reference spectral core (oracle/_ref/libref_spectral.so).  Optional."""
+
+    PATH = os.path.join(ORACLE_DIR, "_ref", "libref_spectral.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        self.lib = C.CDLL(self.PATH)
+        self.lib.ref_init.argtypes = [C.c_double]
+        self.lib.ref_get_table.argtypes = [C.c_int, _dp, C.c_int]
+        self.lib.ref_init(REARTH)
+
+    def table(self, which):
+        name, shape = TABLES[which]
+        n = int(np.prod(shape))
+        out = np.zeros(n)
+        self.lib.ref_get_table(which, _p(out), n)
+        return out.reshape(shape, order="F")
+
+    def tables(self):
+        return {TABLES[w][0]: self.table(w) for w in TABLES}
+
+    def _call(self, fn, ins, out_shapes, *extra):
+        ins = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F")).copy() for a in ins]
+        outs = [np.zeros(int(np.prod(s))) for s in out_shapes]
+        getattr(self.lib, fn)(*[_p(a) for a in ins], *[_p(o) for o in outs], *[C.c_int(e) for e in extra])
+        outs = [o.reshape(s, order="F") for o, s in zip(outs, out_shapes)]
+        return outs[0] if len(outs) == 1 else outs
+
+    def grid(self, vorm, kcos):
+        return self._call("ref_grid", [vorm], [(IX, IL)], kcos)
+
+    def spec(self, vorg):
+        return self._call("ref_spec", [vorg], [(MX2, NX)])
+
+    def gridy(self, v):
+        return self._call("ref_gridy", [v], [(MX2, IL)])
+
+    def gridx(self, varm, kcos):
+        return self._call("ref_gridx", [varm], [(IX, IL)], kcos)
+
+    def specx(self, vorg):
+        return self._call("ref_specx", [vorg], [(MX2, IL)])
+
+    def specy(self, varm):
+        return self._call("ref_specy", [varm], [(MX2, NX)])
+
+    def vdspec(self, ug, vg, kcos):
+        return self._call("ref_vdspec", [ug, vg], [(MX2, NX), (MX2, NX)], kcos)
+
+    def uvspec(self, vorm, divm):
+        return self._call("ref_uvspec", [vorm, divm], [(MX2, NX), (MX2, NX)])
+
+    def vds(self, u, v):
+        return self._call("ref_vds", [u, v], [(MX2, NX), (MX2, NX)])
+
+    def grad(self, psi):
+        return self._call("ref_grad", [psi], [(MX2, NX), (MX2, NX)])
+
+    def lap(self, s):
+        return self._call("ref_lap", [s], [(MX2, NX)])
+
+    def invlap(self, v):
+        return self._call("ref_invlap", [v], [(MX2, NX)])
+
+    def trunct(self, v):
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel(order="F")).copy()
+        self.lib.ref_trunct(_p(a))
+        return a.reshape((MX2, NX), order="F")
+
+    def rfftf(self, r):
+        a = np.array(r, dtype=np.float64).copy()
+        self.lib.ref_rfftf(_p(a))
+        return a
+
+    def rfftb(self, r):
+        a = np.array(r, dtype=np.float64).copy()
+        self.lib.ref_rfftb(_p(a))
+        return a
