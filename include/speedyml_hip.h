@@ -1,0 +1,236 @@
+/* speedyml_hip.h -- C-ABI of libspeedyml_hip.so, the MI355X (gfx950) implementation of the SPEEDY-ML
+ * hybrid-step hot path.  Plain C: pointers, sizes and opaque handles only (no C++/torch types), so it
+ * binds from Fortran (iso_c_binding -- see speedy-ml_amd/fortran/ and INTEGRATION.md), ctypes, cgo...
+ *
+ * Each entry point names the reference interface it replaces (file:line relative to the reference
+ * repository root).  Conventions:
+ *   - every function returns 0 on success, a negative sml_status otherwise; sml_last_error() gives text.
+ *     (The reference has no error propagation -- MKL/LAPACK `info` is printed, then `stop`,
+ *     src/mod_linalg.f90:18-22,147-150 -- the Fortran wrappers print sml_last_error() and `stop`.)
+ *   - "host" pointers are ordinary CPU memory (what the Fortran driver owns); "dev" pointers are HIP
+ *     device memory.  Arrays keep the reference's Fortran layout (column-major, 1-based index VALUES
+ *     inside rows/cols) at the boundary; the library re-lays them out in HBM once, at load.
+ *   - all floating point is IEEE fp64, all indices int32 (the reference's default integer).
+ *   - stream arguments are hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef SPEEDYML_HIP_H
+#define SPEEDYML_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sml_status {
+    SML_OK = 0,
+    SML_ERR_ARG = -1,      /* bad argument / shape mismatch */
+    SML_ERR_HIP = -2,      /* a HIP runtime call failed (no device, OOM, launch failure) */
+    SML_ERR_STATE = -3,    /* call order violated (e.g. predict before load) */
+    SML_ERR_NUMERIC = -4   /* singular matrix in the ridge solve (dgesv info > 0) */
+} sml_status;
+
+const char *sml_last_error(void);
+int sml_version(void);
+/* number of visible HIP devices (0 on a CPU-only box; never initialises a context) */
+int sml_device_count(void);
+int sml_set_device(int ordinal);
+
+/* ===================================================================================================
+ * 1. resdomain: integer bookkeeping (host only, no GPU needed) -- replaces src/res_domain.f90
+ * =================================================================================================== */
+typedef struct sml_region {
+    /* 1-based inclusive extents exactly as grid_type holds them (src/mod_utilities.f90 grid_type) */
+    int32_t res_xstart, res_xend, res_ystart, res_yend, resxchunk, resychunk;
+    int32_t res_zstart, res_zend, reszchunk;
+    int32_t input_xstart, input_xend, input_ystart, input_yend, inputxchunk, inputychunk;
+    int32_t input_zstart, input_zend, inputzchunk;
+    int32_t pole, periodicboundary, top, bottom;
+    int32_t tdata_xstart, tdata_xend, tdata_ystart, tdata_yend, tdata_zstart, tdata_zend;
+} sml_region;
+
+typedef struct sml_res_sizes {
+    /* integer results of allocate_res_new (src/mod_reservoir.f90:80-180) and the u(t) segment offsets of
+     * trained_reservoir_prediction (:1851-1885); offsets 1-based inclusive, 0/0 when the segment is absent */
+    int32_t chunk_size, chunk_size_prediction, chunk_size_speedy, locality;
+    int32_t nodes_per_input, n, k, reservoir_numinputs;
+    int32_t atmo3d_start, atmo3d_end, logp_start, logp_end, precip_start, precip_end;
+    int32_t sst_start, sst_end, tisr_start, tisr_end;
+} sml_res_sizes;
+
+/* processor_decomposition / processor_decomposition_manual (src/res_domain.f90:31-94).
+ * Writes the regions owned by `rank`; returns their count (or <0). */
+int sml_domain_decompose(int rank, int nranks, int number_of_regions, int32_t *region_indices, int capacity);
+/* initializedomain (src/res_domain.f90:96-121) and everything it calls (:123-292, :547-600) */
+int sml_domain_region(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
+                      int vert_overlap, sml_region *out);
+/* allocate_res_new sizing (src/mod_reservoir.f90:80-180) */
+int sml_domain_sizes(const sml_region *g, int m, int deg, int local_predictvars, int logp_bool, int precip_bool,
+                     int sst_bool_input, int tisr_input_bool, int ml_only, sml_res_sizes *out);
+
+/* Global state buffer ("G") layout used by the device-resident step loop (doubles):
+ *   [0, 147456)            grid4d(4,96,48,8)  Fortran order: ((z*48+y)*96+x)*4+v
+ *   [147456, +4608)        logp(96,48)        y*96+x
+ *   [152064, +4608)        precip(96,48)
+ *   [156672, +4608)        sst(96,48)
+ *   [161280, +4608)        tisr(96,48)        (current hour's slice)
+ */
+enum { SML_G4_OFF = 0, SML_G2_OFF = 147456, SML_GP_OFF = 152064, SML_GS_OFF = 156672, SML_GT_OFF = 161280,
+       SML_G_SIZE = 165888 };
+
+/* Index maps that replace the slice-and-reshape tilers by precomputed gathers/scatters:
+ *  - out map: outvec element i of region r -> index into G.  Same ordering as
+ *    tile_full_grid_with_local_state_vec_res1d (src/res_domain.f90:791-826); its first chunk_size_speedy
+ *    entries are also the gather map of tile_4d_and_logp_full_grid_to_local_res_vec (:1022-1053).
+ *    stat_idx[i] = 0-based slot of mean/std used by (un)standardize_state_vec_res (:1270-1315,:1424-1475).
+ *  - in map: input element j of region r -> index into G, ordering of
+ *    tile_4d_and_logp_to_local_state_input (:1081-1125) followed by the sst and tisr segments
+ *    (src/mpires.f90:586-599,752-773); stat_idx as used by standardize_state_vec_input (:1211-1268) and the
+ *    precip/sst/tisr standardisation (src/mpires.f90:765-773).
+ * Both return the number of entries written (or <0). */
+int sml_domain_out_map(int number_of_regions, int region_num, int num_vert_levels, int vert_level, int vert_overlap,
+                       int precip_bool, int32_t *g_index, int32_t *stat_idx, int capacity);
+int sml_domain_in_map(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
+                      int vert_overlap, int precip_bool, int sst_bool_input, int tisr_input_bool,
+                      int32_t *g_index, int32_t *stat_idx, int capacity);
+
+/* ===================================================================================================
+ * 2. reservoir bank: all reservoirs of one rank resident in HBM -- replaces the per-reservoir state of
+ *    reservoir_type (src/mod_utilities.f90) and predict/synchronize (src/mod_reservoir.f90)
+ * =================================================================================================== */
+typedef struct sml_bank sml_bank;
+
+/* capacity = number of reservoir slots; strides bound the per-slot feedback / local_model / outvec vectors */
+int sml_bank_create(int capacity, int max_d, int max_n_model, int max_n_out, sml_bank **out);
+int sml_bank_destroy(sml_bank *bank);
+
+/* Load one trained reservoir into `slot`: what read_trained_res + allocate_res_new + mklsparse leave in
+ * reservoir_type (src/mod_reservoir.f90:1783-1886, src/mod_linalg.f90:10-25).
+ *   rows/cols/vals : COO, 1-based, unsorted, duplicates allowed (they accumulate, as in MKL_SPARSE_D_MV)
+ *   win            : dense (n,d) column-major as the reference stores it; exact zeros are dropped at load
+ *   wout           : (n_out, n_model+n) column-major
+ *   mean/std       : nstat entries (36 for the atmosphere reservoirs)
+ *   out_stat_idx   : n_out 0-based slots into mean/std for the fused un-standardisation (from sml_domain_out_map)
+ */
+int sml_bank_load(sml_bank *bank, int slot, int n, int d, int k, int n_model, int n_out,
+                  const int32_t *rows, const int32_t *cols, const double *vals,
+                  const double *win, const double *wout, double leakage,
+                  const double *mean, const double *std, int nstat, const int32_t *out_stat_idx);
+/* Same, with W_in given as COO triplets (1-based) instead of the 26.5 MB dense array. */
+int sml_bank_load_sparse_win(sml_bank *bank, int slot, int n, int d, int k, int n_model, int n_out,
+                             const int32_t *rows, const int32_t *cols, const double *vals,
+                             int win_nnz, const int32_t *win_rows, const int32_t *win_cols, const double *win_vals,
+                             const double *wout, double leakage,
+                             const double *mean, const double *std, int nstat, const int32_t *out_stat_idx);
+/* replace W_out of a slot (after training) */
+int sml_bank_set_wout(sml_bank *bank, int slot, const double *wout);
+
+/* host <-> device state access (x = reservoir state, in/out of predict; mod_reservoir.f90:1418) */
+int sml_bank_set_state(sml_bank *bank, int slot, const double *x_host);
+int sml_bank_get_state(sml_bank *bank, int slot, double *x_host);
+int sml_bank_set_feedback(sml_bank *bank, int slot, const double *u_host);          /* reservoir%feedback(d) */
+int sml_bank_set_local_model(sml_bank *bank, int slot, const double *lm_host);     /* reservoir%local_model */
+int sml_bank_get_outvec(sml_bank *bank, int slot, double *out_host);               /* reservoir%outvec */
+
+/* device views for the resident loop: [capacity][stride] row-major */
+double *sml_bank_feedback_dev(sml_bank *bank);    /* stride max_d */
+double *sml_bank_local_model_dev(sml_bank *bank); /* stride max_n_model */
+double *sml_bank_outvec_dev(sml_bank *bank);      /* stride max_n_out */
+
+/* predict (src/mod_reservoir.f90:1418-1489) for EVERY loaded slot in one batched pass:
+ *   x <- (1-leak) x + leak tanh(A x + Win u);  outvec <- unstandardize(Wout [local_model ; x with even entries squared])
+ * flags: bit0 = skip the un-standardisation (raw W_out product, for tests). */
+int sml_bank_predict_all(sml_bank *bank, int flags, void *stream);
+/* predict for one slot with the reference's calling shape (x in/out on the host) -- the drop-in for a
+ * per-region call from program main (src/parallelmain.f90:233). */
+int sml_bank_predict_one(sml_bank *bank, int slot, double *x_inout_host, const double *local_model_host,
+                         double *outvec_host);
+/* synchronize (src/mod_reservoir.f90:1354-1381) for every loaded slot: `length` teacher-forced steps.
+ * inputs_dev: [length][capacity][max_d] (step-major) device array. */
+int sml_bank_synchronize_all(sml_bank *bank, const double *inputs_dev, int length, void *stream);
+/* one advance without readout (K1-K3) for every slot, feedback taken from the bank */
+int sml_bank_advance_all(sml_bank *bank, void *stream);
+
+/* byte accounting for the roofline (algorithmic bytes as defined in DESIGN.md) */
+int sml_bank_algorithmic_bytes(sml_bank *bank, uint64_t *update_bytes, uint64_t *readout_bytes);
+
+/* ===================================================================================================
+ * 3. exchange: the device-resident form of sendrecievegrid (src/mpires.f90:218-804) without MPI/NetCDF
+ * =================================================================================================== */
+typedef struct sml_exchange sml_exchange;
+
+/* Build the per-slot index maps for the regions resident in `bank` (region_of_slot[capacity]). */
+int sml_exchange_create(sml_bank *bank, int number_of_regions, const int32_t *region_of_slot, int nslots,
+                        int overlap, int precip_bool, const int32_t *sst_input_of_slot /* 0/1 per slot */,
+                        sml_exchange **out);
+int sml_exchange_destroy(sml_exchange *ex);
+/* outvec slab of this rank -> global slab position (for the all-gather) then G: scatter + clamps (Appendix G 2-3,
+ * src/mpires.f90:309-330,460-490).  all_outvec_dev: [number_of_regions][max_n_out] in REGION order. */
+int sml_exchange_scatter(sml_exchange *ex, const double *all_outvec_dev, double *g_dev,
+                         const double *base_sst_dev /* 4608 or NULL */, const int32_t *sea_mask_dev /* 4608 or NULL */,
+                         void *stream);
+/* G (+ current TISR slice already in G) -> standardised feedback of every slot; forecast F (same layout as the
+ * first two parts of G) -> standardised local_model of every slot (Appendix G 5-6, src/mpires.f90:580-775). */
+int sml_exchange_gather(sml_exchange *ex, const double *g_dev, const double *f_dev, void *stream);
+/* where each slot's outvec goes in the region-ordered slab: offset = region*max_n_out */
+int sml_exchange_pack_outvec(sml_exchange *ex, double *all_outvec_dev, void *stream);
+
+/* ===================================================================================================
+ * 4. spectral transforms -- replaces src/spe_spectral.f90 + src/spe_subfft_fftpack.f90 (FFTPACK)
+ * =================================================================================================== */
+typedef struct sml_spectral sml_spectral;
+/* parmtr(a) + inifft (src/spe_spectral.f90:45-192, src/spe_subfft_fftpack.f90:1-12): tables built on the host in
+ * fp64 and uploaded once. */
+int sml_spectral_create(double a, sml_spectral **out);
+int sml_spectral_destroy(sml_spectral *sp);
+/* copy a table back to the host (numbering as in oracle/ref_spectral_driver.f90: 1 sia .. 24 cpol) */
+int sml_spectral_get_table(sml_spectral *sp, int which, double *out_host, int capacity);
+
+/* Batched device entry points: nf fields per launch (never one transform per launch).
+ *   spec arrays: [nf][32][62] (= Fortran vorm(mx2,nx) per field), grid arrays: [nf][48][96] (= vorg(ix,il)).
+ *   kcos: per call (1 or 2), as in grid(vorm,vorg,kcos) (src/spe_spectral.f90:389-401). */
+int sml_spectral_grid(sml_spectral *sp, const double *vorm_dev, double *vorg_dev, int nf, int kcos, void *stream);
+int sml_spectral_spec(sml_spectral *sp, const double *vorg_dev, double *vorm_dev, int nf, void *stream);      /* :403-414 */
+int sml_spectral_vdspec(sml_spectral *sp, const double *ug_dev, const double *vg_dev, double *vorm_dev,
+                        double *divm_dev, int nf, int kcos, void *stream);                                    /* :416-452 */
+int sml_spectral_uvspec(sml_spectral *sp, const double *vorm_dev, const double *divm_dev, double *ucosm_dev,
+                        double *vcosm_dev, int nf, void *stream);                                             /* :351-387 */
+int sml_spectral_vds(sml_spectral *sp, const double *ucosm_dev, const double *vcosm_dev, double *vorm_dev,
+                     double *divm_dev, int nf, void *stream);                                                 /* :307-349 */
+int sml_spectral_grad(sml_spectral *sp, const double *psi_dev, double *psdx_dev, double *psdy_dev, int nf, void *stream); /* :271-305 */
+int sml_spectral_lap(sml_spectral *sp, const double *strm_dev, double *vorm_dev, int nf, void *stream);      /* :244-254 */
+int sml_spectral_invlap(sml_spectral *sp, const double *vorm_dev, double *strm_dev, int nf, void *stream);   /* :256-269 */
+int sml_spectral_trunct(sml_spectral *sp, double *vor_dev, int nf, void *stream);                             /* :540-551 */
+
+/* Link-level drop-ins with the reference's external F77 symbols (trailing underscore, everything by
+ * reference, host arrays): src/spe_spectral.f90:244-551.  They use a process-global sml_spectral created
+ * by parmtr_()/inifft_(). */
+void parmtr_(const double *a);
+void inifft_(void);
+void grid_(const double *vorm, double *vorg, const int *kcos);
+void spec_(const double *vorg, double *vorm);
+void vdspec_(const double *ug, const double *vg, double *vorm, double *divm, const int *kcos);
+void uvspec_(const double *vorm, const double *divm, double *ucosm, double *vcosm);
+void vds_(const double *ucosm, const double *vcosm, double *vorm, double *divm);
+void grad_(const double *psi, double *psdx, double *psdy);
+void lap_(const double *strm, double *vorm);
+void invlap_(const double *vorm, double *strm);
+void trunct_(double *vor);
+
+/* ===================================================================================================
+ * 5. training -- replaces chunking_matmul / fit_chunk_hybrid / mldivide
+ *    (src/mod_reservoir.f90:1645-1701, 1235-1334; src/mod_linalg.f90:109-151)
+ * =================================================================================================== */
+/* C(n_aug,n_aug) += aug*aug^T and B(n_out,n_aug) += Y*aug^T with aug = [model ; states], fp64 MFMA.
+ * All device, column-major as in the reference: states (n,m), model (n_model,m), y (n_out,m). */
+int sml_train_accumulate(const double *states_dev, const double *model_dev, const double *y_dev,
+                         int n, int n_model, int n_out, int m, double *c_dev, double *b_dev, void *stream);
+/* fit_chunk_hybrid: regularise the diagonal, solve C^T Z = (B+prior)^T by LU with partial pivoting, wout = Z^T.
+ * c_dev is overwritten by its LU factors.  wout_dev: (n_out, n_aug) column-major. */
+int sml_train_fit(double *c_dev, const double *b_dev, int n, int n_model, int n_out, double beta_res, double beta_model,
+                  double prior_val, int using_prior, double *wout_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

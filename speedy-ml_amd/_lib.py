@@ -1,0 +1,114 @@
+"""ctypes loader for csrc/libspeedyml_hip.so (the C-ABI declared in include/speedyml_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a HIP call fails, the caller gets an
+exception carrying sml_last_error().
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libspeedyml_hip.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+_lib = None
+
+
+class SmlError(RuntimeError):
+    pass
+
+
+class Region(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "res_xstart", "res_xend", "res_ystart", "res_yend", "resxchunk", "resychunk",
+        "res_zstart", "res_zend", "reszchunk",
+        "input_xstart", "input_xend", "input_ystart", "input_yend", "inputxchunk", "inputychunk",
+        "input_zstart", "input_zend", "inputzchunk",
+        "pole", "periodicboundary", "top", "bottom",
+        "tdata_xstart", "tdata_xend", "tdata_ystart", "tdata_yend", "tdata_zstart", "tdata_zend")]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class ResSizes(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "chunk_size", "chunk_size_prediction", "chunk_size_speedy", "locality",
+        "nodes_per_input", "n", "k", "reservoir_numinputs",
+        "atmo3d_start", "atmo3d_end", "logp_start", "logp_end", "precip_start", "precip_end",
+        "sst_start", "sst_end", "tisr_start", "tisr_end")]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/speedyml_hip.h declares (checked by tests/test_cabi_symbols.py)
+EXPORTS = [
+    "sml_last_error", "sml_version", "sml_device_count", "sml_set_device",
+    "sml_domain_decompose", "sml_domain_region", "sml_domain_sizes", "sml_domain_out_map", "sml_domain_in_map",
+    "sml_bank_create", "sml_bank_destroy", "sml_bank_load", "sml_bank_load_sparse_win", "sml_bank_set_wout",
+    "sml_bank_set_state", "sml_bank_get_state", "sml_bank_set_feedback", "sml_bank_set_local_model",
+    "sml_bank_get_outvec", "sml_bank_feedback_dev", "sml_bank_local_model_dev", "sml_bank_outvec_dev",
+    "sml_bank_predict_all", "sml_bank_predict_one", "sml_bank_synchronize_all", "sml_bank_advance_all",
+    "sml_bank_algorithmic_bytes",
+    "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
+    "sml_exchange_pack_outvec",
+    "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",
+    "sml_spectral_spec", "sml_spectral_vdspec", "sml_spectral_uvspec", "sml_spectral_vds", "sml_spectral_grad",
+    "sml_spectral_lap", "sml_spectral_invlap", "sml_spectral_trunct",
+    "parmtr_", "inifft_", "grid_", "spec_", "vdspec_", "uvspec_", "vds_", "grad_", "lap_", "invlap_", "trunct_",
+    "sml_train_accumulate", "sml_train_fit",
+]
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmlError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; "
+                       "there is no CPU fallback for the product path")
+    L = C.CDLL(LIB_PATH)
+    L.sml_last_error.restype = C.c_char_p
+    for name in ("sml_bank_feedback_dev", "sml_bank_local_model_dev", "sml_bank_outvec_dev"):
+        getattr(L, name).restype = C.c_void_p
+        getattr(L, name).argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise SmlError(f"libspeedyml_hip: status {rc}: {lib().sml_last_error().decode()}")
+    return rc
+
+
+def dp(a):
+    """double* of a contiguous float64 numpy array, or a raw device address (int)."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.cast(C.c_void_p(int(a)), c_dp)
+    assert a.dtype == np.float64 and (a.flags.c_contiguous or a.flags.f_contiguous)
+    return a.ctypes.data_as(c_dp)
+
+
+def ip(a):
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.cast(C.c_void_p(int(a)), c_ip)
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_ip)
+
+
+def vp(stream):
+    """hipStream_t as void* from None | int | torch.cuda.Stream."""
+    if stream is None:
+        return C.c_void_p(0)
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))

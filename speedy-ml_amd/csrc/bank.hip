@@ -1,0 +1,548 @@
+// Reservoir bank: every local reservoir of one rank resident in HBM, stepped by two batched kernels.
+//
+// Replaces predict / predict_ml / synchronize (src/mod_reservoir.f90:1354-1535) and mklsparse /
+// smatrix_vector (src/mod_linalg.f90:10-25, 516-531).  What one reference `predict` call does per reservoir
+//     y = A x (MKL COO SpMV) ; temp = matmul(win, feedback) ; x = (1-leak) x + leak tanh(y+temp)
+//     outvec = matmul(wout, [local_model ; x with even entries squared]) ; unstandardize
+// becomes, for ALL resident reservoirs at once:
+//   k_update  : one sparse product with the fused operator [A | W_in] on [x ; u] in SELL-64 layout (rows sorted
+//               by length, 64-row slices stored column-major so a wavefront's loads are contiguous), x and u staged
+//               in LDS, tanh + leak fused, ping-pong state buffers.  HBM-bound: 12 B per nonzero.
+//   k_readout : W_out is re-laid out row-major; a 256-thread workgroup streams R=17 rows (17 x 47 KB) with
+//               16-byte loads, every lane keeping 17 partial sums so that 17 independent loads are in flight per
+//               lane; the augmented state is formed on the fly (local_model | x, odd 0-based entries squared);
+//               wavefront shuffle + LDS reduction; un-standardisation (multiply, then add -- two roundings, as
+//               src/mod_utilities.f90:667-831) fused into the epilogue.  HBM-bound: 8 B per W_out element.
+// W_in is kept as whatever nonzeros the dense (n,d) array holds (one per row as shipped,
+// src/mod_reservoir.f90:272-280); dropping exact zeros leaves every sum bit-identical.
+//
+// Workgroup -> (reservoir, part) mapping is XCD-aware: consecutive block ids are dealt round-robin over the 8 XCDs,
+// so block id b serves reservoir 8*(b/(8*parts)) + b%8; the `parts` workgroups that share one reservoir's x / x~
+// vector therefore share an XCD's L2.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct ResDesc {
+    int n, d, n_model, n_out, n_aug, n_aug_pad, nslices, loaded;
+    const int *slice_off;      // [nslices+1] first entry of each 64-row slice (entries are width*64 per slice)
+    const int *sell_col;       // column into [x ; u]
+    const double *sell_val;
+    const int *perm;           // sorted position -> original row (or -1 for the padding rows of the last slice)
+    const int *row_len;        // nonzeros of the row at each sorted position
+    double *x[2];              // ping-pong state
+    const double *wout;        // [n_out][n_aug_pad] row-major, zero padded
+    const double *mean, *stdv;
+    const int *out_stat;       // [n_out] slot into mean/std, <0 = leave as is
+    double leak;
+};
+
+struct HostRes {
+    std::vector<void *> allocs;
+    ResDesc desc{};
+    uint64_t update_bytes = 0, readout_bytes = 0;
+};
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int UPD_THREADS = 512;
+constexpr int RO_THREADS = 256;
+constexpr int RO_ROWS = 17;
+
+__device__ __forceinline__ void decode_block(int id, int parts, int res_begin, int &res, int &part)
+{
+    const int xcd = id & 7;
+    const int t = id >> 3;
+    part = t % parts;
+    res = res_begin + (t / parts) * 8 + xcd;
+}
+
+// x_new = (1-leak) x + leak tanh([A|Win] [x;u])        (src/mod_reservoir.f90:1444-1448)
+__global__ __launch_bounds__(UPD_THREADS) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
+                                                         int parts, const double *__restrict__ u_all, int u_stride, int cur)
+{
+    extern __shared__ __attribute__((aligned(16))) double xu[];
+    int res, part;
+    decode_block(blockIdx.x, parts, res_begin, res, part);
+    if (res >= res_end) return;
+    const ResDesc D = descs[res];
+    if (!D.loaded) return;
+    const double *__restrict__ x = D.x[cur];
+    double *__restrict__ xn = D.x[cur ^ 1];
+    const double *__restrict__ u = u_all + (size_t)res * u_stride;
+    for (int i = threadIdx.x; i < D.n; i += UPD_THREADS) xu[i] = x[i];
+    for (int i = threadIdx.x; i < D.d; i += UPD_THREADS) xu[D.n + i] = u[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = UPD_THREADS / 64;
+    for (int s = part * NW + wave; s < D.nslices; s += parts * NW) {
+        const int off = D.slice_off[s];
+        const int width = (D.slice_off[s + 1] - off) >> 6;
+        const int len = D.row_len[s * 64 + lane];
+        const int *__restrict__ cp = D.sell_col + off + lane;
+        const double *__restrict__ vp = D.sell_val + off + lane;
+        double acc = 0.0;
+        for (int j = 0; j < width; ++j) {
+            const int c = cp[j * 64];
+            const double v = vp[j * 64];
+            if (j < len) acc += v * xu[c];
+        }
+        const int r = D.perm[s * 64 + lane];
+        if (r >= 0) {
+            const double xt = tanh(acc);
+            xn[r] = (1.0 - D.leak) * xu[r] + D.leak * xt;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// outvec = unstandardize(Wout [local_model ; x~])      (src/mod_reservoir.f90:1450-1471)
+template <int R>
+__global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restrict__ descs, int res_begin, int res_end, int parts,
+                                                          const double *__restrict__ lm_all, int lm_stride,
+                                                          double *__restrict__ out_all, int out_stride, int cur, int flags)
+{
+    __shared__ double red[RO_THREADS / 64][R];
+    int res, grp;
+    decode_block(blockIdx.x, parts, res_begin, res, grp);
+    if (res >= res_end) return;
+    const ResDesc D = descs[res];
+    if (!D.loaded) return;
+    const int r0 = grp * R;
+    if (r0 >= D.n_out) return;
+    const double *__restrict__ x = D.x[cur];
+    const double *__restrict__ lm = lm_all + (size_t)res * lm_stride;
+    const size_t ld = (size_t)D.n_aug_pad;
+    const double *wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = D.wout + (size_t)min(r0 + r, D.n_out - 1) * ld;
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+
+    const bool aligned_model = (D.n_model & 1) == 0;
+    for (int kk = threadIdx.x * 2; kk < D.n_aug_pad; kk += RO_THREADS * 2) {
+        double a0, a1;
+        if (kk + 1 < D.n_model) { a0 = lm[kk]; a1 = lm[kk + 1]; }
+        else if (aligned_model && kk >= D.n_model && kk + 1 < D.n_aug) {
+            const double2 xv = *reinterpret_cast<const double2 *>(x + (kk - D.n_model));
+            a0 = xv.x; a1 = xv.y * xv.y;                    // 0-based odd entry == the reference's even (1-based) entry
+        } else {
+            auto aug = [&](int i) -> double {
+                if (i < D.n_model) return lm[i];
+                if (i >= D.n_aug) return 0.0;
+                const int j = i - D.n_model;
+                const double v = x[j];
+                return (j & 1) ? v * v : v;
+            };
+            a0 = aug(kk); a1 = aug(kk + 1);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // streamed once per step, 7.4 GB per sweep >> Infinity Cache: non-temporal 16-byte loads
+            const f64x2 w = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(wrow[r] + kk));
+            acc[r] += w[0] * a0;
+            acc[r] += w[1] * a1;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double s = wave_sum(acc[r]);
+        if (lane == 0) red[wave][r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < R) {
+        const int row = r0 + threadIdx.x;
+        if (row < D.n_out) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < RO_THREADS / 64; ++w) v += red[w][threadIdx.x];
+            if (!(flags & 1)) {
+                const int si = D.out_stat[row];
+                if (si >= 0) {
+                    // unstandardize_data_*: data*std, then +mean, two roundings (src/mod_utilities.f90:667-831)
+                    v = __dadd_rn(__dmul_rn(v, D.stdv[si]), D.mean[si]);
+                }
+            }
+            out_all[(size_t)res * out_stride + row] = v;
+        }
+    }
+}
+
+}  // namespace
+
+struct sml_bank {
+    int capacity = 0, max_d = 0, max_n_model = 0, max_n_out = 0;
+    int cur = 0;
+    int max_nd = 0;                 // LDS doubles needed by k_update
+    int max_parts_ro = 1;
+    std::vector<HostRes> res;
+    ResDesc *d_descs = nullptr;
+    double *d_feedback = nullptr, *d_local_model = nullptr, *d_outvec = nullptr;
+    bool descs_dirty = true;
+};
+
+namespace {
+
+int sync_descs(sml_bank *b)
+{
+    if (!b->descs_dirty) return SML_OK;
+    std::vector<ResDesc> h(b->capacity);
+    for (int i = 0; i < b->capacity; ++i) h[i] = b->res[i].desc;
+    SML_HIP(hipMemcpy(b->d_descs, h.data(), sizeof(ResDesc) * b->capacity, hipMemcpyHostToDevice));
+    b->descs_dirty = false;
+    return SML_OK;
+}
+
+void free_slot(HostRes &r)
+{
+    for (void *p : r.allocs) (void)hipFree(p);
+    r.allocs.clear();
+    r.desc = ResDesc{};
+}
+
+template <class T>
+int upload(HostRes &r, const T **dst, const std::vector<T> &src)
+{
+    T *p = nullptr;
+    int rc = sml::dev_upload(&p, src.data(), src.size());
+    if (rc) return rc;
+    r.allocs.push_back(p);
+    *dst = p;
+    return SML_OK;
+}
+
+int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int n_out,
+                const int32_t *rows, const int32_t *cols, const double *vals,
+                const std::vector<int> &wr, const std::vector<int> &wc, const std::vector<double> &wv,
+                const double *wout, double leakage, const double *mean, const double *stdv, int nstat,
+                const int32_t *out_stat_idx)
+{
+    SML_REQUIRE(bank, "sml_bank_load: null bank");
+    SML_REQUIRE(slot >= 0 && slot < bank->capacity, "sml_bank_load: slot %d out of range [0,%d)", slot, bank->capacity);
+    SML_REQUIRE(n > 0 && d > 0 && k >= 0 && n_model >= 0 && n_out > 0, "sml_bank_load: bad sizes n=%d d=%d k=%d n_model=%d n_out=%d", n, d, k, n_model, n_out);
+    SML_REQUIRE(d <= bank->max_d && n_model <= bank->max_n_model && n_out <= bank->max_n_out,
+                "sml_bank_load: d/n_model/n_out (%d,%d,%d) exceed the bank strides (%d,%d,%d)", d, n_model, n_out, bank->max_d, bank->max_n_model, bank->max_n_out);
+    SML_REQUIRE(rows && cols && vals && wout && mean && stdv && nstat > 0, "sml_bank_load: null array");
+    for (int e = 0; e < k; ++e)
+        SML_REQUIRE(rows[e] >= 1 && rows[e] <= n && cols[e] >= 1 && cols[e] <= n, "sml_bank_load: COO entry %d = (%d,%d) outside 1..%d", e, rows[e], cols[e], n);
+    for (int i = 0; i < n_out && out_stat_idx; ++i)
+        SML_REQUIRE(out_stat_idx[i] < nstat, "sml_bank_load: out_stat_idx[%d]=%d >= nstat=%d", i, out_stat_idx[i], nstat);
+
+    HostRes &R = bank->res[slot];
+    free_slot(R);
+
+    // ---- fused operator [A | Win] as CSR (A entries in COO storage order, then Win), then SELL-64 ----
+    std::vector<int> cnt(n, 0);
+    for (int e = 0; e < k; ++e) cnt[rows[e] - 1]++;
+    for (size_t e = 0; e < wr.size(); ++e) cnt[wr[e]]++;
+    std::vector<int> ptr(n + 1, 0);
+    for (int i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + cnt[i];
+    const int nnz = ptr[n];
+    std::vector<int> ccol(nnz);
+    std::vector<double> cval(nnz);
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int e = 0; e < k; ++e) { int p = fill[rows[e] - 1]++; ccol[p] = cols[e] - 1; cval[p] = vals[e]; }
+    for (size_t e = 0; e < wr.size(); ++e) { int p = fill[wr[e]]++; ccol[p] = n + wc[e]; cval[p] = wv[e]; }
+
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+    const int nslices = (n + 63) / 64;
+    std::vector<int> slice_off(nslices + 1, 0), perm(nslices * 64, -1), row_len(nslices * 64, 0);
+    for (int s = 0; s < nslices; ++s) {
+        int width = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int pos = s * 64 + l;
+            if (pos < n) { perm[pos] = order[pos]; row_len[pos] = cnt[order[pos]]; width = std::max(width, cnt[order[pos]]); }
+        }
+        slice_off[s + 1] = slice_off[s] + width * 64;
+    }
+    std::vector<int> scol(slice_off[nslices], 0);
+    std::vector<double> sval(slice_off[nslices], 0.0);
+    for (int s = 0; s < nslices; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const int pos = s * 64 + l;
+            if (pos >= n) continue;
+            const int r = order[pos];
+            for (int j = 0; j < cnt[r]; ++j) {
+                scol[slice_off[s] + j * 64 + l] = ccol[ptr[r] + j];
+                sval[slice_off[s] + j * 64 + l] = cval[ptr[r] + j];
+            }
+        }
+
+    // ---- W_out: (n_out, n_aug) column-major -> [n_out][n_aug_pad] row-major ----
+    const int n_aug = n + n_model, n_aug_pad = (n_aug + 1) & ~1;
+    std::vector<double> wrm((size_t)n_out * n_aug_pad, 0.0);
+    for (int j = 0; j < n_aug; ++j)
+        for (int i = 0; i < n_out; ++i) wrm[(size_t)i * n_aug_pad + j] = wout[(size_t)j * n_out + i];
+
+    std::vector<double> hmean(mean, mean + nstat), hstd(stdv, stdv + nstat), zeros(n, 0.0);
+    std::vector<int> hstat(n_out, -1);
+    if (out_stat_idx) hstat.assign(out_stat_idx, out_stat_idx + n_out);
+
+    ResDesc D{};
+    D.n = n; D.d = d; D.n_model = n_model; D.n_out = n_out; D.n_aug = n_aug; D.n_aug_pad = n_aug_pad; D.nslices = nslices;
+    D.leak = leakage;
+    int rc;
+    if ((rc = upload(R, &D.slice_off, slice_off))) return rc;
+    if ((rc = upload(R, &D.sell_col, scol))) return rc;
+    if ((rc = upload(R, &D.sell_val, sval))) return rc;
+    if ((rc = upload(R, &D.perm, perm))) return rc;
+    if ((rc = upload(R, &D.row_len, row_len))) return rc;
+    if ((rc = upload(R, &D.wout, wrm))) return rc;
+    if ((rc = upload(R, &D.mean, hmean))) return rc;
+    if ((rc = upload(R, &D.stdv, hstd))) return rc;
+    if ((rc = upload(R, &D.out_stat, hstat))) return rc;
+    const double *x0 = nullptr, *x1 = nullptr;
+    if ((rc = upload(R, &x0, zeros))) return rc;
+    if ((rc = upload(R, &x1, zeros))) return rc;
+    D.x[0] = const_cast<double *>(x0); D.x[1] = const_cast<double *>(x1);
+    D.loaded = 1;
+    R.desc = D;
+    // algorithmic bytes: nonzeros*(8+4) + slice table + x read + x write + u ; W_out + x~ + outvec
+    // A as CSR k*(8+4)+(n+1)*4 ; x read+write 2*n*8 ; W_in nonzeros 8 B each ; u d*8
+    R.update_bytes = (uint64_t)k * 12 + (uint64_t)(n + 1) * 4 + (uint64_t)n * 16 + (uint64_t)wr.size() * 8 + (uint64_t)d * 8;
+    // W_out n_out*n_aug*8 ; local_model + outvec + mean/std
+    R.readout_bytes = (uint64_t)n_out * n_aug * 8 + (uint64_t)(n_model + n_out + 2 * nstat) * 8;
+    bank->max_nd = std::max(bank->max_nd, n + d);
+    bank->max_parts_ro = std::max(bank->max_parts_ro, (n_out + RO_ROWS - 1) / RO_ROWS);
+    bank->descs_dirty = true;
+    return SML_OK;
+}
+
+int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st)
+{
+    const int parts = 2;
+    const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
+    const size_t lds = (size_t)b->max_nd * sizeof(double);
+    SML_REQUIRE(lds <= 160 * 1024, "reservoir too large for the LDS-staged update (n+d=%d)", b->max_nd);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SML_HIP(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_update, dim3(nres8 * parts), dim3(UPD_THREADS), lds, st, b->d_descs, res_begin, res_end, parts,
+                       u_all, b->max_d, b->cur);
+    SML_HIP(hipGetLastError());
+    b->cur ^= 1;
+    return SML_OK;
+}
+
+int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream_t st)
+{
+    const int parts = b->max_parts_ro;
+    const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_readout<RO_ROWS>, dim3(nres8 * parts), dim3(RO_THREADS), 0, st, b->d_descs, res_begin, res_end, parts,
+                       b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sml_last_error(void) { return sml::last_error_ref().c_str(); }
+int sml_version(void) { return 100; }
+
+int sml_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sml_set_device(int ordinal)
+{
+    SML_HIP(hipSetDevice(ordinal));
+    return SML_OK;
+}
+
+int sml_bank_create(int capacity, int max_d, int max_n_model, int max_n_out, sml_bank **out)
+{
+    SML_REQUIRE(out && capacity > 0 && max_d > 0 && max_n_model >= 0 && max_n_out > 0, "sml_bank_create: bad arguments");
+    sml_bank *b = new sml_bank;
+    b->capacity = capacity; b->max_d = max_d; b->max_n_model = std::max(max_n_model, 1); b->max_n_out = max_n_out;
+    b->res.resize(capacity);
+    int rc;
+    if ((rc = sml::dev_zeros(&b->d_descs, (size_t)capacity)) || (rc = sml::dev_zeros(&b->d_feedback, (size_t)capacity * b->max_d)) ||
+        (rc = sml::dev_zeros(&b->d_local_model, (size_t)capacity * b->max_n_model)) ||
+        (rc = sml::dev_zeros(&b->d_outvec, (size_t)capacity * b->max_n_out))) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return SML_OK;
+}
+
+int sml_bank_destroy(sml_bank *b)
+{
+    if (!b) return SML_OK;
+    for (auto &r : b->res) free_slot(r);
+    (void)hipFree(b->d_descs); (void)hipFree(b->d_feedback); (void)hipFree(b->d_local_model); (void)hipFree(b->d_outvec);
+    delete b;
+    return SML_OK;
+}
+
+int sml_bank_load(sml_bank *bank, int slot, int n, int d, int k, int n_model, int n_out,
+                  const int32_t *rows, const int32_t *cols, const double *vals,
+                  const double *win, const double *wout, double leakage,
+                  const double *mean, const double *stdv, int nstat, const int32_t *out_stat_idx)
+{
+    SML_REQUIRE(win, "sml_bank_load: null win");
+    SML_REQUIRE(n > 0 && d > 0, "sml_bank_load: bad sizes");
+    // keep the nonzeros of the dense (n,d) column-major W_in, column by column (src/mod_reservoir.f90:272-280)
+    std::vector<int> wr, wc;
+    std::vector<double> wv;
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < n; ++i) {
+            const double v = win[(size_t)j * n + i];
+            if (v != 0.0) { wr.push_back(i); wc.push_back(j); wv.push_back(v); }
+        }
+    return load_common(bank, slot, n, d, k, n_model, n_out, rows, cols, vals, wr, wc, wv, wout, leakage, mean, stdv, nstat, out_stat_idx);
+}
+
+int sml_bank_load_sparse_win(sml_bank *bank, int slot, int n, int d, int k, int n_model, int n_out,
+                             const int32_t *rows, const int32_t *cols, const double *vals,
+                             int win_nnz, const int32_t *win_rows, const int32_t *win_cols, const double *win_vals,
+                             const double *wout, double leakage,
+                             const double *mean, const double *stdv, int nstat, const int32_t *out_stat_idx)
+{
+    SML_REQUIRE(win_nnz >= 0 && (win_nnz == 0 || (win_rows && win_cols && win_vals)), "sml_bank_load_sparse_win: null W_in triplets");
+    std::vector<int> wr(win_nnz), wc(win_nnz);
+    std::vector<double> wv(win_nnz);
+    for (int e = 0; e < win_nnz; ++e) {
+        SML_REQUIRE(win_rows[e] >= 1 && win_rows[e] <= n && win_cols[e] >= 1 && win_cols[e] <= d, "sml_bank_load_sparse_win: W_in entry %d out of range", e);
+        wr[e] = win_rows[e] - 1; wc[e] = win_cols[e] - 1; wv[e] = win_vals[e];
+    }
+    return load_common(bank, slot, n, d, k, n_model, n_out, rows, cols, vals, wr, wc, wv, wout, leakage, mean, stdv, nstat, out_stat_idx);
+}
+
+#define BANK_SLOT(bank, slot)                                                                                  \
+    SML_REQUIRE(bank, "null bank");                                                                            \
+    SML_REQUIRE(slot >= 0 && slot < bank->capacity, "slot %d out of range [0,%d)", slot, bank->capacity);      \
+    if (!bank->res[slot].desc.loaded) return sml::fail(SML_ERR_STATE, "slot %d has no reservoir loaded", slot); \
+    const ResDesc &D = bank->res[slot].desc
+
+int sml_bank_set_wout(sml_bank *bank, int slot, const double *wout)
+{
+    BANK_SLOT(bank, slot);
+    SML_REQUIRE(wout, "sml_bank_set_wout: null wout");
+    std::vector<double> wrm((size_t)D.n_out * D.n_aug_pad, 0.0);
+    for (int j = 0; j < D.n_aug; ++j)
+        for (int i = 0; i < D.n_out; ++i) wrm[(size_t)i * D.n_aug_pad + j] = wout[(size_t)j * D.n_out + i];
+    SML_HIP(hipMemcpy(const_cast<double *>(D.wout), wrm.data(), wrm.size() * sizeof(double), hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+int sml_bank_set_state(sml_bank *bank, int slot, const double *x)
+{
+    BANK_SLOT(bank, slot);
+    SML_HIP(hipMemcpy(D.x[bank->cur], x, sizeof(double) * D.n, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+int sml_bank_get_state(sml_bank *bank, int slot, double *x)
+{
+    BANK_SLOT(bank, slot);
+    SML_HIP(hipMemcpy(x, D.x[bank->cur], sizeof(double) * D.n, hipMemcpyDeviceToHost));
+    return SML_OK;
+}
+
+int sml_bank_set_feedback(sml_bank *bank, int slot, const double *u)
+{
+    BANK_SLOT(bank, slot);
+    SML_HIP(hipMemcpy(bank->d_feedback + (size_t)slot * bank->max_d, u, sizeof(double) * D.d, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+int sml_bank_set_local_model(sml_bank *bank, int slot, const double *lm)
+{
+    BANK_SLOT(bank, slot);
+    if (D.n_model) SML_HIP(hipMemcpy(bank->d_local_model + (size_t)slot * bank->max_n_model, lm, sizeof(double) * D.n_model, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+int sml_bank_get_outvec(sml_bank *bank, int slot, double *out)
+{
+    BANK_SLOT(bank, slot);
+    SML_HIP(hipMemcpy(out, bank->d_outvec + (size_t)slot * bank->max_n_out, sizeof(double) * D.n_out, hipMemcpyDeviceToHost));
+    return SML_OK;
+}
+
+double *sml_bank_feedback_dev(sml_bank *b) { return b ? b->d_feedback : nullptr; }
+double *sml_bank_local_model_dev(sml_bank *b) { return b ? b->d_local_model : nullptr; }
+double *sml_bank_outvec_dev(sml_bank *b) { return b ? b->d_outvec : nullptr; }
+
+int sml_bank_advance_all(sml_bank *b, void *stream)
+{
+    SML_REQUIRE(b, "null bank");
+    int rc = sync_descs(b);
+    if (rc) return rc;
+    return launch_update(b, 0, b->capacity, b->d_feedback, sml::as_stream(stream));
+}
+
+int sml_bank_predict_all(sml_bank *b, int flags, void *stream)
+{
+    SML_REQUIRE(b, "null bank");
+    int rc = sync_descs(b);
+    if (rc) return rc;
+    if ((rc = launch_update(b, 0, b->capacity, b->d_feedback, sml::as_stream(stream)))) return rc;
+    return launch_readout(b, 0, b->capacity, flags, sml::as_stream(stream));
+}
+
+int sml_bank_predict_one(sml_bank *bank, int slot, double *x_inout, const double *lm, double *outvec)
+{
+    BANK_SLOT(bank, slot);
+    SML_REQUIRE(x_inout && outvec, "sml_bank_predict_one: null array");
+    int rc = sync_descs(bank);
+    if (rc) return rc;
+    // every slot shares the ping-pong parity: stage x into the *current* buffer of this slot, step only this slot,
+    // then copy the new state into BOTH buffers so that the slot is consistent whatever the bank parity is.
+    SML_HIP(hipMemcpy(D.x[bank->cur], x_inout, sizeof(double) * D.n, hipMemcpyHostToDevice));
+    if (D.n_model && lm) SML_HIP(hipMemcpy(bank->d_local_model + (size_t)slot * bank->max_n_model, lm, sizeof(double) * D.n_model, hipMemcpyHostToDevice));
+    const int before = bank->cur;
+    if ((rc = launch_update(bank, slot, slot + 1, bank->d_feedback, nullptr))) return rc;
+    if ((rc = launch_readout(bank, slot, slot + 1, 0, nullptr))) return rc;
+    SML_HIP(hipMemcpy(x_inout, D.x[bank->cur], sizeof(double) * D.n, hipMemcpyDeviceToHost));
+    SML_HIP(hipMemcpy(D.x[before], D.x[bank->cur], sizeof(double) * D.n, hipMemcpyDeviceToDevice));
+    bank->cur = before;
+    SML_HIP(hipMemcpy(outvec, bank->d_outvec + (size_t)slot * bank->max_n_out, sizeof(double) * D.n_out, hipMemcpyDeviceToHost));
+    return SML_OK;
+}
+
+int sml_bank_synchronize_all(sml_bank *b, const double *inputs_dev, int length, void *stream)
+{
+    SML_REQUIRE(b && inputs_dev && length >= 0, "sml_bank_synchronize_all: bad arguments");
+    int rc = sync_descs(b);
+    if (rc) return rc;
+    const size_t step = (size_t)b->capacity * b->max_d;
+    for (int t = 0; t < length; ++t)
+        if ((rc = launch_update(b, 0, b->capacity, inputs_dev + step * t, sml::as_stream(stream)))) return rc;
+    return SML_OK;
+}
+
+int sml_bank_algorithmic_bytes(sml_bank *b, uint64_t *update_bytes, uint64_t *readout_bytes)
+{
+    SML_REQUIRE(b, "null bank");
+    uint64_t u = 0, r = 0;
+    for (auto &h : b->res)
+        if (h.desc.loaded) { u += h.update_bytes; r += h.readout_bytes; }
+    if (update_bytes) *update_bytes = u;
+    if (readout_bytes) *readout_bytes = r;
+    return SML_OK;
+}
+
+}  // extern "C"

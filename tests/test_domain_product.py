@@ -1,0 +1,102 @@
+"""CPU: the product's closed-form resdomain index maps (speedy-ml_amd/csrc/domain.cpp, through the C-ABI)
+against the oracle's slice-and-reshape restatement of src/res_domain.f90.  Integers: bit-exact."""
+import numpy as np
+import pytest
+
+from speedy_ml_amd import domain
+
+REGION_COUNTS = (1152, 288, 4608, 72)
+
+
+@pytest.mark.parametrize("nreg", REGION_COUNTS)
+def test_region_extents_all_regions(oracle, nreg):
+    for r in range(nreg):
+        for ov in ((1, 2) if nreg != 4608 else (1,)):
+            want = oracle.initializedomain(nreg, r, overlap=ov).asdict()
+            got = domain.initializedomain(nreg, r, overlap=ov).asdict()
+            for k, v in got.items():
+                assert v == want[k], (nreg, r, ov, k)
+
+
+def test_vertical_localisation_extents(oracle):
+    for nvl in (1, 2, 4, 8):
+        for vl in range(1, nvl + 1):
+            for vo in (0, 1, 2):
+                want = oracle.initializedomain(1152, 954, 1, nvl, vl, vo).asdict()
+                got = domain.initializedomain(1152, 954, 1, nvl, vl, vo).asdict()
+                for k, v in got.items():
+                    assert v == want[k], (nvl, vl, vo, k)
+
+
+def test_sizes_all_classes(oracle):
+    for r in (0, 1, 23, 24, 500, 954, 1151):
+        for sst in (0, 1):
+            go, gp = oracle.initializedomain(1152, r), domain.initializedomain(1152, r)
+            want = oracle.allocate_sizes(go, sst_input=sst).asdict()
+            got = domain.allocate_res_sizes(gp, sst_bool_input=bool(sst)).asdict()
+            for k, v in got.items():
+                assert v == want[k], (r, sst, k)
+
+
+@pytest.mark.parametrize("nprocs", (1, 2, 4, 5, 7, 8, 16))
+def test_processor_decomposition(oracle, nprocs):
+    for p in range(nprocs):
+        assert np.array_equal(domain.processor_decomposition_manual(p, nprocs, 1152),
+                              oracle.processor_decomposition(p, nprocs, 1152))
+
+
+def test_out_map_equals_oracle_scatter(oracle):
+    # scatter a tagged outvec through the oracle tiler; the product map must point at the same cells
+    for r in (0, 1, 23, 24, 47, 48, 500, 954, 1128, 1151):
+        gi, si = domain.out_map(1152, r)
+        assert len(gi) == 136
+        g4, g2, gp = np.full(147456, -1.0), np.full(4608, -1.0), np.full(4608, -1.0)
+        oracle.scatter_res(1152, r, np.arange(136, dtype=float), g4, g2, gp)
+        G = np.concatenate([g4, g2, gp])
+        assert np.array_equal(G[gi], np.arange(136, dtype=float))
+        assert (G >= 0).sum() == 136
+        # first 132 entries == gather map of tile_4d_and_logp_full_grid_to_local_res_vec
+        tag4, tag2 = np.arange(147456, dtype=float), 1e6 + np.arange(4608, dtype=float)
+        want = oracle.tile_res(1152, r, tag4, tag2, 132)
+        assert np.array_equal(np.concatenate([tag4, tag2])[gi[:132]], want)
+        # mean/std slots: T,u,v,q x 8 levels, logp 32, precip 34
+        assert list(si[:4]) == [0, 8, 16, 24] and si[16] == 1
+        assert list(si[128:132]) == [32] * 4 and list(si[132:]) == [34] * 4
+
+
+def test_in_map_equals_oracle_tiler(oracle):
+    tag4 = np.arange(147456, dtype=float)
+    tag2 = 1e6 + np.arange(4608, dtype=float)
+    tagp = 2e6 + np.arange(4608, dtype=float)
+    tags = 3e6 + np.arange(4608, dtype=float)
+    tagt = 4e6 + np.arange(4608, dtype=float)
+    G = np.concatenate([tag4, tag2, tagp, tags, tagt])
+    assert G.size == domain.G_SIZE
+    for r in range(1152):
+        for sst in (True, False):
+            gi, si = domain.in_map(1152, r, sst_bool_input=sst)
+            g = oracle.initializedomain(1152, r)
+            s = oracle.allocate_sizes(g, sst_input=int(sst))
+            assert len(gi) == s.reservoir_numinputs
+            want = oracle.tile_input(1152, r, tag4, tag2, tagp, s.precip_end)
+            assert np.array_equal(G[gi[:s.precip_end]], want), r
+            in2d = g.inputxchunk * g.inputychunk
+            if sst:
+                assert np.array_equal(G[gi[s.sst_start - 1:s.sst_end]], oracle.tile_input2d(1152, r, tags, in2d))
+                assert np.all(si[s.sst_start - 1:s.sst_end] == 35)
+            assert np.array_equal(G[gi[s.tisr_start - 1:s.tisr_end]], oracle.tile_input2d(1152, r, tagt, in2d))
+            assert np.all(si[s.tisr_start - 1:s.tisr_end] == 33)
+            assert np.all(si[s.logp_start - 1:s.logp_end] == 32) and np.all(si[s.precip_start - 1:s.precip_end] == 34)
+            if r % 97 == 0:
+                # statistics slots of the 3-d block follow standardize_state_vec_input (var-major, level-minor)
+                mean, std = np.arange(36, dtype=float), np.ones(36)
+                v = oracle.standardize_input(g, s, mean, std, np.zeros(s.reservoir_numinputs))
+                assert np.array_equal(-v[:s.logp_end], si[:s.logp_end].astype(float))
+
+
+def test_bad_arguments_fail_loudly():
+    from speedy_ml_amd._lib import SmlError
+    with pytest.raises(SmlError):
+        domain.initializedomain(1152, 1152)
+    with pytest.raises(SmlError):
+        domain.processor_decomposition_manual(8, 8, 1152)

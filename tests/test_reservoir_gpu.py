@@ -1,0 +1,133 @@
+"""GPU: the batched HIP reservoir path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp64): reservoir state |dx| <= 1e-13 absolute (|x| <= 1; device tanh vs libm differ by <= 2 ulp),
+outvec <= 1e-11 of max|outvec| (north_star: fields within 1e-10 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from speedy_ml_amd import domain
+from speedy_ml_amd.reservoir import ReservoirBank
+from speedy_ml_amd.synth import make_reservoir
+
+pytestmark = pytest.mark.gpu
+X_TOL, OUT_TOL = 1e-13, 1e-11
+
+
+def load(bank, slot, r, stat=None):
+    bank.load(slot, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, stat)
+
+
+def oracle_predict(oracle, r, x0, stat=None, leakage=1.0):
+    x1, out = oracle.predict_raw(r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, leakage,
+                                 r.feedback, r.local_model if r.n_model else None, x0)
+    if stat is not None:
+        out = np.array([o * r.std[s] + r.mean[s] if s >= 0 else o for o, s in zip(out, stat)])
+    return x1, out
+
+
+def test_small_mixed_bank(oracle):
+    shapes = [(600, 60, 12, 16), (640, 64, 0, 8), (330, 30, 7, 17), (1280, 40, 12, 35), (64, 8, 2, 1)]
+    rs = [make_reservoir(n=n, d=d, n_model=m, n_out=o, seed=100 + i) for i, (n, d, m, o) in enumerate(shapes)]
+    bank = ReservoirBank(8, max_d=64, max_n_model=12, max_n_out=35)
+    rng = np.random.default_rng(0)
+    x0 = [rng.standard_normal(r.n) * 0.3 for r in rs]
+    for i, r in enumerate(rs):
+        stat = (np.arange(r.n_out) % 36).astype(np.int32)
+        stat[::5] = -1
+        r.stat = stat
+        load(bank, i + 1, r, stat)                 # slot 0 and the tail stay empty on purpose
+        bank.set_state(i + 1, x0[i])
+        bank.set_feedback(i + 1, r.feedback)
+        if r.n_model:
+            bank.set_local_model(i + 1, r.local_model)
+    bank.predict()
+    torch.cuda.synchronize()
+    for i, r in enumerate(rs):
+        xw, ow = oracle_predict(oracle, r, x0[i], r.stat)
+        assert np.max(np.abs(bank.get_state(i + 1) - xw)) <= X_TOL
+        assert np.max(np.abs(bank.get_outvec(i + 1) - ow)) <= OUT_TOL * max(1.0, np.max(np.abs(ow)))
+    # second step continues from the device-resident state
+    bank.predict(raw=True)
+    for i, r in enumerate(rs):
+        x1, _ = oracle_predict(oracle, r, x0[i])
+        x2, o2 = oracle_predict(oracle, r, x1)
+        assert np.max(np.abs(bank.get_state(i + 1) - x2)) <= 2 * X_TOL
+        assert np.max(np.abs(bank.get_outvec(i + 1) - o2)) <= OUT_TOL * max(1.0, np.max(np.abs(o2)))
+
+
+def test_config2_single_reservoir_full_size(oracle):
+    """BASELINE config 2: region 954 (interior, SST input): n=5760, d=576, k=33177, W_out 136x5892."""
+    g = domain.initializedomain(1152, 954)
+    s = domain.allocate_res_sizes(g)
+    assert (s.n, s.reservoir_numinputs, s.k) == (5760, 576, 33177)
+    r = make_reservoir(n=s.n, d=s.reservoir_numinputs, n_model=s.chunk_size_speedy, n_out=s.chunk_size_prediction, seed=20240954)
+    assert r.k == s.k
+    _, stat = domain.out_map(1152, 954)
+    bank = ReservoirBank(1)
+    load(bank, 0, r, stat)
+    # 55 synchronisation steps with N(0,1) inputs, then predict
+    rng = np.random.default_rng(5)
+    inputs = rng.standard_normal((r.d, 55))
+    dev_in = torch.zeros((55, 1, 576), dtype=torch.float64, device="cuda")
+    dev_in[:, 0, :] = torch.from_numpy(np.ascontiguousarray(inputs.T)).cuda()
+    bank.synchronize(dev_in.data_ptr(), 55)
+    xs = oracle.synchronize(r.n, r.d, r.rows, r.cols, r.vals, r.win, 1.0, inputs, np.zeros(r.n))
+    assert np.max(np.abs(bank.get_state(0) - xs)) <= 55 * X_TOL
+    bank.set_state(0, xs)          # teacher-force identical state (parity is per step)
+    bank.set_feedback(0, r.feedback)
+    bank.set_local_model(0, r.local_model)
+    bank.predict()
+    xw, ow = oracle_predict(oracle, r, xs, stat)
+    assert np.max(np.abs(bank.get_state(0) - xw)) <= X_TOL
+    assert np.max(np.abs(bank.get_outvec(0) - ow)) <= OUT_TOL * np.max(np.abs(ow))
+    # reference-shaped per-call entry (x in/out on the host)
+    x1, o1 = bank.predict_one(0, xs, r.local_model)
+    assert np.max(np.abs(x1 - xw)) <= X_TOL and np.max(np.abs(o1 - ow)) <= OUT_TOL * np.max(np.abs(ow))
+    assert np.array_equal(bank.get_state(0), x1)
+
+
+def test_leakage_and_duplicates(oracle):
+    r = make_reservoir(n=256, d=16, n_model=4, n_out=6, seed=9)
+    r.rows[:50] = r.rows[50:100]
+    r.cols[:50] = r.cols[50:100]                     # duplicate (row,col) pairs must accumulate
+    bank = ReservoirBank(1, max_d=16, max_n_model=4, max_n_out=6)
+    bank.load(0, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None, leakage=0.3)
+    x0 = np.random.default_rng(1).standard_normal(r.n)
+    bank.set_state(0, x0)
+    bank.set_feedback(0, r.feedback)
+    bank.set_local_model(0, r.local_model)
+    bank.predict(raw=True)
+    xw, ow = oracle_predict(oracle, r, x0, leakage=0.3)
+    assert np.max(np.abs(bank.get_state(0) - xw)) <= 4 * X_TOL
+    assert np.max(np.abs(bank.get_outvec(0) - ow)) <= OUT_TOL * max(1.0, np.max(np.abs(ow)))
+
+
+def test_dense_win_variant(oracle):
+    """The commented-out reference variant fills whole W_in columns (src/mod_reservoir.f90:279): a dense W_in
+    must give the same result as the oracle's dense matmul."""
+    r = make_reservoir(n=192, d=24, n_model=0, n_out=5, seed=3)
+    r.win = np.asfortranarray(np.random.default_rng(4).uniform(-0.5, 0.5, (r.n, r.d)))
+    bank = ReservoirBank(1, max_d=24, max_n_model=0, max_n_out=5)
+    load(bank, 0, r)
+    x0 = np.random.default_rng(2).standard_normal(r.n) * 0.1
+    bank.set_state(0, x0)
+    bank.set_feedback(0, r.feedback)
+    bank.predict(raw=True)
+    xw, ow = oracle_predict(oracle, r, x0)
+    assert np.max(np.abs(bank.get_state(0) - xw)) <= 10 * X_TOL
+    assert np.max(np.abs(bank.get_outvec(0) - ow)) <= OUT_TOL * max(1.0, np.max(np.abs(ow)))
+
+
+def test_errors_are_loud():
+    from speedy_ml_amd._lib import SmlError
+    bank = ReservoirBank(2, max_d=8, max_n_model=2, max_n_out=4)
+    r = make_reservoir(n=64, d=8, n_model=2, n_out=4, seed=1)
+    with pytest.raises(SmlError):
+        bank.set_state(0, np.zeros(64))              # nothing loaded
+    bad = r.rows.copy()
+    bad[0] = 65
+    with pytest.raises(SmlError):
+        bank.load(0, r.n, r.d, r.n_model, r.n_out, bad, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
+    with pytest.raises(SmlError):
+        bank.load(5, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
