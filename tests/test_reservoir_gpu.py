@@ -88,9 +88,10 @@ def test_config2_single_reservoir_full_size(oracle):
 
 
 def test_leakage_and_duplicates(oracle):
-    r = make_reservoir(n=256, d=16, n_model=4, n_out=6, seed=9)
-    r.rows[:50] = r.rows[50:100]
-    r.cols[:50] = r.cols[50:100]                     # duplicate (row,col) pairs must accumulate
+    r = make_reservoir(n=256, d=16, n_model=4, n_out=6, seed=9, deg=60)
+    q = r.k // 4
+    r.rows[:q] = r.rows[q:2 * q]
+    r.cols[:q] = r.cols[q:2 * q]                     # duplicate (row,col) pairs must accumulate
     bank = ReservoirBank(1, max_d=16, max_n_model=4, max_n_out=6)
     bank.load(0, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None, leakage=0.3)
     x0 = np.random.default_rng(1).standard_normal(r.n)
