@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Benchmark of the SPEEDY-ML hybrid-step hot path on MI355X (contract: see the task statement).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over the 1152 local reservoirs of the T30L8 hybrid model (BASELINE.json
+config 3): batched predict of every resident reservoir, the region exchange (pack / all-gather over RCCL when
+N>1 / scatter + clamps), the SPEEDY hand-off and time-step spectral transforms on the device, and the gather +
+standardisation of the next inputs.  Regions are sharded over ranks exactly as processor_decomposition does
+(src/res_domain.f90:31-62); the only data-path collective is the all-gather of the outvec slab.  Inputs are
+synthetic (seeded, ERA5-shaped) and resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line with the contract's keys plus "roofline" and "cpu_baseline".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="hybrid", choices=["hybrid", "sweep"],
+                    help="sweep = reservoir predict sweep only (development aid; the driver uses the default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--regions", type=int, default=1152, help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    load_package()
+    from speedy_ml_amd import _lib, domain, hybrid, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    _lib.check(_lib.lib().sml_set_device(local_rank))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = [int(r) for r in domain.processor_decomposition_manual(rank, world, hybrid.NREG)]
+    if args.regions < len(regions):
+        regions = regions[:args.regions]
+    t0 = time.time()
+    model = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode=args.mode)
+    if rank == 0:
+        print(f"[bench] rank0 loaded {len(regions)} reservoirs in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
+
+    stream = torch.cuda.current_stream()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.step(stream)
+    barrier()
+    model.timing(True)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        model.step(stream)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kern = model.timing_collect()
+    model.timing(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        upd_b, ro_b = model.bank.algorithmic_bytes()
+        ro_ms = kern["readout_ms"] / max(kern["readout_launches"], 1)
+        upd_ms = kern["update_ms"] / max(kern["update_launches"], 1)
+        achieved = ro_b / (ro_ms * 1e-3) / 1e9 if ro_ms > 0 else 0.0
+        line = {
+            "metric": "hybrid forecast steps/sec at T30L8, 1152 N_res=6000 reservoirs",
+            "value": args.steps / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": model.describe(),
+            "roofline": {"bound": "hbm", "kernel": "k_readout<17> (W_out [local_model;x~] GEMV, all resident reservoirs)",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": ro_b, "avg_launch_ms": ro_ms,
+                         "secondary": {"kernel": "k_update (SELL-64 [A|Win]x + tanh)", "achieved":
+                                       (upd_b / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0), "unit": "GB/s",
+                                       "algorithmic_bytes_per_launch": upd_b, "avg_launch_ms": upd_ms}},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = model.cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

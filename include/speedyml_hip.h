@@ -153,6 +153,11 @@ int sml_bank_advance_all(sml_bank *bank, void *stream);
 
 /* byte accounting for the roofline (algorithmic bytes as defined in DESIGN.md) */
 int sml_bank_algorithmic_bytes(sml_bank *bank, uint64_t *update_bytes, uint64_t *readout_bytes);
+/* Per-kernel timing with HIP events recorded on the launch stream (for bench.py's roofline block).
+ * enable!=0 starts recording an event pair around every k_update / k_readout launch; collect synchronises the
+ * recorded events, returns the summed milliseconds and launch counts since the last collect, and clears them. */
+int sml_bank_timing(sml_bank *bank, int enable);
+int sml_bank_timing_collect(sml_bank *bank, double *update_ms, int *update_launches, double *readout_ms, int *readout_launches);
 
 /* ===================================================================================================
  * 3. exchange: the device-resident form of sendrecievegrid (src/mpires.f90:218-804) without MPI/NetCDF

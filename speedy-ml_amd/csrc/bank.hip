@@ -191,6 +191,8 @@ struct sml_bank {
     ResDesc *d_descs = nullptr;
     double *d_feedback = nullptr, *d_local_model = nullptr, *d_outvec = nullptr;
     bool descs_dirty = true;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_readout;
 };
 
 namespace {
@@ -333,9 +335,12 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
         SML_HIP(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
     hipLaunchKernelGGL(k_update, dim3(nres8 * parts), dim3(UPD_THREADS), lds, st, b->d_descs, res_begin, res_end, parts,
                        u_all, b->max_d, b->cur);
     SML_HIP(hipGetLastError());
+    if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_update.emplace_back(e0, e1); }
     b->cur ^= 1;
     return SML_OK;
 }
@@ -344,9 +349,12 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
 {
     const int parts = b->max_parts_ro;
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
     hipLaunchKernelGGL(k_readout<RO_ROWS>, dim3(nres8 * parts), dim3(RO_THREADS), 0, st, b->d_descs, res_begin, res_end, parts,
                        b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags);
     SML_HIP(hipGetLastError());
+    if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_readout.emplace_back(e0, e1); }
     return SML_OK;
 }
 
@@ -532,6 +540,37 @@ int sml_bank_synchronize_all(sml_bank *b, const double *inputs_dev, int length, 
     for (int t = 0; t < length; ++t)
         if ((rc = launch_update(b, 0, b->capacity, inputs_dev + step * t, sml::as_stream(stream)))) return rc;
     return SML_OK;
+}
+
+int sml_bank_timing(sml_bank *b, int enable)
+{
+    SML_REQUIRE(b, "null bank");
+    b->timing = enable != 0;
+    return SML_OK;
+}
+
+static int drain(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double *ms, int *count)
+{
+    double total = 0.0;
+    for (auto &p : v) {
+        SML_HIP(hipEventSynchronize(p.second));
+        float t = 0.f;
+        SML_HIP(hipEventElapsedTime(&t, p.first, p.second));
+        total += t;
+        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+    }
+    if (ms) *ms = total;
+    if (count) *count = (int)v.size();
+    v.clear();
+    return SML_OK;
+}
+
+int sml_bank_timing_collect(sml_bank *b, double *update_ms, int *update_launches, double *readout_ms, int *readout_launches)
+{
+    SML_REQUIRE(b, "null bank");
+    int rc;
+    if ((rc = drain(b->ev_update, update_ms, update_launches))) return rc;
+    return drain(b->ev_readout, readout_ms, readout_launches);
 }
 
 int sml_bank_algorithmic_bytes(sml_bank *b, uint64_t *update_bytes, uint64_t *readout_bytes)

@@ -23,7 +23,7 @@ def processor_decomposition_manual(proc_number, numprocs, number_of_regions):
 def initializedomain(num_regions, region_num, overlap=1, num_vert_levels=1, vert_level=1, vert_overlap=0):
     """src/res_domain.f90:96-121 -> Region (the grid_type extents)."""
     g = Region()
-    check(_lib.lib().sml_domain_region(num_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap, C.byref(g)))
+    check(_lib.lib().sml_domain_region(int(num_regions), int(region_num), overlap, num_vert_levels, vert_level, vert_overlap, C.byref(g)))
     return g
 
 
@@ -40,7 +40,7 @@ def out_map(num_regions, region_num, num_vert_levels=1, vert_level=1, vert_overl
     """outvec element -> (index into G, mean/std slot); ordering of tile_full_grid_with_local_state_vec_res1d."""
     cap = 4 * XGRID * YGRID * ZGRID
     gi, si = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
-    n = check(_lib.lib().sml_domain_out_map(num_regions, region_num, num_vert_levels, vert_level, vert_overlap,
+    n = check(_lib.lib().sml_domain_out_map(int(num_regions), int(region_num), num_vert_levels, vert_level, vert_overlap,
                                             int(precip_bool), ip(gi), ip(si), cap))
     return gi[:n].copy(), si[:n].copy()
 
@@ -50,6 +50,6 @@ def in_map(num_regions, region_num, overlap=1, num_vert_levels=1, vert_level=1, 
     """input element -> (index into G, mean/std slot); ordering of tile_4d_and_logp_to_local_state_input + sst + tisr."""
     cap = 8 * XGRID * YGRID * ZGRID
     gi, si = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
-    n = check(_lib.lib().sml_domain_in_map(num_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap,
+    n = check(_lib.lib().sml_domain_in_map(int(num_regions), int(region_num), overlap, num_vert_levels, vert_level, vert_overlap,
                                            int(precip_bool), int(sst_bool_input), int(tisr_input_bool), ip(gi), ip(si), cap))
     return gi[:n].copy(), si[:n].copy()
