@@ -1,0 +1,47 @@
+// Shared between bank.hip and exchange.hip: the device-visible reservoir descriptor and the bank object.
+#pragma once
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+namespace sml {
+
+struct ResDesc {
+    int n, d, n_model, n_out, n_aug, n_aug_pad, nslices, loaded;
+    const int *slice_off;      // [nslices+1] first entry of each 64-row slice (entries are width*64 per slice)
+    const int *sell_col;       // column into [x ; u]
+    const double *sell_val;
+    const int *perm;           // sorted position -> original row (or -1 for the padding rows of the last slice)
+    const int *row_len;        // nonzeros of the row at each sorted position
+    double *x[2];              // ping-pong state
+    const double *wout;        // [n_out][n_aug_pad] row-major, zero padded
+    const double *mean, *stdv;
+    const int *out_stat;       // [n_out] slot into mean/std, <0 = leave as is
+    double leak;
+};
+
+struct HostRes {
+    std::vector<void *> allocs;
+    ResDesc desc{};
+    uint64_t update_bytes = 0, readout_bytes = 0;
+};
+
+}  // namespace sml
+
+struct sml_bank {
+    int capacity = 0, max_d = 0, max_n_model = 0, max_n_out = 0;
+    int cur = 0;
+    int max_nd = 0;                 // LDS doubles needed by k_update
+    int max_parts_ro = 1;
+    std::vector<sml::HostRes> res;
+    sml::ResDesc *d_descs = nullptr;
+    double *d_feedback = nullptr, *d_local_model = nullptr, *d_outvec = nullptr;
+    bool descs_dirty = true;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_readout;
+};
+
+namespace sml {
+int bank_sync_descs(sml_bank *b);
+}

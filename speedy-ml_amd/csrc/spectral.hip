@@ -1,0 +1,622 @@
+// SPEEDY T30 spectral transforms on gfx950, batched over fields.
+//
+// Replaces src/spe_spectral.f90 (parmtr/gaussl/lgndre tables :2-242, operators :244-387, grid/spec/vdspec :389-452,
+// Legendre synthesis/analysis gridy/specy :454-538, trunct :540-551) and the longitudinal FFT wrappers
+// gridx/specx over vendored FFTPACK (src/spe_subfft_fftpack.f90:15-87, src/spe_subfft_fftpack2.f90).
+//
+// The reference does one 96x48 transform per call (23 us on a CPU core, 164 calls per time step).  A single transform
+// is ~0.13 Mflop on 53 KB -- far too small for a GPU launch -- so every entry point here takes nf fields and runs ONE
+// workgroup per field with the whole field resident in LDS:
+//   inverse (grid): spectral field (15.9 KB) -> LDS; Legendre synthesis with the even/odd-n split that gives both
+//       hemispheres from one pass (same summation order as gridy, so bit-identical to it without FMA contraction);
+//       Fourier synthesis of the 31 retained zonal modes as a pruned 96-point real DFT from an LDS twiddle table
+//       (60 multiply-adds per grid point, no butterfly stages, no barriers inside) instead of FFTPACK's 2*4*4*3
+//       butterflies: with 65 of the 96 half-complex inputs structurally zero the pruned form needs fewer LDS
+//       round trips than four radix stages; it differs from FFTPACK only in rounding (<= 1e-14 relative).
+//   forward (spec): grid field (36.9 KB) -> LDS (optionally scaled by 1/cos or 1/cos^2 per latitude, the vdspec
+//       prologue); 31-mode forward DFT; symmetric/antisymmetric combinations times the Gaussian weight in place;
+//       Legendre analysis accumulated over latitude in the reference's order (bit-identical to specy).
+// The Legendre table is stored once per zonal wavenumber (cpol(2m-1,n,j)=cpol(2m,n,j), :181-191): 24*32*31 doubles
+// = 190 KB, L2-resident and shared by all workgroups.
+// Spectral arrays: [nf][32][62] doubles (= Fortran (mx2,nx) per field), grids: [nf][48][96] (= (ix,il)).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int IX = 96, IY = 24, IL = 48, NX = 32, MX = 31, MX2 = 62, NTRUN = 30, NTRUN1 = 31, NXP = 33, MXP = 31;
+constexpr int SPEC_N = MX2 * NX;   // 1984
+constexpr int GRID_N = IX * IL;    // 4608
+constexpr int FOUR_N = MX2 * IL;   // 2976
+
+struct HostTables {
+    double sia[IY], coa[IY], wt[IY], wght[IY], cosg[IL], cosgr[IL], cosgr2[IL];
+    double el2[NX][MX], elm2[NX][MX], el4[NX][MX], trfilt[NX][MX];
+    int nsh2[NX];
+    double epsi[NXP][MXP], repsi[NXP][MXP], consq[MXP], sqrhlf;
+    double gradx[MX], gradym[NX][MX], gradyp[NX][MX], uvdx[NX][MX], uvdym[NX][MX], uvdyp[NX][MX], vddym[NX][MX], vddyp[NX][MX];
+    double pol[IY][NX][MX];          // P_m^n at latitude j (cpol without the re/im duplication)
+    double twc[IX], tws[IX];         // cos/sin(2 pi t / 96)
+};
+
+struct DevTables {
+    const double *pol;               // [24][32][31]
+    const double *wt, *cosgr, *cosgr2;
+    const int *nsh2;
+    const double *twc, *tws;
+    const double *el2, *elm2, *trfilt, *gradx, *gradym, *gradyp, *uvdx, *uvdym, *uvdyp, *vddym, *vddyp;   // [32][31]
+};
+
+// ---- table construction on the host, fp64 (the reference promotes every real to 8 bytes, src/makefile:6,12) ----
+void gauss_latitudes(double *x, double *w, int m)
+{   // Newton iteration on P_{2m} from the Numerical-Recipes start value; pi literal and tolerance as src/spe_spectral.f90:16,24
+    const int n = 2 * m;
+    double zprev = 2.0;
+    for (int i = 1; i <= m; ++i) {
+        double z = std::cos(3.141592654 * (i - .25) / (n + .5)), pp = 0.0;
+        while (std::fabs(z - zprev) > 3.e-14) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 1; j <= n; ++j) { const double p3 = p2; p2 = p1; p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j; }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            zprev = z;
+            z = zprev - p1 / pp;
+        }
+        x[i - 1] = z;
+        w[i - 1] = 2.0 / ((1.0 - z * z) * pp * pp);
+    }
+}
+
+void build_tables(HostTables &t, double a)
+{
+    gauss_latitudes(t.sia, t.wt, IY);
+    for (int j = 0; j < IY; ++j) {
+        const double c2 = 1.0 - t.sia[j] * t.sia[j];
+        t.coa[j] = std::sqrt(c2);
+        t.wght[j] = t.wt[j] / (a * c2);
+        const int jj = IL - 1 - j;
+        t.cosg[j] = t.cosg[jj] = t.coa[j];
+        t.cosgr[j] = t.cosgr[jj] = 1. / t.coa[j];
+        t.cosgr2[j] = t.cosgr2[jj] = 1. / (t.coa[j] * t.coa[j]);
+    }
+    const double am2 = 1. / (a * a);
+    for (int n = 0; n < NX; ++n) {
+        t.nsh2[n] = 0;
+        for (int m = 0; m < MX; ++m) {
+            const int l = m + n;                         // total wavenumber
+            t.el2[n][m] = (double)(l * (l + 1)) * am2;
+            t.el4[n][m] = t.el2[n][m] * t.el2[n][m];
+            if (l <= NTRUN1) t.nsh2[n] += 2;
+            t.trfilt[n][m] = l <= NTRUN ? 1. : 0.;
+            t.elm2[n][m] = (m == 0 && n == 0) ? 0. : 1. / t.el2[n][m];
+        }
+    }
+    for (int m = 0; m < MXP; ++m)
+        for (int n = 0; n < NXP; ++n) {
+            const double em = m, el = n + m;
+            double e;
+            if (n == NXP - 1 || (n == 0 && m == 0)) e = 0.0;
+            else e = std::sqrt((el * el - em * em) / (4. * (el * el) - 1.));
+            t.epsi[n][m] = e;
+            t.repsi[n][m] = e > 0. ? 1. / e : 0.0;
+        }
+    t.sqrhlf = std::sqrt(.5);
+    t.consq[0] = 0.0;
+    for (int m = 1; m < MXP; ++m) t.consq[m] = std::sqrt(.5 * (2. * m + 1.) / (double)m);
+    for (int m = 0; m < MX; ++m)
+        for (int n = 0; n < NX; ++n) {
+            const double el1 = m + n;
+            if (n == 0) {
+                t.gradx[m] = (double)m / a;
+                t.uvdx[0][m] = -a / (double)(m + 1);
+                t.uvdym[0][m] = t.vddym[0][m] = t.gradym[0][m] = 0.0;
+            } else {
+                t.uvdx[n][m] = -a * (double)m / (el1 * (el1 + 1));
+                t.gradym[n][m] = (el1 - 1.) * t.epsi[n][m] / a;
+                t.uvdym[n][m] = -a * t.epsi[n][m] / el1;
+                t.vddym[n][m] = (el1 + 1) * t.epsi[n][m] / a;
+            }
+            t.gradyp[n][m] = (el1 + 2.) * t.epsi[n + 1][m] / a;
+            t.uvdyp[n][m] = -a * t.epsi[n + 1][m] / (el1 + 1.);
+            t.vddyp[n][m] = el1 * t.epsi[n + 1][m] / a;
+        }
+    // associated Legendre functions by the three-term recurrence in n, seeded on the m = l diagonal
+    std::vector<double> alp((size_t)NX * MXP);
+    auto A = [&](int m, int n) -> double & { return alp[(size_t)n * MXP + m]; };
+    for (int j = 0; j < IY; ++j) {
+        const double x = t.sia[j], y = t.coa[j];
+        A(0, 0) = t.sqrhlf;
+        for (int m = 1; m < MXP; ++m) A(m, 0) = t.consq[m] * y * A(m - 1, 0);
+        for (int m = 0; m < MXP; ++m) A(m, 1) = (x * A(m, 0)) * t.repsi[1][m];
+        for (int n = 2; n < NX; ++n)
+            for (int m = 0; m < MXP; ++m) A(m, n) = (x * A(m, n - 1) - t.epsi[n - 1][m] * A(m, n - 2)) * t.repsi[n][m];
+        for (int n = 0; n < NX; ++n)
+            for (int m = 0; m < MX; ++m) { double v = A(m, n); if (std::fabs(v) <= 1.e-30) v = 0.0; t.pol[j][n][m] = v; }
+    }
+    for (int k = 0; k < IX; ++k) {
+        const long double ang = 2.0L * 3.14159265358979323846264338327950288L * k / (long double)IX;
+        t.twc[k] = (double)cosl(ang);
+        t.tws[k] = (double)sinl(ang);
+    }
+    t.twc[24] = t.twc[72] = 0.0; t.tws[0] = t.tws[48] = 0.0;
+}
+
+// ------------------------------------------------ kernels ------------------------------------------------
+constexpr int TT = 256;
+
+// inverse transform of one field per workgroup:  vorm[32][62] -> vorg[48][96]
+__global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos)
+{
+    __shared__ double sv[SPEC_N];          // spectral coefficients
+    __shared__ double sf[FOUR_N];          // Fourier coefficients varm[48][62]
+    __shared__ double stc[IX], sts[IX];
+    __shared__ int snsh[NX];
+    const double *v = vorm + (size_t)blockIdx.x * SPEC_N;
+    double *g = vorg + (size_t)blockIdx.x * GRID_N;
+    for (int i = threadIdx.x; i < SPEC_N; i += TT) sv[i] = v[i];
+    for (int i = threadIdx.x; i < IX; i += TT) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
+    if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
+    __syncthreads();
+    // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O
+    for (int w = threadIdx.x; w < MX2 * IY; w += TT) {
+        const int c = w % MX2, j = w / MX2, m = c >> 1;
+        const double *p = T.pol + (size_t)j * NX * MX + m;
+        double e = 0.0, o = 0.0;
+#pragma unroll 4
+        for (int n = 0; n < NX; n += 2) {
+            if (c < snsh[n]) e = e + sv[n * MX2 + c] * p[n * MX];
+            if (c < snsh[n + 1]) o = o + sv[(n + 1) * MX2 + c] * p[(n + 1) * MX];
+        }
+        sf[(IL - 1 - j) * MX2 + c] = e + o;
+        sf[j * MX2 + c] = e - o;
+    }
+    __syncthreads();
+    // Fourier synthesis (gridx): x_i = a0 + sum_k 2 (Re_k cos(2 pi k i/96) - Im_k sin(2 pi k i/96)), k = 1..30
+    for (int w = threadIdx.x; w < GRID_N; w += TT) {
+        const int i = w % IX, j = w / IX;
+        const double *f = sf + j * MX2;
+        double acc = f[0];
+        int ph = 0;
+#pragma unroll 5
+        for (int k = 1; k <= MX - 1; ++k) {
+            ph += i;
+            if (ph >= IX) ph -= IX;
+            acc += 2.0 * (f[2 * k] * stc[ph] - f[2 * k + 1] * sts[ph]);
+        }
+        if (kcos != 1) acc = acc * T.cosgr[j];
+        g[w] = acc;
+    }
+}
+
+// forward transform of one field per workgroup: vorg[48][96] -> vorm[32][62]; scale: 0 none, 1 *cosgr(j), 2 *cosgr2(j)
+__global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restrict__ vorg, double *__restrict__ vorm, int scale)
+{
+    __shared__ double sg[GRID_N];
+    __shared__ double sf[FOUR_N];
+    __shared__ double stc[IX], sts[IX];
+    __shared__ int snsh[NX];
+    const double *g = vorg + (size_t)blockIdx.x * GRID_N;
+    double *v = vorm + (size_t)blockIdx.x * SPEC_N;
+    for (int i = threadIdx.x; i < GRID_N; i += TT) {
+        double x = g[i];
+        if (scale == 1) x = x * T.cosgr[i / IX];
+        else if (scale == 2) x = x * T.cosgr2[i / IX];
+        sg[i] = x;
+    }
+    for (int i = threadIdx.x; i < IX; i += TT) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
+    if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
+    __syncthreads();
+    // forward DFT (specx): a0 = sum x / 96 ; Re_k = sum x cos / 96 ; Im_k = - sum x sin / 96 ; element 1 (Im of k=0) = 0
+    const double sc = 1. / (double)IX;
+    for (int w = threadIdx.x; w < MX * IL; w += TT) {
+        const int k = w % MX, j = w / MX;
+        const double *x = sg + j * IX;
+        double re = 0.0, im = 0.0;
+        int ph = 0;
+        for (int i = 0; i < IX; ++i) {
+            re += x[i] * stc[ph];
+            im -= x[i] * sts[ph];
+            ph += k;
+            if (ph >= IX) ph -= IX;
+        }
+        sf[j * MX2 + 2 * k] = re * sc;
+        sf[j * MX2 + 2 * k + 1] = k == 0 ? 0.0 : im * sc;
+    }
+    __syncthreads();
+    // symmetric / antisymmetric parts times the Gaussian weight, in place (specy :511-517)
+    for (int w = threadIdx.x; w < MX2 * IY; w += TT) {
+        const int c = w % MX2, j = w / MX2, j1 = IL - 1 - j;
+        const double n_ = sf[j1 * MX2 + c], s_ = sf[j * MX2 + c], wj = T.wt[j];
+        sf[j * MX2 + c] = (n_ + s_) * wj;       // svarm
+        sf[j1 * MX2 + c] = (n_ - s_) * wj;      // dvarm
+    }
+    __syncthreads();
+    // Legendre analysis (specy :519-537): odd n (1-based) use svarm, even n use dvarm, n <= ntrun1, c < nsh2(n)
+    for (int w = threadIdx.x; w < SPEC_N; w += TT) {
+        const int c = w % MX2, n = w / MX2, m = c >> 1;
+        double acc = 0.0;
+        if (n < NTRUN1 && c < snsh[n]) {
+            const double *p = T.pol + (size_t)n * MX + m;
+            if ((n & 1) == 0) { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[j * MX2 + c]; }
+            else              { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[(IL - 1 - j) * MX2 + c]; }
+        }
+        v[w] = acc;
+    }
+}
+
+// pointwise / 3-point-in-n spectral operators; one thread per real element [nf][32][62]
+enum { OP_LAP = 0, OP_INVLAP = 1, OP_TRUNCT = 2 };
+__global__ void k_scale(DevTables T, const double *__restrict__ in, double *__restrict__ out, int total, int op)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int e = t % SPEC_N, c = e % MX2, n = e / MX2, m = c >> 1;
+    const double x = in[t];
+    if (op == OP_LAP) out[t] = -x * T.el2[n * MX + m];
+    else if (op == OP_INVLAP) out[t] = -x * T.elm2[n * MX + m];
+    else out[t] = x * T.trfilt[n * MX + m];
+}
+
+// (i g z): (re,im) -> (-g im, g re)
+__device__ __forceinline__ double irot(const double *a, int base, int c, double g)
+{
+    return (c & 1) ? g * a[base + c - 1] : -g * a[base + c + 1];
+}
+
+// uvspec (:351-387) and vds (:307-349) share one stencil:  A = ym*P(n-1) - yp*P(n+1) + i x Q ; B = -ym*Q(n-1) + yp*Q(n+1) + i x P
+// uvspec: P=vor,Q=div, x=uvdx(m,n), ym=uvdym, yp=uvdyp -> (A,B)=(ucos,vcos).  vds: P=ucos,Q=vcos, x=gradx(m), ym=vddym, yp=vddyp -> (vor,div)
+__global__ void k_uvvds(DevTables T, const double *__restrict__ P, const double *__restrict__ Q, double *__restrict__ A,
+                        double *__restrict__ B, int total, int is_vds)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int f = t / SPEC_N, e = t % SPEC_N, c = e % MX2, n = e / MX2, m = c >> 1;
+    const int fb = f * SPEC_N, row = fb + n * MX2;
+    const double gx = is_vds ? T.gradx[m] : T.uvdx[n * MX + m];
+    const double *ym = is_vds ? T.vddym : T.uvdym, *yp = is_vds ? T.vddyp : T.uvdyp;
+    const double zc = irot(Q, row, c, gx);      // i x Q
+    const double zp = irot(P, row, c, gx);      // i x P
+    double a, b;
+    if (n == 0) {
+        a = zc - yp[m] * P[row + MX2 + c];
+        b = zp + yp[m] * Q[row + MX2 + c];
+    } else if (n == NX - 1) {
+        a = ym[n * MX + m] * P[row - MX2 + c];
+        b = -ym[n * MX + m] * Q[row - MX2 + c];
+    } else {
+        a = ym[n * MX + m] * P[row - MX2 + c] - yp[n * MX + m] * P[row + MX2 + c] + zc;
+        b = -ym[n * MX + m] * Q[row - MX2 + c] + yp[n * MX + m] * Q[row + MX2 + c] + zp;
+    }
+    A[t] = a;
+    B[t] = b;
+}
+
+// grad (:271-305)
+__global__ void k_grad(DevTables T, const double *__restrict__ psi, double *__restrict__ dx, double *__restrict__ dy, int total)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int f = t / SPEC_N, e = t % SPEC_N, c = e % MX2, n = e / MX2, m = c >> 1;
+    const int row = f * SPEC_N + n * MX2;
+    dx[t] = irot(psi, row, c, T.gradx[m]);
+    double y;
+    if (n == 0) y = T.gradyp[m] * psi[row + MX2 + c];
+    else if (n == NX - 1) y = -T.gradym[n * MX + m] * psi[row - MX2 + c];
+    else y = -T.gradym[n * MX + m] * psi[row - MX2 + c] + T.gradyp[n * MX + m] * psi[row + MX2 + c];
+    dy[t] = y;
+}
+
+}  // namespace
+
+struct sml_spectral {
+    HostTables h;
+    DevTables d{};
+    std::vector<void *> allocs;
+    double *scratch = nullptr;      // 2 * nf_cap * SPEC_N for vdspec
+    int scratch_fields = 0;
+    double *hs_spec[4] = {nullptr, nullptr, nullptr, nullptr};   // host-call staging (F77 drop-ins)
+    double *hs_grid[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+template <class T>
+int up(sml_spectral *sp, const T **dst, const T *src, size_t n)
+{
+    T *p = nullptr;
+    int rc = sml::dev_upload(&p, src, n);
+    if (rc) return rc;
+    sp->allocs.push_back(p);
+    *dst = p;
+    return SML_OK;
+}
+
+int ensure_scratch(sml_spectral *sp, int nf)
+{
+    if (nf <= sp->scratch_fields) return SML_OK;
+    if (sp->scratch) (void)hipFree(sp->scratch);
+    sp->scratch = nullptr;
+    SML_HIP(hipMalloc((void **)&sp->scratch, (size_t)2 * nf * SPEC_N * sizeof(double)));
+    sp->scratch_fields = nf;
+    return SML_OK;
+}
+
+sml_spectral *g_sp = nullptr;   // used by the F77 drop-ins
+
+}  // namespace
+
+extern "C" {
+
+int sml_spectral_create(double a, sml_spectral **out)
+{
+    SML_REQUIRE(out && a > 0, "sml_spectral_create: bad arguments");
+    sml_spectral *sp = new sml_spectral;
+    build_tables(sp->h, a);
+    HostTables &h = sp->h;
+    int rc = 0;
+#define UP(field, src, n) if (!rc) rc = up(sp, &sp->d.field, src, n)
+    UP(pol, &h.pol[0][0][0], (size_t)IY * NX * MX);
+    UP(wt, h.wt, IY); UP(cosgr, h.cosgr, IL); UP(cosgr2, h.cosgr2, IL); UP(nsh2, h.nsh2, NX);
+    UP(twc, h.twc, IX); UP(tws, h.tws, IX);
+    UP(el2, &h.el2[0][0], NX * MX); UP(elm2, &h.elm2[0][0], NX * MX); UP(trfilt, &h.trfilt[0][0], NX * MX);
+    UP(gradx, h.gradx, MX); UP(gradym, &h.gradym[0][0], NX * MX); UP(gradyp, &h.gradyp[0][0], NX * MX);
+    UP(uvdx, &h.uvdx[0][0], NX * MX); UP(uvdym, &h.uvdym[0][0], NX * MX); UP(uvdyp, &h.uvdyp[0][0], NX * MX);
+    UP(vddym, &h.vddym[0][0], NX * MX); UP(vddyp, &h.vddyp[0][0], NX * MX);
+#undef UP
+    if (rc) { sml_spectral_destroy(sp); return rc; }
+    *out = sp;
+    return SML_OK;
+}
+
+int sml_spectral_destroy(sml_spectral *sp)
+{
+    if (!sp) return SML_OK;
+    for (void *p : sp->allocs) (void)hipFree(p);
+    if (sp->scratch) (void)hipFree(sp->scratch);
+    for (auto p : sp->hs_spec) if (p) (void)hipFree(p);
+    for (auto p : sp->hs_grid) if (p) (void)hipFree(p);
+    if (g_sp == sp) g_sp = nullptr;
+    delete sp;
+    return SML_OK;
+}
+
+int sml_spectral_get_table(sml_spectral *sp, int which, double *out, int capacity)
+{
+    SML_REQUIRE(sp && out, "sml_spectral_get_table: bad arguments");
+    const HostTables &h = sp->h;
+    const double *src = nullptr;
+    int n = 0;
+    std::vector<double> tmp;
+    switch (which) {
+    case 1: src = h.sia; n = IY; break;
+    case 2: src = h.coa; n = IY; break;
+    case 3: src = h.wt; n = IY; break;
+    case 4: src = h.wght; n = IY; break;
+    case 5: src = h.cosg; n = IL; break;
+    case 6: src = h.cosgr; n = IL; break;
+    case 7: src = h.cosgr2; n = IL; break;
+    case 8: src = &h.el2[0][0]; n = NX * MX; break;
+    case 9: src = &h.elm2[0][0]; n = NX * MX; break;
+    case 10: src = &h.el4[0][0]; n = NX * MX; break;
+    case 11: src = &h.trfilt[0][0]; n = NX * MX; break;
+    case 12: tmp.resize(NX); for (int i = 0; i < NX; ++i) tmp[i] = h.nsh2[i]; src = tmp.data(); n = NX; break;
+    case 13: src = &h.epsi[0][0]; n = NXP * MXP; break;
+    case 14: src = &h.repsi[0][0]; n = NXP * MXP; break;
+    case 15: src = h.consq; n = MXP; break;
+    case 16: src = h.gradx; n = MX; break;
+    case 17: src = &h.gradym[0][0]; n = NX * MX; break;
+    case 18: src = &h.gradyp[0][0]; n = NX * MX; break;
+    case 19: src = &h.uvdx[0][0]; n = NX * MX; break;
+    case 20: src = &h.uvdym[0][0]; n = NX * MX; break;
+    case 21: src = &h.uvdyp[0][0]; n = NX * MX; break;
+    case 22: src = &h.vddym[0][0]; n = NX * MX; break;
+    case 23: src = &h.vddyp[0][0]; n = NX * MX; break;
+    case 24:   // cpol(mx2,nx,iy): duplicate each wavenumber into its (re,im) pair
+        tmp.resize((size_t)MX2 * NX * IY);
+        for (int j = 0; j < IY; ++j) for (int nn = 0; nn < NX; ++nn) for (int c = 0; c < MX2; ++c)
+            tmp[((size_t)j * NX + nn) * MX2 + c] = h.pol[j][nn][c / 2];
+        src = tmp.data(); n = MX2 * NX * IY; break;
+    case 26: src = &h.sqrhlf; n = 1; break;
+    default: return sml::fail(SML_ERR_ARG, "sml_spectral_get_table: unknown table %d", which);
+    }
+    SML_REQUIRE(capacity >= n, "sml_spectral_get_table: capacity %d < %d", capacity, n);
+    memcpy(out, src, sizeof(double) * n);
+    return n;
+}
+
+int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf, int kcos, void *stream)
+{
+    SML_REQUIRE(sp && nf >= 0 && (kcos == 1 || kcos == 2) && (nf == 0 || (vorm && vorg)), "sml_spectral_grid: bad arguments");
+    if (!nf) return SML_OK;
+    hipLaunchKernelGGL(k_grid, dim3(nf), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+static int spec_scaled(sml_spectral *sp, const double *vorg, double *vorm, int nf, int scale, void *stream)
+{
+    hipLaunchKernelGGL(k_spec, dim3(nf), dim3(TT), 0, sml::as_stream(stream), sp->d, vorg, vorm, scale);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_spec(sml_spectral *sp, const double *vorg, double *vorm, int nf, void *stream)
+{
+    SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg)), "sml_spectral_spec: bad arguments");
+    if (!nf) return SML_OK;
+    return spec_scaled(sp, vorg, vorm, nf, 0, stream);
+}
+
+static int pointwise2(sml_spectral *sp, const double *p, const double *q, double *a, double *b, int nf, int is_vds, void *stream)
+{
+    const int total = nf * SPEC_N;
+    hipLaunchKernelGGL(k_uvvds, dim3((total + 255) / 256), dim3(256), 0, sml::as_stream(stream), sp->d, p, q, a, b, total, is_vds);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_vdspec(sml_spectral *sp, const double *ug, const double *vg, double *vorm, double *divm, int nf, int kcos, void *stream)
+{
+    SML_REQUIRE(sp && ug && vg && vorm && divm && nf >= 0, "sml_spectral_vdspec: bad arguments");
+    if (!nf) return SML_OK;
+    int rc = ensure_scratch(sp, nf);
+    if (rc) return rc;
+    double *um = sp->scratch, *vm = sp->scratch + (size_t)nf * SPEC_N;
+    const int scale = kcos == 2 ? 1 : 2;                // cosgr for kcos=2, cosgr2 otherwise (:429-443)
+    if ((rc = spec_scaled(sp, ug, um, nf, scale, stream))) return rc;
+    if ((rc = spec_scaled(sp, vg, vm, nf, scale, stream))) return rc;
+    return pointwise2(sp, um, vm, vorm, divm, nf, 1, stream);
+}
+
+int sml_spectral_uvspec(sml_spectral *sp, const double *vorm, const double *divm, double *ucosm, double *vcosm, int nf, void *stream)
+{
+    SML_REQUIRE(sp && vorm && divm && ucosm && vcosm && nf >= 0, "sml_spectral_uvspec: bad arguments");
+    if (!nf) return SML_OK;
+    return pointwise2(sp, vorm, divm, ucosm, vcosm, nf, 0, stream);
+}
+
+int sml_spectral_vds(sml_spectral *sp, const double *ucosm, const double *vcosm, double *vorm, double *divm, int nf, void *stream)
+{
+    SML_REQUIRE(sp && vorm && divm && ucosm && vcosm && nf >= 0, "sml_spectral_vds: bad arguments");
+    if (!nf) return SML_OK;
+    return pointwise2(sp, ucosm, vcosm, vorm, divm, nf, 1, stream);
+}
+
+int sml_spectral_grad(sml_spectral *sp, const double *psi, double *psdx, double *psdy, int nf, void *stream)
+{
+    SML_REQUIRE(sp && psi && psdx && psdy && nf >= 0, "sml_spectral_grad: bad arguments");
+    if (!nf) return SML_OK;
+    const int total = nf * SPEC_N;
+    hipLaunchKernelGGL(k_grad, dim3((total + 255) / 256), dim3(256), 0, sml::as_stream(stream), sp->d, psi, psdx, psdy, total);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+static int scale_op(sml_spectral *sp, const double *in, double *out, int nf, int op, void *stream)
+{
+    SML_REQUIRE(sp && in && out && nf >= 0, "spectral operator: bad arguments");
+    if (!nf) return SML_OK;
+    const int total = nf * SPEC_N;
+    hipLaunchKernelGGL(k_scale, dim3((total + 255) / 256), dim3(256), 0, sml::as_stream(stream), sp->d, in, out, total, op);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_lap(sml_spectral *sp, const double *strm, double *vorm, int nf, void *stream) { return scale_op(sp, strm, vorm, nf, OP_LAP, stream); }
+int sml_spectral_invlap(sml_spectral *sp, const double *vorm, double *strm, int nf, void *stream) { return scale_op(sp, vorm, strm, nf, OP_INVLAP, stream); }
+int sml_spectral_trunct(sml_spectral *sp, double *vor, int nf, void *stream) { return scale_op(sp, vor, vor, nf, OP_TRUNCT, stream); }
+
+// ---------------- F77 link-level drop-ins (host arrays, one field per call) ----------------
+static void die(const char *where)
+{
+    fprintf(stderr, "speedyml_hip: %s failed: %s\n", where, sml_last_error());
+    abort();     // the reference prints and `stop`s on library errors (src/mod_linalg.f90:18-22)
+}
+
+static sml_spectral *global_sp(const char *who)
+{
+    if (!g_sp) { sml::fail(SML_ERR_STATE, "%s called before parmtr_()", who); die(who); }
+    if (!g_sp->hs_spec[0]) {
+        for (auto &p : g_sp->hs_spec) if (hipMalloc((void **)&p, SPEC_N * sizeof(double)) != hipSuccess) { sml::fail(SML_ERR_HIP, "hipMalloc"); die(who); }
+        for (auto &p : g_sp->hs_grid) if (hipMalloc((void **)&p, GRID_N * sizeof(double)) != hipSuccess) { sml::fail(SML_ERR_HIP, "hipMalloc"); die(who); }
+    }
+    return g_sp;
+}
+
+#define H2D(dst, src, n) if (hipMemcpy(dst, src, (n) * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { sml::fail(SML_ERR_HIP, "hipMemcpy H2D"); die(__func__); }
+#define D2H(dst, src, n) if (hipMemcpy(dst, src, (n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { sml::fail(SML_ERR_HIP, "hipMemcpy D2H"); die(__func__); }
+#define CK(call) if ((call) != SML_OK) die(__func__)
+
+void parmtr_(const double *a)
+{
+    if (g_sp) sml_spectral_destroy(g_sp);
+    g_sp = nullptr;
+    sml_spectral *sp = nullptr;
+    if (sml_spectral_create(*a, &sp) != SML_OK) die("parmtr_");
+    g_sp = sp;
+}
+
+void inifft_(void) {}   // the twiddle table is part of sml_spectral_create
+
+void grid_(const double *vorm, double *vorg, const int *kcos)
+{
+    sml_spectral *sp = global_sp("grid_");
+    H2D(sp->hs_spec[0], vorm, SPEC_N);
+    CK(sml_spectral_grid(sp, sp->hs_spec[0], sp->hs_grid[0], 1, *kcos, nullptr));
+    D2H(vorg, sp->hs_grid[0], GRID_N);
+}
+
+void spec_(const double *vorg, double *vorm)
+{
+    sml_spectral *sp = global_sp("spec_");
+    H2D(sp->hs_grid[0], vorg, GRID_N);
+    CK(sml_spectral_spec(sp, sp->hs_grid[0], sp->hs_spec[0], 1, nullptr));
+    D2H(vorm, sp->hs_spec[0], SPEC_N);
+}
+
+void vdspec_(const double *ug, const double *vg, double *vorm, double *divm, const int *kcos)
+{
+    sml_spectral *sp = global_sp("vdspec_");
+    H2D(sp->hs_grid[0], ug, GRID_N);
+    H2D(sp->hs_grid[1], vg, GRID_N);
+    CK(sml_spectral_vdspec(sp, sp->hs_grid[0], sp->hs_grid[1], sp->hs_spec[0], sp->hs_spec[1], 1, *kcos, nullptr));
+    D2H(vorm, sp->hs_spec[0], SPEC_N);
+    D2H(divm, sp->hs_spec[1], SPEC_N);
+}
+
+void uvspec_(const double *vorm, const double *divm, double *ucosm, double *vcosm)
+{
+    sml_spectral *sp = global_sp("uvspec_");
+    H2D(sp->hs_spec[0], vorm, SPEC_N);
+    H2D(sp->hs_spec[1], divm, SPEC_N);
+    CK(sml_spectral_uvspec(sp, sp->hs_spec[0], sp->hs_spec[1], sp->hs_spec[2], sp->hs_spec[3], 1, nullptr));
+    D2H(ucosm, sp->hs_spec[2], SPEC_N);
+    D2H(vcosm, sp->hs_spec[3], SPEC_N);
+}
+
+void vds_(const double *ucosm, const double *vcosm, double *vorm, double *divm)
+{
+    sml_spectral *sp = global_sp("vds_");
+    H2D(sp->hs_spec[0], ucosm, SPEC_N);
+    H2D(sp->hs_spec[1], vcosm, SPEC_N);
+    CK(sml_spectral_vds(sp, sp->hs_spec[0], sp->hs_spec[1], sp->hs_spec[2], sp->hs_spec[3], 1, nullptr));
+    D2H(vorm, sp->hs_spec[2], SPEC_N);
+    D2H(divm, sp->hs_spec[3], SPEC_N);
+}
+
+void grad_(const double *psi, double *psdx, double *psdy)
+{
+    sml_spectral *sp = global_sp("grad_");
+    H2D(sp->hs_spec[0], psi, SPEC_N);
+    CK(sml_spectral_grad(sp, sp->hs_spec[0], sp->hs_spec[1], sp->hs_spec[2], 1, nullptr));
+    D2H(psdx, sp->hs_spec[1], SPEC_N);
+    D2H(psdy, sp->hs_spec[2], SPEC_N);
+}
+
+void lap_(const double *strm, double *vorm)
+{
+    sml_spectral *sp = global_sp("lap_");
+    H2D(sp->hs_spec[0], strm, SPEC_N);
+    CK(sml_spectral_lap(sp, sp->hs_spec[0], sp->hs_spec[1], 1, nullptr));
+    D2H(vorm, sp->hs_spec[1], SPEC_N);
+}
+
+void invlap_(const double *vorm, double *strm)
+{
+    sml_spectral *sp = global_sp("invlap_");
+    H2D(sp->hs_spec[0], vorm, SPEC_N);
+    CK(sml_spectral_invlap(sp, sp->hs_spec[0], sp->hs_spec[1], 1, nullptr));
+    D2H(strm, sp->hs_spec[1], SPEC_N);
+}
+
+void trunct_(double *vor)
+{
+    sml_spectral *sp = global_sp("trunct_");
+    H2D(sp->hs_spec[0], vor, SPEC_N);
+    CK(sml_spectral_trunct(sp, sp->hs_spec[0], 1, nullptr));
+    D2H(vor, sp->hs_spec[0], SPEC_N);
+}
+
+}  // extern "C"
