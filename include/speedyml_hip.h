@@ -180,6 +180,17 @@ int sml_exchange_gather(sml_exchange *ex, const double *g_dev, const double *f_d
 /* where each slot's outvec goes in the region-ordered slab: offset = region*max_n_out */
 int sml_exchange_pack_outvec(sml_exchange *ex, double *all_outvec_dev, void *stream);
 
+/* Hybrid <-> SPEEDY hand-off around iogrid modes 30/31 (src/ppo_iogrid.f90:497-601):
+ *  to_fields  : G -> 33 grid fields [T(8) | u(8) | v(8) | q(8) | ps(1)][48][96], rounded through real(4) exactly as the
+ *               reference's ugr4..psgr4 staging does (quirk Q3, :43-44,500-517) and with q < 0 -> 0 (:511-513);
+ *  from_fields: 33 grid fields -> F (layout of the first two parts of G), with SPEEDY's output floor q < 1e-6 -> 1e-6
+ *               (src/mpires.f90:1648-1650);
+ *  check      : the physical-range guard |u|<=150, |v|<=120, 160<=T<=330, -6<=q<=30 (:563-577); *safe_dev (int32 on
+ *               the device) is set to 0 when the state is unsafe, left untouched otherwise. */
+int sml_handoff_to_fields(const double *g_dev, double *fields_dev, void *stream);
+int sml_handoff_from_fields(const double *fields_dev, double *f_dev, void *stream);
+int sml_handoff_check(const double *fields_dev, int32_t *safe_dev, void *stream);
+
 /* ===================================================================================================
  * 4. spectral transforms -- replaces src/spe_spectral.f90 + src/spe_subfft_fftpack.f90 (FFTPACK)
  * =================================================================================================== */

@@ -89,9 +89,83 @@ __global__ void k_pack(const double *__restrict__ slab, int stride, const int32_
     all_out[(size_t)region_of_slot[slot] * stride + j] = slab[(size_t)slot * stride + j];
 }
 
+// ---- hybrid <-> SPEEDY hand-off (src/ppo_iogrid.f90:497-601) ----
+constexpr int NGP = 96 * 48, NLEV = 8, NFIELD = 33;
+
+// field f: 0..7 T(k), 8..15 u(k), 16..23 v(k), 24..31 q(k), 32 ps ; G4 variable order is (T,u,v,q) (:499-505)
+__global__ void k_to_fields(const double *__restrict__ g, double *__restrict__ fields)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= NFIELD * NGP) return;
+    const int f = t / NGP, p = t % NGP;
+    double v;
+    if (f < 32) {
+        const int var = f >> 3, k = f & 7;
+        v = g[SML_G4_OFF + ((size_t)k * NGP + p) * 4 + var];
+    } else {
+        v = g[SML_G2_OFF + p];
+    }
+    float v4 = (float)v;                           // ugr4..psgr4 are real(4): quirk Q3
+    if (f >= 24 && f < 32 && v4 < 0.0f) v4 = 0.0f;  // where(qgr4 < 0.0) qgr4 = 0.0
+    fields[t] = (double)v4;
+}
+
+__global__ void k_from_fields(const double *__restrict__ fields, double *__restrict__ fo)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= NFIELD * NGP) return;
+    const int f = t / NGP, p = t % NGP;
+    double v = fields[t];
+    if (f < 32) {
+        const int var = f >> 3, k = f & 7;
+        if (var == 3 && v < 0.000001) v = 0.000001;          // run_model, src/mpires.f90:1648-1650
+        fo[SML_G4_OFF + ((size_t)k * NGP + p) * 4 + var] = v;
+    } else {
+        fo[SML_G2_OFF + p] = v;
+    }
+}
+
+__global__ void k_check(const double *__restrict__ fields, int32_t *__restrict__ safe)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 32 * NGP) return;
+    const int var = (t / NGP) >> 3;
+    const double v = fields[t];
+    bool bad;
+    if (var == 0) bad = v < 160.0 || v > 330.0;
+    else if (var == 1) bad = v < -150.0 || v > 150.0;
+    else if (var == 2) bad = v < -120.0 || v > 120.0;
+    else bad = v < -6.0 || v > 30.0;
+    if (bad || v != v) *safe = 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int sml_handoff_to_fields(const double *g_dev, double *fields_dev, void *stream)
+{
+    SML_REQUIRE(g_dev && fields_dev, "sml_handoff_to_fields: null pointer");
+    hipLaunchKernelGGL(k_to_fields, dim3((NFIELD * NGP + 255) / 256), dim3(256), 0, sml::as_stream(stream), g_dev, fields_dev);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_handoff_from_fields(const double *fields_dev, double *f_dev, void *stream)
+{
+    SML_REQUIRE(f_dev && fields_dev, "sml_handoff_from_fields: null pointer");
+    hipLaunchKernelGGL(k_from_fields, dim3((NFIELD * NGP + 255) / 256), dim3(256), 0, sml::as_stream(stream), fields_dev, f_dev);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_handoff_check(const double *fields_dev, int32_t *safe_dev, void *stream)
+{
+    SML_REQUIRE(safe_dev && fields_dev, "sml_handoff_check: null pointer");
+    hipLaunchKernelGGL(k_check, dim3((32 * NGP + 255) / 256), dim3(256), 0, sml::as_stream(stream), fields_dev, safe_dev);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
 
 int sml_exchange_create(sml_bank *bank, int number_of_regions, const int32_t *region_of_slot, int nslots,
                         int overlap, int precip_bool, const int32_t *sst_input_of_slot, sml_exchange **out)

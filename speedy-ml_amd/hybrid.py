@@ -1,23 +1,29 @@
 """Device-resident hybrid step: the MI355X form of one iteration of program main's `t` loop
 (src/parallelmain.f90:207-272) for the regions owned by one rank.
 
-    predict (all resident reservoirs)            src/parallelmain.f90:226-251 -> mod_reservoir.f90:1418
-    exchange: pack / [all-gather] / scatter+clamp  src/mpires.f90:309-490
-    SPEEDY hand-off transforms + step schedule   src/ppo_iogrid.f90:497-601, src/dyn_grtend.f90:61-277
-    gather + standardise next inputs             src/mpires.f90:580-775
+    predict (all resident reservoirs)               src/parallelmain.f90:226-251 -> mod_reservoir.f90:1418
+    exchange: [all-gather] / scatter + clamps       src/mpires.f90:309-490
+    SPEEDY hand-off iogrid(30)/(31) transforms      src/ppo_iogrid.f90:497-601
+    SPEEDY time-step transform schedule             src/dyn_grtend.f90:61-277, src/phy_phypar.f90:54-66
+    gather + standardise next inputs                src/mpires.f90:580-775
 
 Everything runs through libspeedyml_hip.so; torch is used only for device buffers, streams and
-torch.distributed (RCCL).  SPEEDY's grid-point dynamics and column physics stay on the host in the
-reference and are out of scope: the transform schedule of one 6-h window is executed on
-the device-resident spectral state with the grid-point work left out (see DESIGN.md "What a bench step is").
+torch.distributed (RCCL).  SPEEDY's grid-point dynamics and column physics stay on the host in the reference and
+are out of scope: the forecast handed back to the reservoirs is the state after the
+hand-off transforms (single-precision rounding + triangular truncation), and the transform schedule of the 26
+time steps of one 6-h window is replayed on the device-resident spectral state with the grid-point work left out
+(DESIGN.md "What a bench step is").
 """
 import numpy as np
 
 from . import domain
+from .exchange import Exchange, handoff_check, handoff_from_fields, handoff_to_fields
 from .reservoir import ReservoirBank
-from .synth import make_reservoir
+from .spectral import IL, IX, MX2, NX, Spectral
+from .synth import make_reservoir, synthetic_state
 
 NREG = 1152
+STEPS_PER_WINDOW = 26          # stepone (2 steps) + 24 leapfrog steps of one 6-h window
 
 
 def region_classes(sea_mask):
@@ -30,29 +36,29 @@ def region_classes(sea_mask):
     return out
 
 
-def build_bank(regions, classes, seed=20240000, verbose=False):
+def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False):
     """Load one synthetic trained reservoir per region into a ReservoirBank (slot i <-> regions[i]).
 
-    To keep host-side generation short, one base reservoir is generated per size class and every region of the
-    class gets the same A / W_in with a region-dependent W_out scale and statistics: throughput does not depend
-    on the values, and every slot still owns its private copy in HBM."""
+    One base reservoir is generated per size class and shared by the regions of the class (each slot still owns
+    a private copy in HBM; throughput does not depend on the values); statistics are per region.
+    n_override = nodes per input (reference: NINT(6000/d)) -> small reservoirs for parity tests."""
     bank = ReservoirBank(len(regions))
-    base = {}
-    sizes = {}
+    base, sizes, keep = {}, {}, {}
     for slot, r in enumerate(regions):
         pole, sst = classes[r]
         g = domain.initializedomain(NREG, r)
         s = domain.allocate_res_sizes(g, sst_bool_input=sst)
-        key = (s.n, s.reservoir_numinputs)
+        d = s.reservoir_numinputs
+        n = s.n if n_override is None else n_override * d
+        key = (n, d)
         if key not in base:
-            b = make_reservoir(n=s.n, d=s.reservoir_numinputs, n_model=s.chunk_size_speedy, n_out=s.chunk_size_prediction,
+            b = make_reservoir(n=n, d=d, n_model=s.chunk_size_speedy, n_out=s.chunk_size_prediction,
                                seed=seed + len(base), dense_win=False)
-            q = b.win_q
-            b.win_rows = np.arange(1, s.n + 1, dtype=np.int32)
-            b.win_cols = (np.arange(s.n, dtype=np.int32) // q + 1).astype(np.int32)
+            b.win_rows = np.arange(1, n + 1, dtype=np.int32)
+            b.win_cols = (np.arange(n, dtype=np.int32) // b.win_q + 1).astype(np.int32)
             base[key] = b
             if verbose:
-                print(f"class n={s.n} d={s.reservoir_numinputs} k={b.k}", flush=True)
+                print(f"class n={n} d={d} k={b.k}", flush=True)
         b = base[key]
         rng = np.random.default_rng(seed + 7919 * (r + 1))
         mean, std = rng.uniform(-1.0, 1.0, 36), rng.uniform(0.5, 2.0, 36)
@@ -60,41 +66,139 @@ def build_bank(regions, classes, seed=20240000, verbose=False):
         bank.load_sparse_win(slot, b.n, b.d, b.n_model, b.n_out, b.rows, b.cols, b.vals, b.win_rows, b.win_cols,
                              b.win_vals, b.wout, mean, std, stat)
         sizes[slot] = s
+        keep[slot] = (b, mean, std, stat)
+    bank.host_copies = keep
     return bank, sizes
+
+
+def device_view(ptr, shape):
+    """torch view (no copy) of device memory owned by the C-ABI library."""
+    import torch
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(np.prod(shape)),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device="cuda").view(*shape)
 
 
 class HybridRank:
     """All state of one rank for the device-resident step loop."""
 
-    def __init__(self, regions, classes, world=1, rank=0, sea_mask=None, mode="hybrid", seed=20240000):
+    def __init__(self, regions, classes, world=1, rank=0, sea_mask=None, mode="hybrid", seed=20240000, n_override=None,
+                 replay_steps=STEPS_PER_WINDOW):
         import torch
         self.torch = torch
         self.regions, self.classes, self.world, self.rank, self.mode = list(regions), classes, world, rank, mode
-        self.bank, self.sizes = build_bank(self.regions, classes, seed=seed)
-        rng = np.random.default_rng(seed + rank)
+        self.replay_steps = replay_steps
+        self.bank, self.sizes = build_bank(self.regions, classes, seed=seed, n_override=n_override)
         cap = self.bank.capacity
-        # feedback / local_model start from standardised noise; resident before the timed region
-        fb = torch.from_numpy(rng.standard_normal((cap, self.bank.max_d)))
-        lm = torch.from_numpy(rng.standard_normal((cap, self.bank.max_n_model)))
-        self._view(self.bank.feedback_ptr, (cap, self.bank.max_d)).copy_(fb)
-        self._view(self.bank.local_model_ptr, (cap, self.bank.max_n_model)).copy_(lm)
+        self.feedback = device_view(self.bank.feedback_ptr, (cap, self.bank.max_d))
+        self.local_model = device_view(self.bank.local_model_ptr, (cap, self.bank.max_n_model))
+        self.outvec = device_view(self.bank.outvec_ptr, (cap, self.bank.max_n_out))
+        dev = "cuda"
+        f64 = torch.float64
+        self.G = torch.zeros(domain.G_SIZE, dtype=f64, device=dev)
+        self.F = torch.zeros(domain.G_SIZE, dtype=f64, device=dev)
+        g4, logp, precip, sst = synthetic_state(seed)
+        self.base_sst = torch.from_numpy(np.ascontiguousarray(sst.ravel())).to(dev)
+        self.G[domain.G4_OFF:domain.G2_OFF] = torch.from_numpy(g4.ravel()).to(dev)
+        self.G[domain.G2_OFF:domain.GP_OFF] = torch.from_numpy(logp.ravel()).to(dev)
+        self.G[domain.GP_OFF:domain.GS_OFF] = torch.from_numpy(precip.ravel()).to(dev)
+        self.G[domain.GS_OFF:domain.GT_OFF] = self.base_sst
+        # TISR table: one (96,48) slice per 6-h step of a 365-day year (full_tisr, src/mod_reservoir.f90:890-909)
+        lat = np.deg2rad(np.linspace(-87.159, 87.159, 48))[None, :, None]
+        lon = np.deg2rad(np.arange(96) * 3.75)[None, None, :]
+        hours = (np.arange(1460) * 6.0)[:, None, None]
+        decl = np.deg2rad(23.44) * np.sin(2 * np.pi * (hours / 24.0 - 80.0) / 365.0)
+        cosz = np.sin(lat) * np.sin(decl) + np.cos(lat) * np.cos(decl) * np.cos(2 * np.pi * hours / 24.0 + lon - np.pi)
+        self.tisr = torch.from_numpy(np.maximum(0.0, cosz) * 1361.0 * 3600.0).to(dev).contiguous()   # [1460][48][96]
+        self.t = 0
+        if mode == "hybrid":
+            sst_flags = [int(classes[r][1]) for r in self.regions]
+            self.ex = Exchange(self.bank, NREG, self.regions, sst_flags)
+            self.sp = Spectral()
+            self.all_out = torch.zeros((NREG, self.bank.max_n_out), dtype=f64, device=dev)
+            self.fields = torch.zeros((33, IL, IX), dtype=f64, device=dev)
+            self.fields_out = torch.zeros((33, IL, IX), dtype=f64, device=dev)
+            self.spec_state = torch.zeros((33, NX, MX2), dtype=f64, device=dev)     # [t(8) | vor(8) | div(8) | q(8) | ps]
+            self.uv = torch.zeros((16, NX, MX2), dtype=f64, device=dev)
+            self.safe = torch.ones(1, dtype=torch.int32, device=dev)
+            # scratch for the time-step transform schedule (91 inverse + 73 forward per step)
+            self.sched_spec = torch.zeros((91, NX, MX2), dtype=f64, device=dev)
+            self.sched_grid = torch.zeros((91, IL, IX), dtype=f64, device=dev)
+            self.sched_out = torch.zeros((98, NX, MX2), dtype=f64, device=dev)
+            self.even_split = (NREG % world == 0)
+            # first inputs: gather from the synthetic state (forecast = the same state) so feedback is realistic
+            self.G[domain.GT_OFF:] = self.tisr[0].reshape(-1)
+            self.ex.gather(self.G, self.G)
+        else:
+            rng = np.random.default_rng(seed + rank)
+            self.feedback.copy_(torch.from_numpy(rng.standard_normal((cap, self.bank.max_d))))
+            self.local_model.copy_(torch.from_numpy(rng.standard_normal((cap, self.bank.max_n_model))))
         torch.cuda.synchronize()
 
-    def _view(self, ptr, shape):
-        """torch view (no copy) of device memory owned by the C-ABI library."""
-        import ctypes
-        torch = self.torch
-        n = int(np.prod(shape))
+    # ------------------------------------------------------------------ the step
+    def exchange_outvec(self, stream):
+        """All ranks end up with every region's outvec in region order (the MPI gather-to-root of
+        src/mpires.f90:347-454 becomes one RCCL all-gather of the contiguous outvec slab)."""
+        if self.world == 1:
+            return self.outvec
+        import torch.distributed as dist
+        if self.even_split:
+            dist.all_gather_into_tensor(self.all_out, self.outvec)
+        else:   # remainder rule of processor_decomposition: ragged blocks -> pack into region order, then sum
+            self.all_out.zero_()
+            self.ex.pack_outvec(self.all_out, stream)
+            dist.all_reduce(self.all_out)
+        return self.all_out
 
-        class _Holder:
-            pass
-        h = _Holder()
-        h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
-        return torch.as_tensor(h, device="cuda").view(*shape)
+    def handoff(self, stream):
+        """iogrid(30) then iogrid(31) (src/ppo_iogrid.f90:497-601) on the device, 33 fields per launch."""
+        sp, S = self.sp, self.spec_state
+        handoff_to_fields(self.G, self.fields, stream)
+        fT, fu, fv, fq_ps = self.fields[0:8], self.fields[8:16], self.fields[16:24], self.fields[24:33]
+        sp.vdspec(fu, fv, 2, out=(S[8:16], S[16:24]), stream=stream)
+        sp.spec(fT, out=S[0:8], stream=stream)
+        sp.spec(fq_ps, out=S[24:33], stream=stream)
+        sp.trunct(S, stream=stream)
+        # back to grid point space: uvspec -> grid(.,2) for u,v ; grid(.,1) for t, q, ps
+        sp.uvspec(S[8:16], S[16:24], out=(self.uv[0:8], self.uv[8:16]), stream=stream)
+        sp.grid(self.uv, 2, out=self.fields_out[8:24], stream=stream)
+        sp.grid(S[0:8], 1, out=self.fields_out[0:8], stream=stream)
+        sp.grid(S[24:33], 1, out=self.fields_out[24:33], stream=stream)
+        handoff_check(self.fields_out, self.safe, stream)
+        handoff_from_fields(self.fields_out, self.F, stream)
+
+    def speedy_transform_schedule(self, stream):
+        """The 164 transforms of one SPEEDY time step (SURVEY Appendix C 'Schedule inside one step()') as batched
+        launches on the device-resident spectral state: 57 inverse with kcos=1, 34 with kcos=2, 24 vdspec(.,.,2)
+        (= 48 scaled forward transforms + vds) and 25 plain forward transforms."""
+        sp = self.sp
+        sp.grid(self.sched_spec[0:57], 1, out=self.sched_grid[0:57], stream=stream)
+        sp.grid(self.sched_spec[57:91], 2, out=self.sched_grid[57:91], stream=stream)
+        sp.vdspec(self.sched_grid[0:24], self.sched_grid[24:48], 2, out=(self.sched_out[0:24], self.sched_out[24:48]), stream=stream)
+        sp.spec(self.sched_grid[48:73], out=self.sched_out[48:73], stream=stream)
 
     def step(self, stream):
         self.bank.predict(stream=stream)
+        if self.mode == "sweep":
+            return
+        allv = self.exchange_outvec(stream)
+        self.ex.scatter(allv, self.G, base_sst=self.base_sst, stream=stream)
+        self.handoff(stream)
+        if self.replay_steps:
+            # inputs of the replay: the hand-off's spectral state, tiled over the 91 schedule slots
+            self.sched_spec[0:33].copy_(self.spec_state)
+            self.sched_spec[33:66].copy_(self.spec_state)
+            self.sched_spec[66:91].copy_(self.spec_state[0:25])
+            for _ in range(self.replay_steps):
+                self.speedy_transform_schedule(stream)
+        self.t += 1
+        self.G[domain.GT_OFF:].copy_(self.tisr[self.t % self.tisr.shape[0]].reshape(-1))
+        self.ex.gather(self.G, self.F, stream=stream)
 
+    # ------------------------------------------------------------------ measurement helpers
     def timing(self, on):
         from ._lib import check, lib
         check(lib().sml_bank_timing(self.bank._h, 1 if on else 0))
@@ -107,12 +211,20 @@ class HybridRank:
         return {"update_ms": um.value, "update_launches": uc.value, "readout_ms": rm.value, "readout_launches": rc.value}
 
     def describe(self):
-        return {"workload": "config3 sweep-only: batched predict of the rank's resident reservoirs" if self.mode == "sweep"
-                else "config3 hybrid step", "regions_total": NREG, "regions_this_rank": len(self.regions),
-                "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s)"}
+        if self.mode == "sweep":
+            wl = "config3 sweep-only: batched predict of the rank's resident reservoirs"
+        else:
+            wl = ("BASELINE config 3: 1152-reservoir batched predict + region exchange (scatter, clamps, gather, standardise) "
+                  "+ SPEEDY hand-off transforms (33 forward, 33 inverse) + transform schedule of %d SPEEDY time steps "
+                  "(91 inverse + 73 forward each) on the device; host grid-point dynamics/column physics excluded "
+                  "(SURVEY section 8: out of scope)" % self.replay_steps)
+        return {"workload": wl, "regions_total": NREG, "regions_this_rank": len(self.regions),
+                "transforms_per_step": 66 + 164 * self.replay_steps if self.mode == "hybrid" else 0,
+                "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s); "
+                               + ("one all-gather of the outvec slab per step" if self.world > 1 else "no collective")}
 
-    def cpu_baseline(self, budget_s=15.0):
-        """Reference-faithful CPU path (oracle, 1 core) on a bounded sample of the same workload."""
+    def cpu_baseline(self, budget_s=12.0):
+        """Reference-faithful CPU path (the oracle, 1 core) on a bounded sample of the same workload."""
         import os
         import sys
         import time
@@ -128,7 +240,23 @@ class HybridRank:
             x, out = o.predict_raw(r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, 1.0,
                                    r.feedback, r.local_model, x)
             n += 1
-        per = (time.perf_counter() - t0) / n
-        return {"value": 1.0 / (per * NREG), "unit": "steps/s", "cores": 1, "kind": "port",
-                "sample": f"{n} reference-faithful predict calls (COO SpMV, dense 26.5 MB W_in matmul, W_out GEMV) of one "
-                          f"interior reservoir, {per * 1e3:.2f} ms each, extrapolated to 1152 per step; reservoir part only"}
+        per_predict = (time.perf_counter() - t0) / n
+        sample = (f"{n} reference-faithful predict calls (COO SpMV, dense 26.5 MB W_in matmul, W_out GEMV) of one interior "
+                  f"reservoir: {per_predict * 1e3:.3f} ms each, x1152 per step")
+        total = per_predict * NREG
+        if self.mode == "hybrid":
+            rng = np.random.default_rng(1)
+            v = rng.standard_normal((MX2, NX))
+            gfield = rng.standard_normal((IX, IL))
+            t1 = time.perf_counter()
+            m = 0
+            while time.perf_counter() - t1 < 3.0:
+                o.grid(v, 1)
+                o.spec(gfield)
+                m += 1
+            per_pair = (time.perf_counter() - t1) / m
+            ntr = 66 + 164 * self.replay_steps
+            total += per_pair * ntr / 2.0
+            sample += (f"; {m} oracle grid+spec pairs (direct-DFT restatement): {per_pair * 1e6:.0f} us per pair, "
+                       f"x{ntr // 2} pairs per step; exchange tilers not timed (small)")
+        return {"value": 1.0 / total, "unit": "steps/s", "cores": 1, "kind": "port", "sample": sample}
