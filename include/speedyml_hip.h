@@ -241,8 +241,12 @@ void trunct_(double *vor);
  * All device, column-major as in the reference: states (n,m), model (n_model,m), y (n_out,m). */
 int sml_train_accumulate(const double *states_dev, const double *model_dev, const double *y_dev,
                          int n, int n_model, int n_out, int m, double *c_dev, double *b_dev, void *stream);
-/* fit_chunk_hybrid: regularise the diagonal, solve C^T Z = (B+prior)^T by LU with partial pivoting, wout = Z^T.
- * c_dev is overwritten by its LU factors.  wout_dev: (n_out, n_aug) column-major. */
+/* sml_train_accumulate updates only the tiles of C on or below the diagonal (half the flops and half the C traffic of
+ * the reference's full DGEMM); this mirrors them into the upper triangle (sml_train_fit calls it itself). */
+int sml_train_symmetrize(double *c_dev, int n_aug, void *stream);
+/* fit_chunk_hybrid: regularise the diagonal, solve C^T Z = (B+prior)^T by LU with partial pivoting (dgesv), wout = Z^T.
+ * c_dev is symmetrised in place (not destroyed).  wout_dev: (n_out, n_aug) column-major.  Synchronises the stream.
+ * Returns SML_ERR_NUMERIC when a pivot is exactly zero (dgesv info > 0). */
 int sml_train_fit(double *c_dev, const double *b_dev, int n, int n_model, int n_out, double beta_res, double beta_model,
                   double prior_val, int using_prior, double *wout_dev, void *stream);
 

@@ -1,0 +1,408 @@
+// Ridge-regression training on gfx950: fp64-MFMA accumulation of the Gram matrices and the LU solve.
+//
+// Replaces chunking_matmul (src/mod_reservoir.f90:1645-1701: temp = matmul(targetdata, transpose(aug)); DGEMM('N','N',
+// n,n,m, aug, transpose(aug))), fit_chunk_hybrid (:1235-1334) and mldivide = dgesv (src/mod_linalg.f90:109-151).
+//
+//   k_gemm_acc : C(i,j) += alpha * sum_k A(i,k) B(j,k) with v_mfma_f64_16x16x4_f64.  128x128 tile per 256-thread
+//                workgroup, 64x64 per wavefront (4x4 MFMA tiles, 128 accumulator VGPRs), K-tile 16 staged through
+//                LDS with a 144-double row stride (rows land 128 B apart modulo the 256-B bank period, so the
+//                16-lane x 4-row operand reads are conflict free).  The MFMA is issued as D[j][i] = B.A so that the
+//                accumulator's lane index runs along i, the contiguous direction of the column-major C: every
+//                16-lane group stores 128 contiguous bytes.  For the symmetric update only tiles on or below the
+//                diagonal are computed; sml_train_fit mirrors them once before factorising.
+//   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on [A | B] so that the forward
+//                substitution of the right-hand sides rides along: panel (one workgroup, pivot search by
+//                workgroup reduction) -> row interchanges outside the panel -> U12 = L11^-1 A12 -> trailing update
+//                with k_gemm_acc (alpha = -1) ; then a blocked back substitution.
+// All matrices are column-major fp64, as in the reference.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, KT = 16, LDS_LD = 144, GT = 256;
+constexpr int LU_NB = 32;      // LU panel width
+
+// Staging of one 128 x 16 operand tile: element (r, k) = p[r * sr + k * sk], zero outside rows < nrows, k < K.
+// Split in two halves (T14-style): stage_load issues the 8 global loads into registers early, stage_write puts them
+// into LDS after the barrier, so the loads of K-tile t+1 fly under the MFMAs of K-tile t.
+template <bool K_CONTIG>
+__device__ __forceinline__ void stage_load(const double *__restrict__ p, long sr, long sk, int r0, int nrows, int k0, int K, double (&v)[8])
+{
+    if (!K_CONTIG) {
+        const int r = threadIdx.x & 127, kb = threadIdx.x >> 7;
+        const bool rok = r0 + r < nrows;
+        const double *q = p + (long)(r0 + r) * sr + (long)(k0 + kb) * sk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (rok && k0 + kb + 2 * i < K) ? q[(long)(2 * i) * sk] : 0.0;
+    } else {
+        const int k = threadIdx.x & 15, rb = threadIdx.x >> 4;
+        const bool kok = k0 + k < K;
+        const double *q = p + (long)(r0 + rb) * sr + (long)(k0 + k) * sk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (kok && r0 + rb + 16 * i < nrows) ? q[(long)(16 * i) * sr] : 0.0;
+    }
+}
+
+template <bool K_CONTIG>
+__device__ __forceinline__ void stage_write(const double (&v)[8], double (*dst)[LDS_LD])
+{
+    if (!K_CONTIG) {
+        const int r = threadIdx.x & 127, kb = threadIdx.x >> 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[kb + 2 * i][r] = v[i];
+    } else {
+        const int k = threadIdx.x & 15, rb = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[k][rb + 16 * i] = v[i];
+    }
+}
+
+// C[i + j*ldc] += alpha * sum_k A(i,k) * B(j,k);  lower_only: skip tiles strictly above the diagonal
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(GT, 2) void k_gemm_acc(const double *__restrict__ A, long sai, long sak, const double *__restrict__ B,
+                                                     long sbj, long sbk, double *__restrict__ C, long ldc, int M, int N, int K,
+                                                     double alpha, int lower_only)
+{
+    __shared__ double As[KT][LDS_LD];
+    __shared__ double Bs[KT][LDS_LD];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (lower_only && tj > ti) return;
+    const int i0 = ti * BM, j0 = tj * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4d acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    double ra[8], rb[8];
+    stage_load<A_KC>(A, sai, sak, i0, M, 0, K, ra);
+    stage_load<B_KC>(B, sbj, sbk, j0, N, 0, K, rb);
+    for (int k0 = 0; k0 < K; k0 += KT) {
+        __syncthreads();                       // everyone is done reading the previous tile
+        stage_write<A_KC>(ra, As);
+        stage_write<B_KC>(rb, Bs);
+        __syncthreads();
+        if (k0 + KT < K) {                     // next tile's loads stay in flight during the MFMAs below
+            stage_load<A_KC>(A, sai, sak, i0, M, k0 + KT, K, ra);
+            stage_load<B_KC>(B, sbj, sbk, j0, N, k0 + KT, K, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = As[kk + l4][wi + 16 * t + l15];   // A(i,k) -> MFMA "B" operand (k x col=i)
+                bf[t] = Bs[kk + l4][wj + 16 * t + l15];   // B(j,k) -> MFMA "A" operand (row=j x k)
+            }
+#pragma unroll
+            for (int tjj = 0; tjj < 4; ++tjj)
+#pragma unroll
+                for (int tii = 0; tii < 4; ++tii)
+                    acc[tjj][tii] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[tjj], af[tii], acc[tjj][tii], 0, 0, 0);
+        }
+    }
+    // D[row = j_local = l4 + 4 r][col = i_local = l15]: 16 lanes store 128 contiguous bytes of one column of C
+#pragma unroll
+    for (int tjj = 0; tjj < 4; ++tjj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + wj + 16 * tjj + l4 + 4 * r;
+            if (j >= N) continue;
+            double *cj = C + (long)j * ldc;
+#pragma unroll
+            for (int tii = 0; tii < 4; ++tii) {
+                const int i = i0 + wi + 16 * tii + l15;
+                if (i < M) cj[i] = cj[i] + alpha * acc[tjj][tii][r];
+            }
+        }
+}
+
+__global__ void k_symmetrize(double *__restrict__ c, int n)
+{   // upper <- lower^T, tile-wise through LDS so both the read and the write are contiguous
+    __shared__ double t[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj >= bi) return;                       // strictly-lower tiles feed the strictly-upper ones
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) {
+        const int i = bi * 32 + tx, j = bj * 32 + y;
+        t[y][tx] = (i < n && j < n) ? c[(long)i + (long)j * n] : 0.0;
+    }
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) {
+        const int i = bj * 32 + tx, j = bi * 32 + y;      // transposed position
+        if (i < n && j < n) c[(long)i + (long)j * n] = t[tx][y];
+    }
+}
+
+__global__ void k_symmetrize_diag(double *__restrict__ c, int n)
+{   // inside the diagonal 32x32 tiles
+    const int b = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) {
+        const int i = b * 32 + tx, j = b * 32 + y;
+        if (i < n && j < n && j > i) c[(long)i + (long)j * n] = c[(long)j + (long)i * n];
+    }
+}
+
+// W = [ (C + reg)^T | (B + prior)^T ]   (fit_chunk_hybrid :1261-1309); C is symmetric at this point
+__global__ void k_build_system(const double *__restrict__ c, const double *__restrict__ b, double *__restrict__ w, int n_aug, int n_model,
+                               int n_out, double reg_model, double reg_res, double prior_diag)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_aug * (n_aug + n_out);
+    if (t >= total) return;
+    const int i = (int)(t % n_aug);
+    const int j = (int)(t / n_aug);
+    double v;
+    if (j < n_aug) {
+        v = c[(long)i + (long)j * n_aug];                 // a_trans = transpose(C); C is symmetric here, read it contiguously
+        if (i == j) v = v + (i < n_model ? reg_model : reg_res);
+    } else {
+        const int o = j - n_aug;                          // b_trans(i, o) = B(o, i) + prior(o, i)
+        v = b[(long)o + (long)i * n_out];
+        if (o == i && o < n_model) v = v + prior_diag;
+    }
+    w[t] = v;
+}
+
+__global__ void k_extract_wout(const double *__restrict__ w, double *__restrict__ wout, int n_aug, int n_out)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)n_aug * n_out) return;
+    const int o = (int)(t % n_out), i = (int)(t / n_out);
+    wout[t] = w[(long)i + (long)(n_aug + o) * n_aug];     // wout(o,i) = Z(i,o)
+}
+
+// ---- LU panel: columns [k0, k0+nb) of W, rows [k0, n); one workgroup ----
+constexpr int PT = 1024;
+__global__ __launch_bounds__(PT) void k_panel(double *__restrict__ w, int n, int k0, int nb, int *__restrict__ ipiv, int *__restrict__ info)
+{
+    __shared__ double sval[PT / 64];
+    __shared__ int sidx[PT / 64];
+    __shared__ int spiv;
+    __shared__ double srow[LU_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = 0; c < nb; ++c) {
+        const int col = k0 + c;
+        double *wc = w + (long)col * n;
+        // pivot search: first maximum of |a| (dgetf2 / idamax)
+        double best = -1.0; int bi = n;
+        for (int r = col + tid; r < n; r += PT) {
+            const double a = fabs(wc[r]);
+            if (a > best) { best = a; bi = r; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double b2 = sval[0]; int i2 = sidx[0];
+            for (int q = 1; q < PT / 64; ++q)
+                if (sval[q] > b2 || (sval[q] == b2 && sidx[q] < i2)) { b2 = sval[q]; i2 = sidx[q]; }
+            spiv = i2;
+            ipiv[col] = i2;
+            if (b2 == 0.0 && *info == 0) *info = col + 1;
+        }
+        __syncthreads();
+        const int p = spiv;
+        // interchange rows col <-> p inside the panel and stage the pivot row
+        if (tid < nb) {
+            double *q = w + (long)(k0 + tid) * n;
+            const double a = q[col], b = q[p];
+            if (p != col) { q[col] = b; q[p] = a; }
+            srow[tid] = b;
+        }
+        __syncthreads();
+        const double piv = srow[c];
+        if (piv != 0.0) {
+            const double inv = 1.0 / piv;
+            for (int r = col + 1 + tid; r < n; r += PT) {
+                const double l = wc[r] * inv;
+                wc[r] = l;
+                for (int cc = c + 1; cc < nb; ++cc) {
+                    double *q = w + (long)(k0 + cc) * n;
+                    q[r] = q[r] - l * srow[cc];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// apply the panel's interchanges to every column outside the panel (columns [0,k0) and [k0+nb, ncols))
+__global__ void k_swap(double *__restrict__ w, int n, int ncols, int k0, int nb, const int *__restrict__ ipiv)
+{
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols - nb) return;
+    if (col >= k0) col += nb;
+    double *q = w + (long)col * n;
+    for (int c = 0; c < nb; ++c) {
+        const int r = k0 + c, p = ipiv[r];
+        if (p != r) { const double a = q[r]; q[r] = q[p]; q[p] = a; }
+    }
+}
+
+// U12 = L11^-1 A12: one thread per column of A12 (columns [k0+nb, ncols)); unit-lower L11 and the thread's column
+// segment live in LDS (xs[r][thread] is conflict free), so nothing is indexed dynamically in registers.
+constexpr int TRSM_T = 64;
+__global__ __launch_bounds__(TRSM_T) void k_trsm_lower(double *__restrict__ w, int n, int ncols, int k0, int nb)
+{
+    __shared__ double L[LU_NB][LU_NB + 1];
+    __shared__ double xs[LU_NB][TRSM_T];
+    for (int e = threadIdx.x; e < nb * nb; e += TRSM_T) {
+        const int r = e % nb, c = e / nb;
+        L[r][c] = w[(long)(k0 + r) + (long)(k0 + c) * n];
+    }
+    __syncthreads();
+    const int col = k0 + nb + blockIdx.x * TRSM_T + threadIdx.x;
+    if (col >= ncols) return;
+    double *q = w + (long)col * n + k0;
+    for (int r = 0; r < nb; ++r) xs[r][threadIdx.x] = q[r];
+    for (int r = 1; r < nb; ++r) {
+        double s = xs[r][threadIdx.x];
+        for (int c = 0; c < r; ++c) s = s - L[r][c] * xs[c][threadIdx.x];
+        xs[r][threadIdx.x] = s;
+    }
+    for (int r = 0; r < nb; ++r) q[r] = xs[r][threadIdx.x];
+}
+
+// back substitution block: X_kb = U_kk^-1 Y_kb for every right-hand side (columns [n, ncols))
+__global__ __launch_bounds__(TRSM_T) void k_trsm_upper(double *__restrict__ w, int n, int ncols, int k0, int nb)
+{
+    __shared__ double U[LU_NB][LU_NB + 1];
+    __shared__ double xs[LU_NB][TRSM_T];
+    for (int e = threadIdx.x; e < nb * nb; e += TRSM_T) {
+        const int r = e % nb, c = e / nb;
+        U[r][c] = w[(long)(k0 + r) + (long)(k0 + c) * n];
+    }
+    __syncthreads();
+    const int col = n + blockIdx.x * TRSM_T + threadIdx.x;
+    if (col >= ncols) return;
+    double *q = w + (long)col * n + k0;
+    for (int r = 0; r < nb; ++r) xs[r][threadIdx.x] = q[r];
+    for (int r = nb - 1; r >= 0; --r) {
+        double s = xs[r][threadIdx.x];
+        for (int c = r + 1; c < nb; ++c) s = s - U[r][c] * xs[c][threadIdx.x];
+        xs[r][threadIdx.x] = s / U[r][r];
+    }
+    for (int r = 0; r < nb; ++r) q[r] = xs[r][threadIdx.x];
+}
+
+template <bool A_KC, bool B_KC>
+int gemm(const double *A, long sai, long sak, const double *B, long sbj, long sbk, double *C, long ldc, int M, int N, int K,
+         double alpha, int lower_only, hipStream_t st)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return SML_OK;
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+    hipLaunchKernelGGL((k_gemm_acc<A_KC, B_KC>), grid, dim3(GT), 0, st, A, sai, sak, B, sbj, sbk, C, ldc, M, N, K, alpha, lower_only);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sml_train_accumulate(const double *states, const double *model, const double *y, int n, int n_model, int n_out, int m,
+                         double *c, double *b, void *stream)
+{
+    SML_REQUIRE(states && y && c && b && n > 0 && n_model >= 0 && n_out > 0 && m > 0 && (n_model == 0 || model),
+                "sml_train_accumulate: bad arguments");
+    hipStream_t st = sml::as_stream(stream);
+    const int n_aug = n + n_model;
+    int rc;
+    // aug = [model ; states] is never materialised: the four (model|states) x (model|states) blocks of C and the two
+    // blocks of B are separate launches on the original arrays.  Only tiles on/below the diagonal of C are updated.
+    double *c_ss = c + (long)n_model + (long)n_model * n_aug;
+    if ((rc = gemm<false, false>(states, 1, n, states, 1, n, c_ss, n_aug, n, n, m, 1.0, 1, st))) return rc;
+    if (n_model) {
+        if ((rc = gemm<false, false>(model, 1, n_model, model, 1, n_model, c, n_aug, n_model, n_model, m, 1.0, 0, st))) return rc;
+        // lower-left block: rows = states, cols = model
+        if ((rc = gemm<false, false>(states, 1, n, model, 1, n_model, c + n_model, n_aug, n, n_model, m, 1.0, 0, st))) return rc;
+        if ((rc = gemm<false, false>(y, 1, n_out, model, 1, n_model, b, n_out, n_out, n_model, m, 1.0, 0, st))) return rc;
+    }
+    return gemm<false, false>(y, 1, n_out, states, 1, n, b + (long)n_model * n_out, n_out, n_out, n, m, 1.0, 0, st);
+}
+
+int sml_train_symmetrize(double *c, int n_aug, void *stream)
+{
+    SML_REQUIRE(c && n_aug > 0, "sml_train_symmetrize: bad arguments");
+    const int nb = (n_aug + 31) / 32;
+    hipLaunchKernelGGL(k_symmetrize, dim3(nb, nb), dim3(256), 0, sml::as_stream(stream), c, n_aug);
+    SML_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_symmetrize_diag, dim3(nb), dim3(256), 0, sml::as_stream(stream), c, n_aug);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_train_fit(double *c, const double *b, int n, int n_model, int n_out, double beta_res, double beta_model,
+                  double prior_val, int using_prior, double *wout, void *stream)
+{
+    SML_REQUIRE(c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit: bad arguments");
+    hipStream_t st = sml::as_stream(stream);
+    const int n_aug = n + n_model, ncols = n_aug + n_out;
+    constexpr int NB = LU_NB;
+    int rc;
+    if ((rc = sml_train_symmetrize(c, n_aug, stream))) return rc;
+    double *w = nullptr;
+    int *ipiv = nullptr, *info = nullptr;
+    SML_HIP(hipMalloc((void **)&w, (size_t)n_aug * ncols * sizeof(double)));
+    SML_HIP(hipMalloc((void **)&ipiv, (size_t)n_aug * sizeof(int)));
+    SML_HIP(hipMalloc((void **)&info, sizeof(int)));
+    SML_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    // with a prior the betas enter squared (quirk Q8, src/mod_reservoir.f90:1271-1290)
+    const double reg_model = using_prior ? beta_model * beta_model : beta_model;
+    const double reg_res = using_prior ? beta_res * beta_res : beta_res;
+    const double prior_diag = using_prior ? prior_val * (beta_model * beta_model) : 0.0;
+    const long total = (long)n_aug * ncols;
+    hipLaunchKernelGGL(k_build_system, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c, b, w, n_aug, n_model, n_out,
+                       reg_model, reg_res, prior_diag);
+    rc = SML_OK;
+    for (int k0 = 0; k0 < n_aug && rc == SML_OK; k0 += NB) {
+        const int nb = std::min(NB, n_aug - k0);
+        hipLaunchKernelGGL(k_panel, dim3(1), dim3(PT), 0, st, w, n_aug, k0, nb, ipiv, info);
+        hipLaunchKernelGGL(k_swap, dim3((ncols - nb + 255) / 256), dim3(256), 0, st, w, n_aug, ncols, k0, nb, ipiv);
+        const int rest_cols = ncols - (k0 + nb), rest_rows = n_aug - (k0 + nb);
+        if (rest_cols > 0) {
+            hipLaunchKernelGGL(k_trsm_lower, dim3((rest_cols + TRSM_T - 1) / TRSM_T), dim3(TRSM_T), 0, st, w, n_aug, ncols, k0, nb);
+            if (rest_rows > 0)
+                rc = gemm<false, true>(w + (k0 + nb) + (long)k0 * n_aug, 1, n_aug,                  // L21(i,k)
+                                       w + k0 + (long)(k0 + nb) * n_aug, n_aug, 1,                 // U12(k,j) as B(j,k)
+                                       w + (k0 + nb) + (long)(k0 + nb) * n_aug, n_aug, rest_rows, rest_cols, nb, -1.0, 0, st);
+        }
+    }
+    // back substitution on the right-hand sides
+    for (int k0 = ((n_aug - 1) / NB) * NB; k0 >= 0 && rc == SML_OK; k0 -= NB) {
+        const int nb = std::min(NB, n_aug - k0);
+        hipLaunchKernelGGL(k_trsm_upper, dim3((n_out + TRSM_T - 1) / TRSM_T), dim3(TRSM_T), 0, st, w, n_aug, ncols, k0, nb);
+        if (k0 > 0)
+            rc = gemm<false, true>(w + (long)k0 * n_aug, 1, n_aug,                                  // U(i, k0+k), i < k0
+                                   w + k0 + (long)n_aug * n_aug, n_aug, 1,                          // X(k0+k, j) as B(j,k)
+                                   w + (long)n_aug * n_aug, n_aug, k0, n_out, nb, -1.0, 0, st);
+    }
+    if (rc == SML_OK) {
+        const long tw = (long)n_aug * n_out;
+        hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, st, w, wout, n_aug, n_out);
+        if (hipGetLastError() != hipSuccess) rc = sml::fail(SML_ERR_HIP, "k_extract_wout launch failed");
+    }
+    int hinfo = 0;
+    hipError_t e = hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(w); (void)hipFree(ipiv); (void)hipFree(info);
+    if (e != hipSuccess) return sml::fail(SML_ERR_HIP, "sml_train_fit: %s", hipGetErrorString(e));
+    if (rc) return rc;
+    if (hinfo) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", hinfo, hinfo, hinfo);
+    return SML_OK;
+}
+
+}  // extern "C"

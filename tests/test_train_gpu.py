@@ -1,0 +1,126 @@
+"""GPU: fp64-MFMA Gram accumulation and the LU ridge solve (through the C-ABI) against the CPU oracle.
+
+Tolerances: Gram matrices 1e-12 relative to their max-abs (pin R^T R / R^T Y to 1e-12); W_out entrywise
+1e-8 when well conditioned, otherwise by the backward error of the regularised system (cond * eps bounds the entries)."""
+import numpy as np
+import pytest
+import torch
+
+from speedy_ml_amd import train
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(a):       # numpy (r, c) -> column-major device buffer, torch shape [c, r]
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a).T)).cuda()
+
+
+def to_host(t):
+    return t.cpu().numpy().T
+
+
+@pytest.mark.parametrize("n,n_model,n_out,m", [(600, 12, 16, 98), (333, 7, 5, 7), (128, 0, 8, 16), (1000, 132, 136, 40), (61, 3, 2, 130)])
+def test_accumulate_matches_oracle(oracle, n, n_model, n_out, m):
+    rng = np.random.default_rng(n + m)
+    n_aug = n + n_model
+    c = train.fortran_zeros(n_aug, n_aug)
+    b = train.fortran_zeros(n_out, n_aug)
+    co = np.zeros((n_aug, n_aug), order="F")
+    bo = np.zeros((n_out, n_aug), order="F")
+    for _ in range(2):                                # accumulates across batches (C and B persist, Appendix D.4)
+        states = rng.standard_normal((n, m))
+        model = rng.standard_normal((n_model, m))
+        y = rng.standard_normal((n_out, m))
+        train.chunking_matmul(to_dev(states), to_dev(model) if n_model else None, to_dev(y), c, b)
+        oracle.chunking_matmul(states, model if n_model else np.zeros((0, m)), y, co, bo)
+    cg, bg = to_host(c), to_host(b)
+    low = np.tril_indices(n_aug)
+    assert np.max(np.abs(cg[low] - co[low])) <= 1e-12 * np.max(np.abs(co))
+    assert np.max(np.abs(bg - bo)) <= 1e-12 * np.max(np.abs(bo))
+    # tiles strictly above the diagonal tiles are left untouched until the mirror pass
+    train.symmetrize(c)
+    cs = to_host(c)
+    assert np.array_equal(cs, cs.T) and np.array_equal(cs[low], cg[low])
+
+
+def test_fit_well_conditioned(oracle):
+    rng = np.random.default_rng(21)
+    n, n_model, n_out, m = 300, 12, 16, 200
+    n_aug = n + n_model
+    c = train.fortran_zeros(n_aug, n_aug)
+    b = train.fortran_zeros(n_out, n_aug)
+    co = np.zeros((n_aug, n_aug), order="F")
+    bo = np.zeros((n_out, n_aug), order="F")
+    for _ in range(3):
+        states, model, y = rng.standard_normal((n, m)), rng.standard_normal((n_model, m)), rng.standard_normal((n_out, m))
+        train.chunking_matmul(to_dev(states), to_dev(model), to_dev(y), c, b)
+        oracle.chunking_matmul(states, model, y, co, bo)
+    for using_prior, prior_val in ((True, 0.0), (True, 0.3), (False, 0.0)):
+        wg = to_host(train.fit_chunk_hybrid(c, b, n, n_model, n_out, 1e-3, 1.0, prior_val, using_prior))
+        info, wo = oracle.fit_chunk_hybrid(n, n_model, n_out, 1e-3, 1.0, prior_val, using_prior, co, bo)
+        assert info == 0
+        assert np.max(np.abs(wg - wo)) <= 1e-8 * np.max(np.abs(wo)), (using_prior, prior_val)
+
+
+def test_fit_ill_conditioned_by_residual_and_pivoting(oracle):
+    rng = np.random.default_rng(22)
+    n, n_model, n_out, m = 500, 12, 16, 98            # rank 98 Gram matrix + 1e-6 ridge: cond ~ 1e9
+    n_aug = n + n_model
+    states, model, y = rng.standard_normal((n, m)), rng.standard_normal((n_model, m)), rng.standard_normal((n_out, m))
+    c = train.fortran_zeros(n_aug, n_aug)
+    b = train.fortran_zeros(n_out, n_aug)
+    train.chunking_matmul(to_dev(states), to_dev(model), to_dev(y), c, b)
+    wg = to_host(train.fit_chunk_hybrid(c, b, n, n_model, n_out, 1e-3, 1.0, 0.0, True))
+    cs, bs = to_host(c), to_host(b)
+    reg = np.diag(np.r_[np.full(n_model, 1.0), np.full(n, 1e-6)])
+    resid = (cs + reg).T @ wg.T - bs.T
+    assert np.linalg.norm(resid) / np.linalg.norm(bs) < 1e-9
+    # predictions agree with the oracle's solution although the entries only agree to cond*eps
+    co = np.zeros((n_aug, n_aug), order="F")
+    bo = np.zeros((n_out, n_aug), order="F")
+    oracle.chunking_matmul(states, model, y, co, bo)
+    _, wo = oracle.fit_chunk_hybrid(n, n_model, n_out, 1e-3, 1.0, 0.0, True, co, bo)
+    aug = np.vstack([model, states])
+    assert np.max(np.abs(wg @ aug - wo @ aug)) <= 1e-6 * np.max(np.abs(wo @ aug))
+
+
+def test_fit_general_matrix_needs_pivoting():
+    """dgesv semantics: a non-symmetric-looking system whose leading entry is tiny must still solve accurately.
+    (C is symmetrised by the fit, so build a symmetric indefinite matrix with a zero leading diagonal.)"""
+    rng = np.random.default_rng(23)
+    n, n_out = 97, 3
+    a = rng.standard_normal((n, n))
+    a = a + a.T
+    a[0, 0] = 0.0
+    bmat = rng.standard_normal((n_out, n))
+    wg = to_host(train.fit_chunk_hybrid(to_dev(a), to_dev(bmat), n, 0, n_out, 0.0, 0.0, 0.0, False))
+    want = np.linalg.solve(a.T, bmat.T).T
+    assert np.max(np.abs(wg - want)) <= 1e-9 * np.max(np.abs(want))
+
+
+def test_singular_matrix_fails_loudly():
+    from speedy_ml_amd._lib import SmlError
+    n, n_out = 64, 2
+    c = train.fortran_zeros(n, n)
+    b = train.fortran_zeros(n_out, n)
+    with pytest.raises(SmlError):
+        train.fit_chunk_hybrid(c, b, n, 0, n_out, 0.0, 0.0, 0.0, False)
+
+
+def test_full_size_gram_against_torch_fp64():
+    """BASELINE config 4 shape: n=5760, n_model=132, n_out=136, m=98 (shipped batch size)."""
+    torch.manual_seed(5)
+    n, n_model, n_out, m = 5760, 132, 136, 98
+    n_aug = n + n_model
+    states = torch.randn((m, n), dtype=torch.float64, device="cuda")
+    model = torch.randn((m, n_model), dtype=torch.float64, device="cuda")
+    y = torch.randn((m, n_out), dtype=torch.float64, device="cuda")
+    c = train.fortran_zeros(n_aug, n_aug)
+    b = train.fortran_zeros(n_out, n_aug)
+    train.chunking_matmul(states, model, y, c, b)
+    train.symmetrize(c)
+    aug = torch.cat([model, states], dim=1)           # [m, n_aug]
+    cref = aug.T @ aug                                # symmetric, so layout does not matter
+    bref = aug.T @ y                                  # torch [n_aug, n_out] == column-major (n_out, n_aug)
+    assert float((c - cref).abs().max()) <= 1e-12 * float(cref.abs().max())
+    assert float((b - bref).abs().max()) <= 1e-12 * float(bref.abs().max())
