@@ -82,6 +82,25 @@ def device_view(ptr, shape):
     return torch.as_tensor(h, device="cuda").view(*shape)
 
 
+def gather_outvec_slab(local_outvec, regions, all_out, even_split):
+    """Region-ordered slab of every rank's outvecs on every rank (works on any torch device / backend).
+
+    processor_decomposition gives each rank a contiguous block of regions; when the region count divides evenly the
+    rank blocks are equal and one all_gather_into_tensor of the resident outvec buffer IS the region-ordered slab
+    (no packing, no copy).  With a remainder (ranks 1..left_over own one extra region taken from the tail,
+    src/res_domain.f90:53-60) the blocks are ragged: every rank writes its rows into a zeroed slab and the slabs
+    are summed -- each row has exactly one owner, so the sum is exact."""
+    import torch.distributed as dist
+    if even_split:
+        dist.all_gather_into_tensor(all_out, local_outvec)
+    else:
+        import torch
+        all_out.zero_()
+        all_out[torch.as_tensor(regions, dtype=torch.long, device=all_out.device)] = local_outvec[:len(regions)]
+        dist.all_reduce(all_out)
+    return all_out
+
+
 class HybridRank:
     """All state of one rank for the device-resident step loop."""
 
@@ -144,14 +163,7 @@ class HybridRank:
         src/mpires.f90:347-454 becomes one RCCL all-gather of the contiguous outvec slab)."""
         if self.world == 1:
             return self.outvec
-        import torch.distributed as dist
-        if self.even_split:
-            dist.all_gather_into_tensor(self.all_out, self.outvec)
-        else:   # remainder rule of processor_decomposition: ragged blocks -> pack into region order, then sum
-            self.all_out.zero_()
-            self.ex.pack_outvec(self.all_out, stream)
-            dist.all_reduce(self.all_out)
-        return self.all_out
+        return gather_outvec_slab(self.outvec, self.regions, self.all_out, self.even_split)
 
     def handoff(self, stream):
         """iogrid(30) then iogrid(31) (src/ppo_iogrid.f90:497-601) on the device, 33 fields per launch."""

@@ -1,0 +1,57 @@
+"""CPU, gloo, world_size > 1: the N>1 data path of the hybrid step -- region sharding by processor_decomposition and the
+one collective of the step (region-ordered outvec slab on every rank), even and ragged (remainder rule) splits."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+NREG, STRIDE = 1152, 136
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+    load_package()
+    from speedy_ml_amd import domain, hybrid
+    regions = [int(r) for r in domain.processor_decomposition_manual(rank, world, NREG)]
+    cap = max(len(domain.processor_decomposition_manual(p, world, NREG)) for p in range(world))
+    # each region's outvec is a deterministic function of the region id, so every rank can check the whole slab
+    local = torch.zeros((len(regions), STRIDE), dtype=torch.float64)
+    for i, r in enumerate(regions):
+        local[i] = torch.arange(STRIDE, dtype=torch.float64) + 1000.0 * r
+    all_out = torch.full((NREG, STRIDE), -1.0, dtype=torch.float64)
+    even = NREG % world == 0
+    for _ in range(2):      # twice: the slab is reused every step
+        hybrid.gather_outvec_slab(local, regions, all_out, even)
+    want = torch.arange(STRIDE, dtype=torch.float64)[None, :] + 1000.0 * torch.arange(NREG, dtype=torch.float64)[:, None]
+    ok = bool(torch.equal(all_out, want))
+    np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([ok, len(regions), cap]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_outvec_slab_gloo(world, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    total = 0
+    for r in range(world):
+        ok, n, cap = np.load(tmp_path / f"ok_{r}.npy")
+        assert ok == 1, f"rank {r} assembled a wrong slab"
+        total += int(n)
+    assert total == NREG
