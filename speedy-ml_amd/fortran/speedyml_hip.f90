@@ -1,0 +1,117 @@
+! iso_c_binding interfaces to libspeedyml_hip.so (include/speedyml_hip.h) -- the host language the reference is
+! written in.  Only plain pointers, sizes and opaque handles cross the boundary.
+module speedyml_hip
+  use iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: SML_OK = 0
+
+  interface
+    function sml_last_error() bind(C, name="sml_last_error") result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function
+    function sml_device_count() bind(C, name="sml_device_count") result(n)
+      import :: c_int
+      integer(c_int) :: n
+    end function
+    function sml_set_device(ordinal) bind(C, name="sml_set_device") result(rc)
+      import :: c_int
+      integer(c_int), value :: ordinal
+      integer(c_int) :: rc
+    end function
+
+    ! ---- resdomain ----
+    function sml_domain_decompose(rank, nranks, number_of_regions, region_indices, capacity) bind(C, name="sml_domain_decompose") result(n)
+      import :: c_int
+      integer(c_int), value :: rank, nranks, number_of_regions, capacity
+      integer(c_int), intent(out) :: region_indices(*)
+      integer(c_int) :: n
+    end function
+    function sml_domain_out_map(number_of_regions, region_num, num_vert_levels, vert_level, vert_overlap, precip_bool, &
+                                g_index, stat_idx, capacity) bind(C, name="sml_domain_out_map") result(n)
+      import :: c_int
+      integer(c_int), value :: number_of_regions, region_num, num_vert_levels, vert_level, vert_overlap, precip_bool, capacity
+      integer(c_int), intent(out) :: g_index(*), stat_idx(*)
+      integer(c_int) :: n
+    end function
+
+    ! ---- reservoir bank ----
+    function sml_bank_create(capacity, max_d, max_n_model, max_n_out, bank) bind(C, name="sml_bank_create") result(rc)
+      import :: c_int, c_ptr
+      integer(c_int), value :: capacity, max_d, max_n_model, max_n_out
+      type(c_ptr), intent(out) :: bank
+      integer(c_int) :: rc
+    end function
+    function sml_bank_destroy(bank) bind(C, name="sml_bank_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: bank
+      integer(c_int) :: rc
+    end function
+    function sml_bank_load(bank, slot, n, d, k, n_model, n_out, rows, cols, vals, win, wout, leakage, mean, std, nstat, &
+                           out_stat_idx) bind(C, name="sml_bank_load") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot, n, d, k, n_model, n_out, nstat
+      integer(c_int), intent(in) :: rows(*), cols(*), out_stat_idx(*)
+      real(c_double), intent(in) :: vals(*), win(*), wout(*), mean(*), std(*)
+      real(c_double), value :: leakage
+      integer(c_int) :: rc
+    end function
+    function sml_bank_set_feedback(bank, slot, u) bind(C, name="sml_bank_set_feedback") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(in) :: u(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_set_state(bank, slot, x) bind(C, name="sml_bank_set_state") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(in) :: x(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_get_state(bank, slot, x) bind(C, name="sml_bank_get_state") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(out) :: x(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_predict_one(bank, slot, x, local_model, outvec) bind(C, name="sml_bank_predict_one") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(inout) :: x(*)
+      real(c_double), intent(in) :: local_model(*)
+      real(c_double), intent(out) :: outvec(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_advance_all(bank, stream) bind(C, name="sml_bank_advance_all") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: bank, stream
+      integer(c_int) :: rc
+    end function
+  end interface
+
+contains
+
+  ! The reference prints library status and stops (src/mod_linalg.f90:18-22,147-150); same here.
+  subroutine sml_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    integer :: i
+    if (rc >= 0) return
+    call c_f_pointer(sml_last_error(), msg, [512])
+    write(*,'(a,a,a,i0,a)', advance='no') 'speedyml_hip: ', where, ' failed (status ', rc, '): '
+    do i = 1, 512
+      if (msg(i) == c_null_char) exit
+      write(*,'(a)', advance='no') msg(i)
+    end do
+    write(*,*)
+    stop 1
+  end subroutine
+
+end module speedyml_hip

@@ -1,0 +1,149 @@
+! Fortran host test: a synthetic region-954-shaped reservoir is stepped (a) by the drop-in module on the MI355X and
+! (b) by the reference's own statements written out in plain Fortran (COO loop, matmul, tanh, matmul, un-standardise);
+! the spectral externals grid_/spec_ are exercised with the reference's F77 calling convention (array-element
+! actual arguments, sequence association).  Exit status 0 = parity within tolerance.
+program test_driver
+  use iso_c_binding
+  use speedyml_hip
+  use mod_reservoir_hip
+  implicit none
+
+  type(reservoir_type) :: res
+  integer, parameter :: n = 1152, d = 576, n_model = 132, n_out = 136
+  integer :: k, i, j, e, q, nfail, length
+  real(kind=dp), allocatable :: x(:), x_ref(:), y(:), temp(:), x_aug(:), out_ref(:), input(:,:)
+  integer(c_int), allocatable :: gidx(:)
+  integer(c_int) :: nmap
+  real(kind=dp) :: seed, errx, erro
+  real(kind=dp) :: vorm(62,32,2), vorg(96,48), back(62,32), a
+  integer :: kcos
+  external :: parmtr, inifft, grid, spec
+
+  if (sml_device_count() < 1) then
+    print *, 'test_driver: no HIP device visible'
+    stop 2
+  end if
+  nfail = 0
+  seed = 0.314159_dp
+  k = int((6.0_dp/6000.0_dp)*n*n)
+  res%assigned_region = 954
+  res%n = n; res%k = k; res%reservoir_numinputs = d
+  res%chunk_size_speedy = n_model; res%chunk_size_prediction = n_out
+  res%leakage = 1.0_dp
+  allocate(res%rows(k), res%cols(k), res%vals(k), res%win(n,d), res%wout(n_out,n+n_model))
+  allocate(res%feedback(d), res%local_model(n_model), res%outvec(n_out), res%mean(36), res%std(36), res%out_stat_idx(n_out))
+  do e = 1, k
+    res%rows(e) = 1 + int(rnd()*n); res%cols(e) = 1 + int(rnd()*n); res%vals(e) = rnd()*0.25_dp
+  end do
+  res%win = 0.0_dp
+  q = n/d
+  do i = 1, d
+    do j = (i-1)*q+1, i*q
+      res%win(j,i) = 0.5_dp*(2.0_dp*rnd()-1.0_dp)        ! src/mod_reservoir.f90:272-280
+    end do
+  end do
+  do j = 1, n+n_model
+    do i = 1, n_out
+      res%wout(i,j) = 0.02_dp*(rnd()-0.5_dp)
+    end do
+  end do
+  do i = 1, 36
+    res%mean(i) = 2.0_dp*rnd()-1.0_dp; res%std(i) = 0.5_dp+1.5_dp*rnd()
+  end do
+  do i = 1, d
+    res%feedback(i) = 2.0_dp*rnd()-1.0_dp
+  end do
+  do i = 1, n_model
+    res%local_model(i) = 2.0_dp*rnd()-1.0_dp
+  end do
+  allocate(gidx(n_out))
+  nmap = sml_domain_out_map(1152_c_int, 954_c_int, 1_c_int, 1_c_int, 0_c_int, 1_c_int, gidx, res%out_stat_idx, int(n_out, c_int))
+  if (nmap /= n_out) then
+    print *, 'sml_domain_out_map returned', nmap
+    stop 3
+  end if
+
+  call mklsparse(res)
+
+  ! ---- synchronize: 5 teacher-forced steps ----
+  length = 5
+  allocate(x(n), x_ref(n), y(n), temp(n), x_aug(n+n_model), out_ref(n_out), input(d,length))
+  do j = 1, length
+    do i = 1, d
+      input(i,j) = 2.0_dp*rnd()-1.0_dp
+    end do
+  end do
+  x = 0.0_dp; x_ref = 0.0_dp
+  call synchronize(res, input, x, length)
+  do j = 1, length
+    call coo_mv(x_ref, y)
+    temp = matmul(res%win, input(:,j))
+    x_ref = (1.0_dp-res%leakage)*x_ref + res%leakage*tanh(y+temp)
+  end do
+  errx = maxval(abs(x - x_ref))
+  print '(a,es10.3)', 'synchronize max|dx| = ', errx
+  if (errx > 1.0e-12_dp) nfail = nfail + 1
+
+  ! ---- predict: reference statements (src/mod_reservoir.f90:1444-1471) vs the drop-in ----
+  x = x_ref
+  call predict(res, x, res%local_model)
+  call coo_mv(x_ref, y)
+  temp = matmul(res%win, res%feedback)
+  x_ref = (1.0_dp-res%leakage)*x_ref + res%leakage*tanh(y+temp)
+  x_aug(1:n_model) = res%local_model
+  x_aug(n_model+1:) = x_ref
+  x_aug(n_model+2:n_model+n:2) = x_aug(n_model+2:n_model+n:2)**2
+  out_ref = matmul(res%wout, x_aug)
+  do i = 1, n_out
+    out_ref(i) = out_ref(i)*res%std(res%out_stat_idx(i)+1)
+    out_ref(i) = out_ref(i) + res%mean(res%out_stat_idx(i)+1)
+  end do
+  errx = maxval(abs(x - x_ref))
+  erro = maxval(abs(res%outvec - out_ref))/maxval(abs(out_ref))
+  print '(a,es10.3,a,es10.3)', 'predict max|dx| = ', errx, '   rel outvec err = ', erro
+  if (errx > 1.0e-13_dp .or. erro > 1.0e-11_dp) nfail = nfail + 1
+
+  ! ---- spectral externals with the reference's calling convention ----
+  a = 6.371e6_dp
+  call parmtr(a)
+  call inifft()
+  vorm = 0.0_dp
+  do j = 1, 31
+    do i = 1, 62
+      if ((i-1)/2 + j - 1 <= 30 .and. i /= 2) vorm(i,j,1) = 2.0_dp*rnd()-1.0_dp
+    end do
+  end do
+  kcos = 1
+  call grid(vorm(1,1,1), vorg, kcos)            ! array-element actual argument, as src/dyn_grtend.f90:62
+  call spec(vorg, back)
+  errx = maxval(abs(back - vorm(:,:,1)))/maxval(abs(vorm(:,:,1)))
+  print '(a,es10.3)', 'spec(grid(v)) rel err = ', errx
+  if (errx > 1.0e-12_dp) nfail = nfail + 1
+
+  if (nfail == 0) then
+    print *, 'FORTRAN HOST PARITY OK'
+  else
+    print *, 'FORTRAN HOST PARITY FAILED', nfail
+    stop 1
+  end if
+
+contains
+
+  function rnd() result(r)          ! small deterministic generator (the compiler RNG is not reproducible, SURVEY H5)
+    real(kind=dp) :: r
+    seed = seed*997.0_dp + 0.1234567_dp
+    seed = seed - int(seed)
+    r = seed
+  end function
+
+  subroutine coo_mv(xin, yout)      ! MKL_SPARSE_D_MV semantics: y = A x, COO in storage order
+    real(kind=dp), intent(in) :: xin(:)
+    real(kind=dp), intent(out) :: yout(:)
+    integer :: ee
+    yout = 0.0_dp
+    do ee = 1, res%k
+      yout(res%rows(ee)) = yout(res%rows(ee)) + res%vals(ee)*xin(res%cols(ee))
+    end do
+  end subroutine
+
+end program test_driver
