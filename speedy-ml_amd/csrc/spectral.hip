@@ -146,22 +146,35 @@ void build_tables(HostTables &t, double a)
 // ------------------------------------------------ kernels ------------------------------------------------
 constexpr int TT = 256;
 
-// inverse transform of one field per workgroup:  vorm[32][62] -> vorg[48][96]
+// A single 96x48 transform is far too small to fill the chip, and even a whole transform set (<= 91 fields) gives
+// only 91 workgroups for 256 CUs.  Each field is therefore split over several workgroups along the dimension that
+// needs no cross-workgroup reduction: latitude pairs for the inverse transform (Legendre synthesis and Fourier
+// synthesis are both independent per latitude), zonal wavenumbers for the forward transform (the DFT is independent
+// per wavenumber and the Legendre analysis only sums over latitude within one wavenumber).  Every workgroup re-reads
+// its field from L2 (16-37 KB); nothing is exchanged between workgroups.
+constexpr int LATG = 4;                 // latitude pairs per workgroup (inverse)
+constexpr int NLG = IY / LATG;          // 6 workgroups per field
+constexpr int MG = 4;                   // zonal wavenumbers per workgroup (forward)
+constexpr int NMG = (MX + MG - 1) / MG; // 8 workgroups per field
+
+// inverse transform: vorm[32][62] -> vorg[48][96]; workgroup = (field, group of LATG latitude pairs)
 __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos)
 {
-    __shared__ double sv[SPEC_N];          // spectral coefficients
-    __shared__ double sf[FOUR_N];          // Fourier coefficients varm[48][62]
+    __shared__ double sv[SPEC_N];              // spectral coefficients
+    __shared__ double sf[2 * LATG][MX2];       // Fourier coefficients of the 2*LATG latitude rows of this workgroup
     __shared__ double stc[IX], sts[IX];
     __shared__ int snsh[NX];
-    const double *v = vorm + (size_t)blockIdx.x * SPEC_N;
-    double *g = vorg + (size_t)blockIdx.x * GRID_N;
+    const int f = blockIdx.x / NLG, lg = blockIdx.x % NLG;
+    const double *v = vorm + (size_t)f * SPEC_N;
+    double *g = vorg + (size_t)f * GRID_N;
     for (int i = threadIdx.x; i < SPEC_N; i += TT) sv[i] = v[i];
     for (int i = threadIdx.x; i < IX; i += TT) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
     if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
     __syncthreads();
-    // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O
-    for (int w = threadIdx.x; w < MX2 * IY; w += TT) {
-        const int c = w % MX2, j = w / MX2, m = c >> 1;
+    // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O.
+    // Summation order is the reference's, so without FMA contraction this is bit-identical to gridy.
+    if (threadIdx.x < LATG * MX2) {
+        const int c = threadIdx.x % MX2, jj = threadIdx.x / MX2, j = lg * LATG + jj, m = c >> 1;
         const double *p = T.pol + (size_t)j * NX * MX + m;
         double e = 0.0, o = 0.0;
 #pragma unroll 4
@@ -169,80 +182,91 @@ __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restri
             if (c < snsh[n]) e = e + sv[n * MX2 + c] * p[n * MX];
             if (c < snsh[n + 1]) o = o + sv[(n + 1) * MX2 + c] * p[(n + 1) * MX];
         }
-        sf[(IL - 1 - j) * MX2 + c] = e + o;
-        sf[j * MX2 + c] = e - o;
+        sf[2 * jj + 1][c] = e + o;       // northern row il+1-j
+        sf[2 * jj][c] = e - o;           // southern row j
     }
     __syncthreads();
     // Fourier synthesis (gridx): x_i = a0 + sum_k 2 (Re_k cos(2 pi k i/96) - Im_k sin(2 pi k i/96)), k = 1..30
-    for (int w = threadIdx.x; w < GRID_N; w += TT) {
-        const int i = w % IX, j = w / IX;
-        const double *f = sf + j * MX2;
-        double acc = f[0];
+    for (int w = threadIdx.x; w < 2 * LATG * IX; w += TT) {
+        const int i = w % IX, r = w / IX;
+        const int j = lg * LATG + (r >> 1);
+        const int row = (r & 1) ? IL - 1 - j : j;
+        const double *fc = sf[r];
+        double acc = fc[0];
         int ph = 0;
-#pragma unroll 5
+#pragma unroll 6
         for (int k = 1; k <= MX - 1; ++k) {
             ph += i;
             if (ph >= IX) ph -= IX;
-            acc += 2.0 * (f[2 * k] * stc[ph] - f[2 * k + 1] * sts[ph]);
+            acc += 2.0 * (fc[2 * k] * stc[ph] - fc[2 * k + 1] * sts[ph]);
         }
-        if (kcos != 1) acc = acc * T.cosgr[j];
-        g[w] = acc;
+        if (kcos != 1) acc = acc * T.cosgr[row];
+        g[row * IX + i] = acc;
     }
 }
 
-// forward transform of one field per workgroup: vorg[48][96] -> vorm[32][62]; scale: 0 none, 1 *cosgr(j), 2 *cosgr2(j)
+// forward transform: vorg[48][96] -> vorm[32][62]; workgroup = (field, group of MG zonal wavenumbers)
+// scale: 0 none, 1 *cosgr(j), 2 *cosgr2(j)  (the vdspec prologue, :429-443)
 __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restrict__ vorg, double *__restrict__ vorm, int scale)
 {
-    __shared__ double sg[GRID_N];
-    __shared__ double sf[FOUR_N];
-    __shared__ double stc[IX], sts[IX];
-    __shared__ int snsh[NX];
-    const double *g = vorg + (size_t)blockIdx.x * GRID_N;
-    double *v = vorm + (size_t)blockIdx.x * SPEC_N;
-    for (int i = threadIdx.x; i < GRID_N; i += TT) {
-        double x = g[i];
-        if (scale == 1) x = x * T.cosgr[i / IX];
-        else if (scale == 2) x = x * T.cosgr2[i / IX];
-        sg[i] = x;
+    __shared__ double sg[IL][IX + 1];          // padded rows: lanes that differ in latitude hit different banks
+    __shared__ double twc[MG][IX + 2], tws[MG][IX + 2];
+    __shared__ double sf[IL][2 * MG];          // this workgroup's Fourier coefficients [lat][re/im of its wavenumbers]
+    const int f = blockIdx.x / NMG, mg = blockIdx.x % NMG;
+    const int k0 = mg * MG, nk = min(MG, MX - k0);
+    const double *g = vorg + (size_t)f * GRID_N;
+    double *v = vorm + (size_t)f * SPEC_N;
+    for (int w = threadIdx.x; w < GRID_N; w += TT) {
+        const int i = w % IX, j = w / IX;
+        double x = g[w];
+        if (scale == 1) x = x * T.cosgr[j];
+        else if (scale == 2) x = x * T.cosgr2[j];
+        sg[j][i] = x;
     }
-    for (int i = threadIdx.x; i < IX; i += TT) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
-    if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
+    for (int w = threadIdx.x; w < MG * IX; w += TT) {
+        const int i = w % IX, kk = w / IX;
+        const int ph = ((k0 + kk) * i) % IX;
+        twc[kk][i] = T.twc[ph];
+        tws[kk][i] = T.tws[ph];
+    }
     __syncthreads();
-    // forward DFT (specx): a0 = sum x / 96 ; Re_k = sum x cos / 96 ; Im_k = - sum x sin / 96 ; element 1 (Im of k=0) = 0
-    const double sc = 1. / (double)IX;
-    for (int w = threadIdx.x; w < MX * IL; w += TT) {
-        const int k = w % MX, j = w / MX;
-        const double *x = sg + j * IX;
+    // forward DFT (specx): a0 = sum x / 96 ; Re_k = sum x cos / 96 ; Im_k = - sum x sin / 96 ; Im of k=0 is set to 0
+    if (threadIdx.x < nk * IL) {
+        const int j = threadIdx.x % IL, kk = threadIdx.x / IL;
+        const double *x = sg[j], *cc = twc[kk], *ss = tws[kk];
         double re = 0.0, im = 0.0;
-        int ph = 0;
+#pragma unroll 8
         for (int i = 0; i < IX; ++i) {
-            re += x[i] * stc[ph];
-            im -= x[i] * sts[ph];
-            ph += k;
-            if (ph >= IX) ph -= IX;
+            re += x[i] * cc[i];
+            im -= x[i] * ss[i];
         }
-        sf[j * MX2 + 2 * k] = re * sc;
-        sf[j * MX2 + 2 * k + 1] = k == 0 ? 0.0 : im * sc;
+        const double sc = 1. / (double)IX;
+        sf[j][2 * kk] = re * sc;
+        sf[j][2 * kk + 1] = (k0 + kk == 0) ? 0.0 : im * sc;
     }
     __syncthreads();
     // symmetric / antisymmetric parts times the Gaussian weight, in place (specy :511-517)
-    for (int w = threadIdx.x; w < MX2 * IY; w += TT) {
-        const int c = w % MX2, j = w / MX2, j1 = IL - 1 - j;
-        const double n_ = sf[j1 * MX2 + c], s_ = sf[j * MX2 + c], wj = T.wt[j];
-        sf[j * MX2 + c] = (n_ + s_) * wj;       // svarm
-        sf[j1 * MX2 + c] = (n_ - s_) * wj;      // dvarm
+    if (threadIdx.x < IY * 2 * MG) {
+        const int cc = threadIdx.x % (2 * MG), j = threadIdx.x / (2 * MG), j1 = IL - 1 - j;
+        const double n_ = sf[j1][cc], s_ = sf[j][cc], wj = T.wt[j];
+        sf[j][cc] = (n_ + s_) * wj;       // svarm
+        sf[j1][cc] = (n_ - s_) * wj;      // dvarm
     }
     __syncthreads();
-    // Legendre analysis (specy :519-537): odd n (1-based) use svarm, even n use dvarm, n <= ntrun1, c < nsh2(n)
-    for (int w = threadIdx.x; w < SPEC_N; w += TT) {
-        const int c = w % MX2, n = w / MX2, m = c >> 1;
-        double acc = 0.0;
-        if (n < NTRUN1 && c < snsh[n]) {
-            const double *p = T.pol + (size_t)n * MX + m;
-            if ((n & 1) == 0) { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[j * MX2 + c]; }
-            else              { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[(IL - 1 - j) * MX2 + c]; }
+    // Legendre analysis (specy :519-537): odd n (1-based) use svarm, even n use dvarm, n <= ntrun1, c < nsh2(n);
+    // accumulation over latitude in the reference's order -> bit-identical to specy for identical Fourier input
+    {
+        const int cc = threadIdx.x % (2 * MG), n = threadIdx.x / (2 * MG);     // 8 x 32 = 256 threads
+        const int c = 2 * k0 + cc, m = c >> 1;
+        if (cc < 2 * nk) {
+            double acc = 0.0;
+            if (n < NTRUN1 && c < T.nsh2[n]) {
+                const double *p = T.pol + (size_t)n * MX + m;
+                if ((n & 1) == 0) { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[j][cc]; }
+                else              { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[IL - 1 - j][cc]; }
+            }
+            v[n * MX2 + c] = acc;
         }
-        v[w] = acc;
     }
 }
 
@@ -430,14 +454,14 @@ int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf
 {
     SML_REQUIRE(sp && nf >= 0 && (kcos == 1 || kcos == 2) && (nf == 0 || (vorm && vorg)), "sml_spectral_grid: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
 
 static int spec_scaled(sml_spectral *sp, const double *vorg, double *vorm, int nf, int scale, void *stream)
 {
-    hipLaunchKernelGGL(k_spec, dim3(nf), dim3(TT), 0, sml::as_stream(stream), sp->d, vorg, vorm, scale);
+    hipLaunchKernelGGL(k_spec, dim3(nf * NMG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorg, vorm, scale);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
