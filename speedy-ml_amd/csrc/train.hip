@@ -3,8 +3,8 @@
 // Replaces chunking_matmul (src/mod_reservoir.f90:1645-1701: temp = matmul(targetdata, transpose(aug)); DGEMM('N','N',
 // n,n,m, aug, transpose(aug))), fit_chunk_hybrid (:1235-1334) and mldivide = dgesv (src/mod_linalg.f90:109-151).
 //
-//   k_gemm_acc : C(i,j) += alpha * sum_k A(i,k) B(j,k) with v_mfma_f64_16x16x4_f64.  128x128 tile per 256-thread
-//                workgroup, 64x64 per wavefront (4x4 MFMA tiles, 128 accumulator VGPRs), K-tile 16 staged through
+//   k_gemm_acc : C(i,j) += alpha * sum_k A(i,k) B(j,k) with v_mfma_f64_4x4x4_4b_f64 (see the kernel).  128x128 tile per 256-thread
+//                workgroup, 64x64 per wavefront (4x16 MFMA tiles of 16x4, 128 accumulator VGPRs), K-tile 16 staged through
 //                LDS with a 144-double row stride (rows land 128 B apart modulo the 256-B bank period, so the
 //                16-lane x 4-row operand reads are conflict free).  The MFMA is issued as D[j][i] = B.A so that the
 //                accumulator's lane index runs along i, the contiguous direction of the column-major C: every
@@ -15,6 +15,7 @@
 //                workgroup reduction) -> row interchanges outside the panel -> U12 = L11^-1 A12 -> trailing update
 //                with k_gemm_acc (alpha = -1) ; then a blocked back substitution.
 // All matrices are column-major fp64, as in the reference.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -26,9 +27,62 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BN = 128, KT = 16, LDS_LD = 144, GT = 256;
 constexpr int LU_NB = 32;      // LU panel width
 
-// Staging of one 128 x 16 operand tile: element (r, k) = p[r * sr + k * sk], zero outside rows < nrows, k < K.
-// Split in two halves (T14-style): stage_load issues the 8 global loads into registers early, stage_write puts them
-// into LDS after the barrier, so the loads of K-tile t+1 fly under the MFMAs of K-tile t.
+// ---- shared pieces of the two GEMM kernels ----
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction, 16 cycles, measured 75 TFLOP/s on this part
+// versus 36-48 TFLOP/s for v_mfma_f64_16x16x4_f64 (profiles/micro/mfma_f64_peak.hip).  Measured lane layout
+// (profiles/micro/mfma_f64_4x4x4_layout.hip): A operand lane = 16 k + 4 blk + i, B operand lane = 16 k + 4 blk + j,
+// D lane = 16 i + 4 blk + j.  C's column index J goes on the MFMA's i and C's row index I on (blk, j), so one instruction
+// produces a 16 (I) x 4 (J) tile of C whose 16 consecutive lanes are 16 consecutive rows of one column: contiguous
+// 128-byte stores into the column-major C.  A wavefront owns 64 x 64 of C = 4 x 16 such tiles (128 accumulator VGPRs).
+struct WavePos { int wi, wj, l15, l4, l3; };
+
+__device__ __forceinline__ WavePos wave_pos()
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return {(wave & 1) * 64, (wave >> 1) * 64, lane & 15, lane >> 4, lane & 3};
+}
+
+__device__ __forceinline__ void mma_ktile(const double (*As)[LDS_LD], const double (*Bs)[LDS_LD], const WavePos &w, double (&acc)[4][16])
+{
+#pragma unroll
+    for (int kk = 0; kk < KT; kk += 4) {
+        double af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = As[kk + w.l4][w.wi + 16 * t + w.l15];       // A(I0 + 4 blk + j, k): MFMA "B" operand
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                                    // two halves keep 16 fewer VGPRs live
+            double bf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bf[u] = Bs[kk + w.l4][w.wj + 4 * (8 * h + u) + w.l3];   // B(J0 + i, k): MFMA "A" operand
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t][8 * h + u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bf[u], af[t], acc[t][8 * h + u], 0, 0, 0);
+        }
+    }
+}
+
+// lane l holds C(I0 + 16 t + (l & 15), J0 + 4 u + (l >> 4))
+__device__ __forceinline__ void store_tile(double *__restrict__ C, long ldc, int M, int N, int i0, int j0, const WavePos &w, double alpha,
+                                           const double (&acc)[4][16])
+{
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = j0 + w.wj + 4 * u + w.l4;
+        if (j >= N) continue;
+        double *cj = C + (long)j * ldc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = i0 + w.wi + 16 * t + w.l15;
+            if (i < M) cj[i] = cj[i] + alpha * acc[t][u];
+        }
+    }
+}
+
+// Staging of one 128 x 16 operand tile through registers: element (r, k) = p[r * sr + k * sk], zero outside rows < nrows,
+// k < K.  Split in two halves (T14-style): stage_load issues the 8 global loads early, stage_write puts them into LDS
+// after the barrier, so the loads of K-tile t+1 fly under the MFMAs of K-tile t.
 template <bool K_CONTIG>
 __device__ __forceinline__ void stage_load(const double *__restrict__ p, long sr, long sk, int r0, int nrows, int k0, int K, double (&v)[8])
 {
@@ -61,7 +115,8 @@ __device__ __forceinline__ void stage_write(const double (&v)[8], double (*dst)[
     }
 }
 
-// C[i + j*ldc] += alpha * sum_k A(i,k) * B(j,k);  lower_only: skip tiles strictly above the diagonal
+// General kernel (any strides, any K, edge tiles): C[i + j*ldc] += alpha * sum_k A(i,k) * B(j,k).
+// lower_only: skip tiles strictly above the diagonal.
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(GT, 2) void k_gemm_acc(const double *__restrict__ A, long sai, long sak, const double *__restrict__ B,
                                                      long sbj, long sbk, double *__restrict__ C, long ldc, int M, int N, int K,
@@ -72,15 +127,12 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_acc(const double *__restrict__ A
     const int ti = blockIdx.x, tj = blockIdx.y;
     if (lower_only && tj > ti) return;
     const int i0 = ti * BM, j0 = tj * BN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    v4d acc[4][4];
+    const WavePos w = wave_pos();
+    double acc[4][16];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
+        for (int b = 0; b < 16; ++b) acc[a][b] = 0.0;
     double ra[8], rb[8];
     stage_load<A_KC>(A, sai, sak, i0, M, 0, K, ra);
     stage_load<B_KC>(B, sbj, sbk, j0, N, 0, K, rb);
@@ -93,35 +145,52 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_acc(const double *__restrict__ A
             stage_load<A_KC>(A, sai, sak, i0, M, k0 + KT, K, ra);
             stage_load<B_KC>(B, sbj, sbk, j0, N, k0 + KT, K, rb);
         }
-#pragma unroll
-        for (int kk = 0; kk < KT; kk += 4) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = As[kk + l4][wi + 16 * t + l15];   // A(i,k) -> MFMA "B" operand (k x col=i)
-                bf[t] = Bs[kk + l4][wj + 16 * t + l15];   // B(j,k) -> MFMA "A" operand (row=j x k)
-            }
-#pragma unroll
-            for (int tjj = 0; tjj < 4; ++tjj)
-#pragma unroll
-                for (int tii = 0; tii < 4; ++tii)
-                    acc[tjj][tii] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[tjj], af[tii], acc[tjj][tii], 0, 0, 0);
-        }
+        mma_ktile(As, Bs, w, acc);
     }
-    // D[row = j_local = l4 + 4 r][col = i_local = l15]: 16 lanes store 128 contiguous bytes of one column of C
+    store_tile(C, ldc, M, N, i0, j0, w, alpha, acc);
+}
+
+// Fast path for the Gram updates: both operands row-contiguous (A(i,k) = A[i + k*lda], B(j,k) = B[j + k*ldb]), 16-byte
+// aligned columns, K a multiple of 16.  Operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): one
+// wavefront instruction moves 64 lanes x 16 B = one 128-row k-column of the tile straight into its (padded) LDS row --
+// no staging registers, no ds_write -- double-buffered so the DMA of K-tile t+1 runs under the MFMAs of K-tile t with
+// one barrier per K-tile.  Rows past M/N are clamped to valid memory (their products only feed rows that are never stored).
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
+                                                        double *__restrict__ C, long ldc, int M, int N, int K, double alpha, int lower_only)
+{
+    __shared__ __attribute__((aligned(16))) double S[2][2][KT][LDS_LD];       // [buffer][operand][k][row]
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (lower_only && tj > ti) return;
+    const int i0 = ti * BM, j0 = tj * BN;
+    const WavePos w = wave_pos();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ra = min(i0 + 2 * lane, (M - 2) & ~1), rb = min(j0 + 2 * lane, (N - 2) & ~1);
+    const double *pa = A + ra, *pb = B + rb;
+    double acc[4][16];
 #pragma unroll
-    for (int tjj = 0; tjj < 4; ++tjj)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + wj + 16 * tjj + l4 + 4 * r;
-            if (j >= N) continue;
-            double *cj = C + (long)j * ldc;
+        for (int b = 0; b < 16; ++b) acc[a][b] = 0.0;
+
+    auto issue = [&](int buf, int k0) {
 #pragma unroll
-            for (int tii = 0; tii < 4; ++tii) {
-                const int i = i0 + wi + 16 * tii + l15;
-                if (i < M) cj[i] = cj[i] + alpha * acc[tjj][tii][r];
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int k = wave * 4 + q;
+            __builtin_amdgcn_global_load_lds((gptr_t)(pa + (long)(k0 + k) * lda), (lptr_t)&S[buf][0][k][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(pb + (long)(k0 + k) * ldb), (lptr_t)&S[buf][1][k][0], 16, 0, 0);
         }
+    };
+    issue(0, 0);
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += KT, cur ^= 1) {
+        __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) here; all waves also finished reading buffer cur^1
+        if (k0 + KT < K) issue(cur ^ 1, k0 + KT);
+        mma_ktile(S[cur][0], S[cur][1], w, acc);
+    }
+    store_tile(C, ldc, M, N, i0, j0, w, alpha, acc);
 }
 
 __global__ void k_symmetrize(double *__restrict__ c, int n)
@@ -309,6 +378,27 @@ int gemm(const double *A, long sai, long sak, const double *B, long sbj, long sb
     return SML_OK;
 }
 
+// C += alpha * A * B^T for row-contiguous operands: LDS-DMA kernel on the part of K that is a multiple of 16 (when the
+// alignment conditions hold), general kernel on the tail.
+int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int M, int N, int K, double alpha, int lower_only,
+            hipStream_t st)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return SML_OK;
+    auto ok = [](const double *p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0; };
+    int kmain = 0;
+    // short K (the shipped batch size m = 98) is bound by the read-modify-write of C: one pass with the general kernel
+    // beats main + tail passes.  Long K (m = 2920, the 40-year configuration) takes the LDS-DMA kernel.
+    if (ok(A, lda) && ok(B, ldb) && M >= 2 && N >= 2 && K >= 512) {
+        kmain = (K / KT) * KT;
+        dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+        hipLaunchKernelGGL(k_gemm_nt_dma, grid, dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, lower_only);
+        SML_HIP(hipGetLastError());
+    }
+    if (kmain < K)
+        return gemm<false, false>(A + (long)kmain * lda, 1, lda, B + (long)kmain * ldb, 1, ldb, C, ldc, M, N, K - kmain, alpha, lower_only, st);
+    return SML_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -324,14 +414,14 @@ int sml_train_accumulate(const double *states, const double *model, const double
     // aug = [model ; states] is never materialised: the four (model|states) x (model|states) blocks of C and the two
     // blocks of B are separate launches on the original arrays.  Only tiles on/below the diagonal of C are updated.
     double *c_ss = c + (long)n_model + (long)n_model * n_aug;
-    if ((rc = gemm<false, false>(states, 1, n, states, 1, n, c_ss, n_aug, n, n, m, 1.0, 1, st))) return rc;
+    if ((rc = gemm_nt(states, n, states, n, c_ss, n_aug, n, n, m, 1.0, 1, st))) return rc;
     if (n_model) {
-        if ((rc = gemm<false, false>(model, 1, n_model, model, 1, n_model, c, n_aug, n_model, n_model, m, 1.0, 0, st))) return rc;
+        if ((rc = gemm_nt(model, n_model, model, n_model, c, n_aug, n_model, n_model, m, 1.0, 0, st))) return rc;
         // lower-left block: rows = states, cols = model
-        if ((rc = gemm<false, false>(states, 1, n, model, 1, n_model, c + n_model, n_aug, n, n_model, m, 1.0, 0, st))) return rc;
-        if ((rc = gemm<false, false>(y, 1, n_out, model, 1, n_model, b, n_out, n_out, n_model, m, 1.0, 0, st))) return rc;
+        if ((rc = gemm_nt(states, n, model, n_model, c + n_model, n_aug, n, n_model, m, 1.0, 0, st))) return rc;
+        if ((rc = gemm_nt(y, n_out, model, n_model, b, n_out, n_out, n_model, m, 1.0, 0, st))) return rc;
     }
-    return gemm<false, false>(y, 1, n_out, states, 1, n, b + (long)n_model * n_out, n_out, n_out, n, m, 1.0, 0, st);
+    return gemm_nt(y, n_out, states, n, b + (long)n_model * n_out, n_out, n_out, n, m, 1.0, 0, st);
 }
 
 int sml_train_symmetrize(double *c, int n_aug, void *stream)
