@@ -12,7 +12,7 @@ struct ResDesc {
     const int *slice_off;      // [nslices+1] first entry of each 64-row slice (entries are width*64 per slice)
     const int *sell_col;       // column into [x ; u]
     const double *sell_val;
-    const int *perm;           // sorted position -> original row (or -1 for the padding rows of the last slice)
+    const int *perm;           // device position -> original row (kept for diagnostics; the kernels do not need it)
     const int *row_len;        // nonzeros of the row at each sorted position
     double *x[2];              // ping-pong state
     const double *wout;        // [n_out][n_aug_pad] row-major, zero padded
@@ -25,6 +25,7 @@ struct HostRes {
     std::vector<void *> allocs;
     ResDesc desc{};
     uint64_t update_bytes = 0, readout_bytes = 0;
+    std::vector<int> order;      // device position -> original row of the state vector
 };
 
 }  // namespace sml

@@ -20,6 +20,7 @@
 // so block id b serves reservoir 8*(b/(8*parts)) + b%8; the `parts` workgroups that share one reservoir's x / x~
 // vector therefore share an XCD's L2.
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -32,7 +33,6 @@ namespace {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int UPD_THREADS = 512;
 constexpr int RO_THREADS = 256;
 constexpr int RO_ROWS = 17;
 
@@ -45,8 +45,9 @@ __device__ __forceinline__ void decode_block(int id, int parts, int res_begin, i
 }
 
 // x_new = (1-leak) x + leak tanh([A|Win] [x;u])        (src/mod_reservoir.f90:1444-1448)
-__global__ __launch_bounds__(UPD_THREADS) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
-                                                         int parts, const double *__restrict__ u_all, int u_stride, int cur)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
+                                                     int parts, const double *__restrict__ u_all, int u_stride, int cur)
 {
     extern __shared__ __attribute__((aligned(16))) double xu[];
     int res, part;
@@ -57,25 +58,40 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(const ResDesc *__restric
     const double *__restrict__ x = D.x[cur];
     double *__restrict__ xn = D.x[cur ^ 1];
     const double *__restrict__ u = u_all + (size_t)res * u_stride;
-    for (int i = threadIdx.x; i < D.n; i += UPD_THREADS) xu[i] = x[i];
-    for (int i = threadIdx.x; i < D.d; i += UPD_THREADS) xu[D.n + i] = u[i];
+    // stage [x ; u] with 16-byte loads (x is 256-byte aligned)
+    const int n2 = D.n >> 1;
+    for (int i = threadIdx.x; i < n2; i += THREADS) reinterpret_cast<f64x2 *>(xu)[i] = reinterpret_cast<const f64x2 *>(x)[i];
+    if ((D.n & 1) && threadIdx.x == 0) xu[D.n - 1] = x[D.n - 1];
+    for (int i = threadIdx.x; i < D.d; i += THREADS) xu[D.n + i] = u[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = UPD_THREADS / 64;
+    constexpr int NW = THREADS / 64;
     for (int s = part * NW + wave; s < D.nslices; s += parts * NW) {
         const int off = D.slice_off[s];
         const int width = (D.slice_off[s + 1] - off) >> 6;
         const int len = D.row_len[s * 64 + lane];
+        const int r = s * 64 + lane;                      // device position == sorted position: contiguous stores
         const int *__restrict__ cp = D.sell_col + off + lane;
         const double *__restrict__ vp = D.sell_val + off + lane;
         double acc = 0.0;
-        for (int j = 0; j < width; ++j) {
+        int j = 0;
+        // four entries per trip: the eight global loads are issued before the first LDS gather; accumulation stays in
+        // storage order (A entries in COO order, then W_in).  (Deeper software pipelining across slices and an LDS-free
+        // variant gathering x from L2 were measured slower: 0.23-0.45 ms vs 0.21 ms per 1152-reservoir launch.)
+        for (; j + 4 <= width; j += 4) {
+            const int c0 = cp[j * 64], c1 = cp[(j + 1) * 64], c2 = cp[(j + 2) * 64], c3 = cp[(j + 3) * 64];
+            const double v0 = vp[j * 64], v1 = vp[(j + 1) * 64], v2 = vp[(j + 2) * 64], v3 = vp[(j + 3) * 64];
+            if (j < len) acc += v0 * xu[c0];
+            if (j + 1 < len) acc += v1 * xu[c1];
+            if (j + 2 < len) acc += v2 * xu[c2];
+            if (j + 3 < len) acc += v3 * xu[c3];
+        }
+        for (; j < width; ++j) {
             const int c = cp[j * 64];
             const double v = vp[j * 64];
             if (j < len) acc += v * xu[c];
         }
-        const int r = D.perm[s * 64 + lane];
-        if (r >= 0) {
+        if (r < D.n) {
             const double xt = tanh(acc);
             xn[r] = (1.0 - D.leak) * xu[r] + D.leak * xt;
         }
@@ -238,9 +254,19 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
     for (int e = 0; e < k; ++e) { int p = fill[rows[e] - 1]++; ccol[p] = cols[e] - 1; cval[p] = vals[e]; }
     for (size_t e = 0; e < wr.size(); ++e) { int p = fill[wr[e]]++; ccol[p] = n + wc[e]; cval[p] = wv[e]; }
 
-    std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+    // Device order of the state vector: rows sorted by length (SELL), but with the even-indexed and odd-indexed rows
+    // sorted separately and interleaved, so that position p holds a row of the same parity as p.  The state lives in HBM
+    // in THIS order: k_update stores x_new contiguously (scattered 8-byte stores cost a 64-byte write each: measured
+    // WRITE_SIZE 0.35 GB per sweep instead of 0.05 GB), the readout's "square the odd entries" rule stays positional, and
+    // W_out's state columns are permuted once at load.  inv[row] = position.
+    std::vector<int> order(n), ev, od;
+    for (int i = 0; i < n; ++i) (i & 1 ? od : ev).push_back(i);
+    auto by_len = [&](int a, int b) { return cnt[a] > cnt[b]; };
+    std::stable_sort(ev.begin(), ev.end(), by_len);
+    std::stable_sort(od.begin(), od.end(), by_len);
+    for (int p = 0; p < n; ++p) order[p] = (p & 1) ? od[p >> 1] : ev[p >> 1];
+    std::vector<int> inv(n);
+    for (int p = 0; p < n; ++p) inv[order[p]] = p;
     const int nslices = (n + 63) / 64;
     std::vector<int> slice_off(nslices + 1, 0), perm(nslices * 64, -1), row_len(nslices * 64, 0);
     for (int s = 0; s < nslices; ++s) {
@@ -259,7 +285,8 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
             if (pos >= n) continue;
             const int r = order[pos];
             for (int j = 0; j < cnt[r]; ++j) {
-                scol[slice_off[s] + j * 64 + l] = ccol[ptr[r] + j];
+                const int c = ccol[ptr[r] + j];
+                scol[slice_off[s] + j * 64 + l] = c < n ? inv[c] : c;           // state columns refer to device positions
                 sval[slice_off[s] + j * 64 + l] = cval[ptr[r] + j];
             }
         }
@@ -267,8 +294,11 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
     // ---- W_out: (n_out, n_aug) column-major -> [n_out][n_aug_pad] row-major ----
     const int n_aug = n + n_model, n_aug_pad = (n_aug + 1) & ~1;
     std::vector<double> wrm((size_t)n_out * n_aug_pad, 0.0);
-    for (int j = 0; j < n_aug; ++j)
-        for (int i = 0; i < n_out; ++i) wrm[(size_t)i * n_aug_pad + j] = wout[(size_t)j * n_out + i];
+    for (int j = 0; j < n_aug; ++j) {
+        const int jd = j < n_model ? j : n_model + inv[j - n_model];             // state columns follow the device order
+        for (int i = 0; i < n_out; ++i) wrm[(size_t)i * n_aug_pad + jd] = wout[(size_t)j * n_out + i];
+    }
+    R.order = order;
 
     std::vector<double> hmean(mean, mean + nstat), hstd(stdv, stdv + nstat), zeros(n, 0.0);
     std::vector<int> hstat(n_out, -1);
@@ -304,21 +334,48 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
     return SML_OK;
 }
 
+// host <-> device state: the host sees the reference's row order, HBM holds the device order (HostRes::order)
+int upload_state(const HostRes &R, double *dst, const double *x_host)
+{
+    std::vector<double> tmp(R.order.size());
+    for (size_t p = 0; p < tmp.size(); ++p) tmp[p] = x_host[R.order[p]];
+    SML_HIP(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+int download_state(const HostRes &R, const double *src, double *x_host)
+{
+    std::vector<double> tmp(R.order.size());
+    SML_HIP(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < tmp.size(); ++p) x_host[R.order[p]] = tmp[p];
+    return SML_OK;
+}
+
 int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st)
 {
-    const int parts = 2;
+    // (threads, parts): 512 x 2 -> three workgroups (3 x 53.8 KB LDS, 24 waves) per CU and 2304 workgroups = exactly three
+    // rounds over 768 slots; 1024 x 1 halves the x re-reads but leaves a quarter-full last round.
+    static const int cfg = getenv("SML_UPD_CFG") ? atoi(getenv("SML_UPD_CFG")) : 0;
+    const int threads = cfg == 1 ? 1024 : (cfg == 2 ? 256 : 512);
+    const int parts = cfg == 1 ? 1 : (cfg == 2 ? 4 : 2);
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
     const size_t lds = (size_t)b->max_nd * sizeof(double);
     SML_REQUIRE(lds <= 160 * 1024, "reservoir too large for the LDS-staged update (n+d=%d)", b->max_nd);
     static bool attr_set = false;
     if (!attr_set) {
-        SML_HIP(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SML_HIP(hipFuncSetAttribute((const void *)k_update<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SML_HIP(hipFuncSetAttribute((const void *)k_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SML_HIP(hipFuncSetAttribute((const void *)k_update<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
-    hipLaunchKernelGGL(k_update, dim3(nres8 * parts), dim3(UPD_THREADS), lds, st, b->d_descs, res_begin, res_end, parts,
-                       u_all, b->max_d, b->cur);
+    if (threads == 1024)
+        hipLaunchKernelGGL(k_update<1024>, dim3(nres8 * parts), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur);
+    else if (threads == 256)
+        hipLaunchKernelGGL(k_update<256>, dim3(nres8 * parts), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur);
+    else
+        hipLaunchKernelGGL(k_update<512>, dim3(nres8 * parts), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur);
     SML_HIP(hipGetLastError());
     if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_update.emplace_back(e0, e1); }
     b->cur ^= 1;
@@ -438,15 +495,13 @@ int sml_bank_set_wout(sml_bank *bank, int slot, const double *wout)
 int sml_bank_set_state(sml_bank *bank, int slot, const double *x)
 {
     BANK_SLOT(bank, slot);
-    SML_HIP(hipMemcpy(D.x[bank->cur], x, sizeof(double) * D.n, hipMemcpyHostToDevice));
-    return SML_OK;
+    return upload_state(bank->res[slot], D.x[bank->cur], x);
 }
 
 int sml_bank_get_state(sml_bank *bank, int slot, double *x)
 {
     BANK_SLOT(bank, slot);
-    SML_HIP(hipMemcpy(x, D.x[bank->cur], sizeof(double) * D.n, hipMemcpyDeviceToHost));
-    return SML_OK;
+    return download_state(bank->res[slot], D.x[bank->cur], x);
 }
 
 int sml_bank_set_feedback(sml_bank *bank, int slot, const double *u)
@@ -499,12 +554,12 @@ int sml_bank_predict_one(sml_bank *bank, int slot, double *x_inout, const double
     if (rc) return rc;
     // every slot shares the ping-pong parity: stage x into the *current* buffer of this slot, step only this slot,
     // then copy the new state into BOTH buffers so that the slot is consistent whatever the bank parity is.
-    SML_HIP(hipMemcpy(D.x[bank->cur], x_inout, sizeof(double) * D.n, hipMemcpyHostToDevice));
+    if ((rc = upload_state(bank->res[slot], D.x[bank->cur], x_inout))) return rc;
     if (D.n_model && lm) SML_HIP(hipMemcpy(bank->d_local_model + (size_t)slot * bank->max_n_model, lm, sizeof(double) * D.n_model, hipMemcpyHostToDevice));
     const int before = bank->cur;
     if ((rc = launch_update(bank, slot, slot + 1, bank->d_feedback, nullptr))) return rc;
     if ((rc = launch_readout(bank, slot, slot + 1, 0, nullptr))) return rc;
-    SML_HIP(hipMemcpy(x_inout, D.x[bank->cur], sizeof(double) * D.n, hipMemcpyDeviceToHost));
+    if ((rc = download_state(bank->res[slot], D.x[bank->cur], x_inout))) return rc;
     SML_HIP(hipMemcpy(D.x[before], D.x[bank->cur], sizeof(double) * D.n, hipMemcpyDeviceToDevice));
     bank->cur = before;
     SML_HIP(hipMemcpy(outvec, bank->d_outvec + (size_t)slot * bank->max_n_out, sizeof(double) * D.n_out, hipMemcpyDeviceToHost));
