@@ -34,7 +34,7 @@ struct sml_bank {
     int capacity = 0, max_d = 0, max_n_model = 0, max_n_out = 0;
     int cur = 0;
     int max_nd = 0;                 // LDS doubles needed by k_update
-    int max_parts_ro = 1;
+    int max_n_out_loaded = 1;       // largest n_out among loaded slots (sizes the readout grid)
     std::vector<sml::HostRes> res;
     sml::ResDesc *d_descs = nullptr;
     double *d_feedback = nullptr, *d_local_model = nullptr, *d_outvec = nullptr;

@@ -8,7 +8,7 @@
 //   k_update  : one sparse product with the fused operator [A | W_in] on [x ; u] in SELL-64 layout (rows sorted
 //               by length, 64-row slices stored column-major so a wavefront's loads are contiguous), x and u staged
 //               in LDS, tanh + leak fused, ping-pong state buffers.  HBM-bound: 12 B per nonzero.
-//   k_readout : W_out is re-laid out row-major; a 256-thread workgroup streams R=17 rows (17 x 47 KB) with
+//   k_readout : W_out is re-laid out row-major; a one-wavefront workgroup streams R=17 rows (17 x 47 KB) with
 //               16-byte loads, every lane keeping 17 partial sums so that 17 independent loads are in flight per
 //               lane; the augmented state is formed on the fly (local_model | x, odd 0-based entries squared);
 //               wavefront shuffle + LDS reduction; un-standardisation (multiply, then add -- two roundings, as
@@ -33,7 +33,6 @@ namespace {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int RO_THREADS = 256;
 constexpr int RO_ROWS = 17;
 
 __device__ __forceinline__ void decode_block(int id, int parts, int res_begin, int &res, int &part)
@@ -106,7 +105,7 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // outvec = unstandardize(Wout [local_model ; x~])      (src/mod_reservoir.f90:1450-1471)
-template <int R>
+template <int R, int RO_THREADS, bool NT>
 __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restrict__ descs, int res_begin, int res_end, int parts,
                                                           const double *__restrict__ lm_all, int lm_stride,
                                                           double *__restrict__ out_all, int out_stride, int cur, int flags)
@@ -149,7 +148,8 @@ __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restric
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             // streamed once per step, 7.4 GB per sweep >> Infinity Cache: non-temporal 16-byte loads
-            const f64x2 w = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(wrow[r] + kk));
+            const f64x2 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(wrow[r] + kk))
+                               : *reinterpret_cast<const f64x2 *>(wrow[r] + kk);
             acc[r] += w[0] * a0;
             acc[r] += w[1] * a1;
         }
@@ -329,7 +329,7 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
     // W_out n_out*n_aug*8 ; local_model + outvec + mean/std
     R.readout_bytes = (uint64_t)n_out * n_aug * 8 + (uint64_t)(n_model + n_out + 2 * nstat) * 8;
     bank->max_nd = std::max(bank->max_nd, n + d);
-    bank->max_parts_ro = std::max(bank->max_parts_ro, (n_out + RO_ROWS - 1) / RO_ROWS);
+    bank->max_n_out_loaded = std::max(bank->max_n_out_loaded, n_out);
     bank->descs_dirty = true;
     return SML_OK;
 }
@@ -384,12 +384,35 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
 
 int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream_t st)
 {
-    const int parts = b->max_parts_ro;
+    // measured on MI355X (1152 reservoirs, event-timed): <17,64> 1.40 ms, <17,128> 1.46, <17,256> 1.58, <8,128> 1.57,
+    // <17,512> 1.89, <34,256> 1.84, <34,128> 2.03 ms; non-temporal vs plain loads within 1 %.  One wavefront per workgroup wins.
+    static const int variant = getenv("SML_RO_VARIANT") ? atoi(getenv("SML_RO_VARIANT")) : 7;
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
-    hipLaunchKernelGGL(k_readout<RO_ROWS>, dim3(nres8 * parts), dim3(RO_THREADS), 0, st, b->d_descs, res_begin, res_end, parts,
-                       b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags);
+#define RO_LAUNCH(R, T, NT)                                                                                             \
+    {                                                                                                                   \
+        const int parts = (b->max_n_out_loaded + (R) - 1) / (R);                                                        \
+        hipLaunchKernelGGL((k_readout<R, T, NT>), dim3(nres8 * parts), dim3(T), 0, st, b->d_descs, res_begin, res_end, parts, \
+                           b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags);                 \
+    }
+    switch (variant) {
+    case 1: RO_LAUNCH(17, 512, true) break;
+    case 2: RO_LAUNCH(34, 256, true) break;
+    case 3: RO_LAUNCH(8, 256, true) break;
+    case 4: RO_LAUNCH(17, 128, true) break;
+    case 5: RO_LAUNCH(17, 256, false) break;
+    case 6: RO_LAUNCH(34, 512, true) break;
+    case 7: RO_LAUNCH(17, 64, true) break;
+    case 8: RO_LAUNCH(8, 128, true) break;
+    case 9: RO_LAUNCH(34, 128, true) break;
+    case 10: RO_LAUNCH(17, 128, false) break;
+    case 11: RO_LAUNCH(8, 64, true) break;
+    case 12: RO_LAUNCH(34, 64, true) break;
+    case 0: RO_LAUNCH(RO_ROWS, 256, true) break;
+    default: RO_LAUNCH(RO_ROWS, 64, true) break;
+    }
+#undef RO_LAUNCH
     SML_HIP(hipGetLastError());
     if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_readout.emplace_back(e0, e1); }
     return SML_OK;
