@@ -207,6 +207,11 @@ int sml_spectral_get_table(sml_spectral *sp, int which, double *out_host, int ca
  *   kcos: per call (1 or 2), as in grid(vorm,vorg,kcos) (src/spe_spectral.f90:389-401). */
 int sml_spectral_grid(sml_spectral *sp, const double *vorm_dev, double *vorg_dev, int nf, int kcos, void *stream);
 int sml_spectral_spec(sml_spectral *sp, const double *vorg_dev, double *vorm_dev, int nf, void *stream);      /* :403-414 */
+/* One launch for a whole transform SET of a SPEEDY time step, where fields differ in kcos (grid(.,.,1) next to
+ * grid(.,.,2), src/dyn_grtend.f90:61-99) or in the forward pre-scaling (plain spec next to the two specx of a vdspec,
+ * :237-277): per-field int32 flags on the device.  kcos: 1|2.  scale: 0 none, 1 *cosgr(j) (vdspec kcos=2), 2 *cosgr2(j). */
+int sml_spectral_grid_mixed(sml_spectral *sp, const double *vorm_dev, double *vorg_dev, int nf, const int32_t *kcos_dev, void *stream);
+int sml_spectral_spec_mixed(sml_spectral *sp, const double *vorg_dev, double *vorm_dev, int nf, const int32_t *scale_dev, void *stream);
 int sml_spectral_vdspec(sml_spectral *sp, const double *ug_dev, const double *vg_dev, double *vorm_dev,
                         double *divm_dev, int nf, int kcos, void *stream);                                    /* :416-452 */
 int sml_spectral_uvspec(sml_spectral *sp, const double *vorm_dev, const double *divm_dev, double *ucosm_dev,

@@ -158,13 +158,15 @@ constexpr int MG = 4;                   // zonal wavenumbers per workgroup (forw
 constexpr int NMG = (MX + MG - 1) / MG; // 8 workgroups per field
 
 // inverse transform: vorm[32][62] -> vorg[48][96]; workgroup = (field, group of LATG latitude pairs)
-__global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos)
+__global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos_all,
+                                              const int *__restrict__ kcos_of_field)
 {
     __shared__ double sv[SPEC_N];              // spectral coefficients
     __shared__ double sf[2 * LATG][MX2];       // Fourier coefficients of the 2*LATG latitude rows of this workgroup
     __shared__ double stc[IX], sts[IX];
     __shared__ int snsh[NX];
     const int f = blockIdx.x / NLG, lg = blockIdx.x % NLG;
+    const int kcos = kcos_of_field ? kcos_of_field[f] : kcos_all;
     const double *v = vorm + (size_t)f * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
     for (int i = threadIdx.x; i < SPEC_N; i += TT) sv[i] = v[i];
@@ -207,12 +209,14 @@ __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restri
 
 // forward transform: vorg[48][96] -> vorm[32][62]; workgroup = (field, group of MG zonal wavenumbers)
 // scale: 0 none, 1 *cosgr(j), 2 *cosgr2(j)  (the vdspec prologue, :429-443)
-__global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restrict__ vorg, double *__restrict__ vorm, int scale)
+__global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restrict__ vorg, double *__restrict__ vorm, int scale_all,
+                                              const int *__restrict__ scale_of_field)
 {
     __shared__ double sg[IL][IX + 1];          // padded rows: lanes that differ in latitude hit different banks
     __shared__ double twc[MG][IX + 2], tws[MG][IX + 2];
     __shared__ double sf[IL][2 * MG];          // this workgroup's Fourier coefficients [lat][re/im of its wavenumbers]
     const int f = blockIdx.x / NMG, mg = blockIdx.x % NMG;
+    const int scale = scale_of_field ? scale_of_field[f] : scale_all;
     const int k0 = mg * MG, nk = min(MG, MX - k0);
     const double *g = vorg + (size_t)f * GRID_N;
     double *v = vorm + (size_t)f * SPEC_N;
@@ -454,14 +458,32 @@ int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf
 {
     SML_REQUIRE(sp && nf >= 0 && (kcos == 1 || kcos == 2) && (nf == 0 || (vorm && vorg)), "sml_spectral_grid: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
 
 static int spec_scaled(sml_spectral *sp, const double *vorg, double *vorm, int nf, int scale, void *stream)
 {
-    hipLaunchKernelGGL(k_spec, dim3(nf * NMG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorg, vorm, scale);
+    hipLaunchKernelGGL(k_spec, dim3(nf * NMG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorg, vorm, scale, (const int *)nullptr);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_grid_mixed(sml_spectral *sp, const double *vorm, double *vorg, int nf, const int32_t *kcos_dev, void *stream)
+{
+    SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg && kcos_dev)), "sml_spectral_grid_mixed: bad arguments");
+    if (!nf) return SML_OK;
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_spec_mixed(sml_spectral *sp, const double *vorg, double *vorm, int nf, const int32_t *scale_dev, void *stream)
+{
+    SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg && scale_dev)), "sml_spectral_spec_mixed: bad arguments");
+    if (!nf) return SML_OK;
+    hipLaunchKernelGGL(k_spec, dim3(nf * NMG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorg, vorm, 0, (const int *)scale_dev);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }

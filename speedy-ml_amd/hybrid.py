@@ -147,6 +147,9 @@ class HybridRank:
             self.sched_spec = torch.zeros((91, NX, MX2), dtype=f64, device=dev)
             self.sched_grid = torch.zeros((91, IL, IX), dtype=f64, device=dev)
             self.sched_out = torch.zeros((98, NX, MX2), dtype=f64, device=dev)
+            self.sched_vds2 = torch.zeros((24, NX, MX2), dtype=f64, device=dev)
+            self.sched_kcos = torch.tensor([1] * 57 + [2] * 34, dtype=torch.int32, device=dev)
+            self.sched_scale = torch.tensor([1] * 48 + [0] * 25, dtype=torch.int32, device=dev)
             self.even_split = (NREG % world == 0)
             # first inputs: gather from the synthetic state (forecast = the same state) so feedback is realistic
             self.G[domain.GT_OFF:] = self.tisr[0].reshape(-1)
@@ -183,14 +186,14 @@ class HybridRank:
         handoff_from_fields(self.fields_out, self.F, stream)
 
     def speedy_transform_schedule(self, stream):
-        """The 164 transforms of one SPEEDY time step (SURVEY Appendix C 'Schedule inside one step()') as batched
-        launches on the device-resident spectral state: 57 inverse with kcos=1, 34 with kcos=2, 24 vdspec(.,.,2)
-        (= 48 scaled forward transforms + vds) and 25 plain forward transforms."""
+        """The 164 transforms of one SPEEDY time step (SURVEY Appendix C 'Schedule inside one step()') as THREE launches on
+        the device-resident spectral state: all 91 inverse transforms (57 with kcos=1, 34 with kcos=2; per-field flags),
+        all 73 forward transforms (48 pre-scaled by 1/cos = the specx halves of the 24 vdspec(.,.,2), 25 plain), then vds
+        for the 24 (u,v) pairs."""
         sp = self.sp
-        sp.grid(self.sched_spec[0:57], 1, out=self.sched_grid[0:57], stream=stream)
-        sp.grid(self.sched_spec[57:91], 2, out=self.sched_grid[57:91], stream=stream)
-        sp.vdspec(self.sched_grid[0:24], self.sched_grid[24:48], 2, out=(self.sched_out[0:24], self.sched_out[24:48]), stream=stream)
-        sp.spec(self.sched_grid[48:73], out=self.sched_out[48:73], stream=stream)
+        sp.grid_mixed(self.sched_spec, self.sched_kcos, out=self.sched_grid, stream=stream)
+        sp.spec_mixed(self.sched_grid[0:73], self.sched_scale, out=self.sched_out[0:73], stream=stream)
+        sp.vds(self.sched_out[0:24], self.sched_out[24:48], out=(self.sched_out[73:97], self.sched_vds2), stream=stream)
 
     def step(self, stream):
         self.bank.predict(stream=stream)

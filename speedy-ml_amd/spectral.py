@@ -64,6 +64,24 @@ class Spectral:
         check(_lib.lib().sml_spectral_spec(self._h, dp(vorg.data_ptr()), dp(out.data_ptr()), nf, vp(stream)))
         return out
 
+    def grid_mixed(self, vorm, kcos_flags, out=None, stream=None):
+        """One launch for fields with different kcos (int32 device tensor of 1|2 per field)."""
+        nf = self._chk(vorm, (NX, MX2))
+        assert kcos_flags.numel() == nf and kcos_flags.is_cuda and kcos_flags.element_size() == 4
+        out = self._new(vorm, nf, (IL, IX)) if out is None else out
+        check(_lib.lib().sml_spectral_grid_mixed(self._h, dp(vorm.data_ptr()), dp(out.data_ptr()), nf,
+                                                 _lib.ip(kcos_flags.data_ptr()), vp(stream)))
+        return out
+
+    def spec_mixed(self, vorg, scale_flags, out=None, stream=None):
+        """One launch for fields with different forward pre-scaling (0 none, 1 *cosgr, 2 *cosgr2 per field)."""
+        nf = self._chk(vorg, (IL, IX))
+        assert scale_flags.numel() == nf and scale_flags.is_cuda and scale_flags.element_size() == 4
+        out = self._new(vorg, nf, (NX, MX2)) if out is None else out
+        check(_lib.lib().sml_spectral_spec_mixed(self._h, dp(vorg.data_ptr()), dp(out.data_ptr()), nf,
+                                                 _lib.ip(scale_flags.data_ptr()), vp(stream)))
+        return out
+
     def vdspec(self, ug, vg, kcos, out=None, stream=None):
         nf = self._chk(ug, (IL, IX))
         assert self._chk(vg, (IL, IX)) == nf
