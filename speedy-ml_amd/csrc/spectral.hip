@@ -162,6 +162,7 @@ __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restri
                                               const int *__restrict__ kcos_of_field)
 {
     __shared__ double sv[SPEC_N];              // spectral coefficients
+    __shared__ double sp[LATG][NX][MX];        // this workgroup's slab of the Legendre table (31 KB), staged with sv
     __shared__ double sf[2 * LATG][MX2];       // Fourier coefficients of the 2*LATG latitude rows of this workgroup
     __shared__ double stc[IX], sts[IX];
     __shared__ int snsh[NX];
@@ -169,41 +170,50 @@ __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restri
     const int kcos = kcos_of_field ? kcos_of_field[f] : kcos_all;
     const double *v = vorm + (size_t)f * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
+    // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
     for (int i = threadIdx.x; i < SPEC_N; i += TT) sv[i] = v[i];
+    {
+        const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
+        double *pl = &sp[0][0][0];
+        for (int i = threadIdx.x; i < LATG * NX * MX; i += TT) pl[i] = pg[i];
+    }
     for (int i = threadIdx.x; i < IX; i += TT) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
     if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
     __syncthreads();
     // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O.
     // Summation order is the reference's, so without FMA contraction this is bit-identical to gridy.
     if (threadIdx.x < LATG * MX2) {
-        const int c = threadIdx.x % MX2, jj = threadIdx.x / MX2, j = lg * LATG + jj, m = c >> 1;
-        const double *p = T.pol + (size_t)j * NX * MX + m;
+        const int c = threadIdx.x % MX2, jj = threadIdx.x / MX2, m = c >> 1;
         double e = 0.0, o = 0.0;
 #pragma unroll 4
         for (int n = 0; n < NX; n += 2) {
-            if (c < snsh[n]) e = e + sv[n * MX2 + c] * p[n * MX];
-            if (c < snsh[n + 1]) o = o + sv[(n + 1) * MX2 + c] * p[(n + 1) * MX];
+            if (c < snsh[n]) e = e + sv[n * MX2 + c] * sp[jj][n][m];
+            if (c < snsh[n + 1]) o = o + sv[(n + 1) * MX2 + c] * sp[jj][n + 1][m];
         }
         sf[2 * jj + 1][c] = e + o;       // northern row il+1-j
         sf[2 * jj][c] = e - o;           // southern row j
     }
     __syncthreads();
-    // Fourier synthesis (gridx): x_i = a0 + sum_k 2 (Re_k cos(2 pi k i/96) - Im_k sin(2 pi k i/96)), k = 1..30
-    for (int w = threadIdx.x; w < 2 * LATG * IX; w += TT) {
-        const int i = w % IX, r = w / IX;
+    // Fourier synthesis (gridx) of the 31 retained modes, two longitudes per work item: with A = sum_k Re_k cos(k i t)
+    // and B = sum_k Im_k sin(k i t),  x_i = a0 + 2(A - B)  and  x_{96-i} = a0 + 2(A + B)   (i = 0..48).
+    for (int w = threadIdx.x; w < 2 * LATG * (IX / 2 + 1); w += TT) {
+        const int i = w % (IX / 2 + 1), r = w / (IX / 2 + 1);
         const int j = lg * LATG + (r >> 1);
         const int row = (r & 1) ? IL - 1 - j : j;
         const double *fc = sf[r];
-        double acc = fc[0];
+        double A = 0.0, B = 0.0;
         int ph = 0;
 #pragma unroll 6
         for (int k = 1; k <= MX - 1; ++k) {
             ph += i;
             if (ph >= IX) ph -= IX;
-            acc += 2.0 * (fc[2 * k] * stc[ph] - fc[2 * k + 1] * sts[ph]);
+            A += fc[2 * k] * stc[ph];
+            B += fc[2 * k + 1] * sts[ph];
         }
-        if (kcos != 1) acc = acc * T.cosgr[row];
-        g[row * IX + i] = acc;
+        double x0 = fc[0] + 2.0 * (A - B), x1 = fc[0] + 2.0 * (A + B);
+        if (kcos != 1) { const double cg = T.cosgr[row]; x0 = x0 * cg; x1 = x1 * cg; }
+        g[row * IX + i] = x0;
+        if (i != 0 && i != IX / 2) g[row * IX + IX - i] = x1;
     }
 }
 
@@ -212,23 +222,27 @@ __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restri
 __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restrict__ vorg, double *__restrict__ vorm, int scale_all,
                                               const int *__restrict__ scale_of_field)
 {
-    __shared__ double sg[IL][IX + 1];          // padded rows: lanes that differ in latitude hit different banks
-    __shared__ double twc[MG][IX + 2], tws[MG][IX + 2];
+    // The field is folded about longitude index 48 while it is staged: ss = x_i + x_{96-i}, sd = x_i - x_{96-i}
+    // (i = 1..47; ss[0] = x_0, ss[48] = x_48), which halves the DFT: Re_k = sum ss cos, Im_k = - sum sd sin.
+    __shared__ double ss[IL][IX / 2 + 2];      // padded rows: lanes that differ in latitude hit different banks
+    __shared__ double sd[IL][IX / 2 + 2];
+    __shared__ double twc[MG][IX / 2 + 3], tws[MG][IX / 2 + 3];
     __shared__ double sf[IL][2 * MG];          // this workgroup's Fourier coefficients [lat][re/im of its wavenumbers]
     const int f = blockIdx.x / NMG, mg = blockIdx.x % NMG;
     const int scale = scale_of_field ? scale_of_field[f] : scale_all;
     const int k0 = mg * MG, nk = min(MG, MX - k0);
     const double *g = vorg + (size_t)f * GRID_N;
     double *v = vorm + (size_t)f * SPEC_N;
-    for (int w = threadIdx.x; w < GRID_N; w += TT) {
-        const int i = w % IX, j = w / IX;
-        double x = g[w];
-        if (scale == 1) x = x * T.cosgr[j];
-        else if (scale == 2) x = x * T.cosgr2[j];
-        sg[j][i] = x;
+    for (int w = threadIdx.x; w < IL * (IX / 2 + 1); w += TT) {
+        const int i = w % (IX / 2 + 1), j = w / (IX / 2 + 1);
+        double a = g[j * IX + i], b = (i == 0 || i == IX / 2) ? 0.0 : g[j * IX + IX - i];
+        if (scale == 1) { const double cg = T.cosgr[j]; a = a * cg; b = b * cg; }
+        else if (scale == 2) { const double cg = T.cosgr2[j]; a = a * cg; b = b * cg; }
+        ss[j][i] = a + b;
+        sd[j][i] = a - b;
     }
-    for (int w = threadIdx.x; w < MG * IX; w += TT) {
-        const int i = w % IX, kk = w / IX;
+    for (int w = threadIdx.x; w < MG * (IX / 2 + 1); w += TT) {
+        const int i = w % (IX / 2 + 1), kk = w / (IX / 2 + 1);
         const int ph = ((k0 + kk) * i) % IX;
         twc[kk][i] = T.twc[ph];
         tws[kk][i] = T.tws[ph];
@@ -237,12 +251,12 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     // forward DFT (specx): a0 = sum x / 96 ; Re_k = sum x cos / 96 ; Im_k = - sum x sin / 96 ; Im of k=0 is set to 0
     if (threadIdx.x < nk * IL) {
         const int j = threadIdx.x % IL, kk = threadIdx.x / IL;
-        const double *x = sg[j], *cc = twc[kk], *ss = tws[kk];
+        const double *xs = ss[j], *xd = sd[j], *cc = twc[kk], *sn = tws[kk];
         double re = 0.0, im = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < IX; ++i) {
-            re += x[i] * cc[i];
-            im -= x[i] * ss[i];
+#pragma unroll 7
+        for (int i = 0; i <= IX / 2; ++i) {
+            re += xs[i] * cc[i];
+            im -= xd[i] * sn[i];          // sd[.][0] = x_0 and sd[.][48] = x_48 meet sin = 0
         }
         const double sc = 1. / (double)IX;
         sf[j][2 * kk] = re * sc;
@@ -258,7 +272,8 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     }
     __syncthreads();
     // Legendre analysis (specy :519-537): odd n (1-based) use svarm, even n use dvarm, n <= ntrun1, c < nsh2(n);
-    // accumulation over latitude in the reference's order -> bit-identical to specy for identical Fourier input
+    // accumulation over latitude in the reference's order -> bit-identical to specy for identical Fourier input.
+    // The 24 table loads of a thread are independent and issued together (full unroll).
     {
         const int cc = threadIdx.x % (2 * MG), n = threadIdx.x / (2 * MG);     // 8 x 32 = 256 threads
         const int c = 2 * k0 + cc, m = c >> 1;
@@ -266,8 +281,16 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
             double acc = 0.0;
             if (n < NTRUN1 && c < T.nsh2[n]) {
                 const double *p = T.pol + (size_t)n * MX + m;
-                if ((n & 1) == 0) { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[j][cc]; }
-                else              { for (int j = 0; j < IY; ++j) acc = acc + p[(size_t)j * NX * MX] * sf[IL - 1 - j][cc]; }
+                double pj[IY];
+#pragma unroll
+                for (int j = 0; j < IY; ++j) pj[j] = p[(size_t)j * NX * MX];
+                if ((n & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < IY; ++j) acc = acc + pj[j] * sf[j][cc];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < IY; ++j) acc = acc + pj[j] * sf[IL - 1 - j][cc];
+                }
             }
             v[n * MX2 + c] = acc;
         }
