@@ -239,6 +239,18 @@ void invlap_(const double *vorm, double *strm);
 void trunct_(double *vor);
 
 /* ===================================================================================================
+ * 4b. reservoir construction (host, set-up time) -- replaces gen_res / makesparse / shuffle / sparse_eigen
+ *     (src/mod_reservoir.f90:182-212, src/mod_linalg.f90:180-514, src/mod_utilities.f90:1569-1596)
+ * =================================================================================================== */
+/* makesparse: k COO entries, rows and cols each a concatenation of random permutations of 1..n, vals ~ U(0,1) */
+int sml_makesparse(int n, int k, uint64_t seed, int32_t *rows, int32_t *cols, double *vals);
+/* largest-magnitude eigenvalue of the (non-negative) COO matrix by power iteration (ARPACK 'LM' replacement) */
+int sml_spectral_radius(int n, int k, const int32_t *rows, const int32_t *cols, const double *vals, double tol, int maxit,
+                        double *lambda, int *iterations);
+/* gen_res: makesparse, then vals <- vals / lambda_max * radius */
+int sml_gen_res(int n, int k, double radius, uint64_t seed, int32_t *rows, int32_t *cols, double *vals, double *eigs);
+
+/* ===================================================================================================
  * 5. training -- replaces chunking_matmul / fit_chunk_hybrid / mldivide
  *    (src/mod_reservoir.f90:1645-1701, 1235-1334; src/mod_linalg.f90:109-151)
  * =================================================================================================== */
@@ -246,6 +258,19 @@ void trunct_(double *vor);
  * All device, column-major as in the reference: states (n,m), model (n_model,m), y (n_out,m). */
 int sml_train_accumulate(const double *states_dev, const double *model_dev, const double *y_dev,
                          int n, int n_model, int n_out, int m, double *c_dev, double *b_dev, void *stream);
+/* reservoir_layer_chunking_hybrid (src/mod_reservoir.f90:1067-1175) for EVERY loaded slot of a bank, one pass over T
+ * input columns: x <- 0; `discard` warm-up steps; then one advance per column, the (squared-even)
+ * state stored as a column of the slot's states(n, batch) buffer; every `batch` columns C += aug aug^T, B += Y aug^T.
+ *   noisy_inputs_dev : [T][capacity][max_d]   inputs with the training noise already applied (the reference's noise
+ *                      comes from the compiler RNG and is not reproducible -- SURVEY H5)
+ *   model_dev[slot]  : (n_model, T) column-major "imperfect model" forecasts;  targets_dev[slot] : (n_out, T)
+ *   c_dev[slot]      : (n_aug, n_aug), b_dev[slot] : (n_out, n_aug), accumulated (lower-triangle tiles of C)
+ * The four pointer tables are HOST arrays of device pointers, one entry per slot (NULL entries are skipped).
+ * Returns the number of batches flushed (or <0). */
+int sml_bank_train_pass(sml_bank *bank, const double *noisy_inputs_dev, int T, int discard, int batch,
+                        const double *const *model_dev, const double *const *targets_dev,
+                        double *const *c_dev, double *const *b_dev, void *stream);
+
 /* sml_train_accumulate updates only the tiles of C on or below the diagonal (half the flops and half the C traffic of
  * the reference's full DGEMM); this mirrors them into the upper triangle (sml_train_fit calls it itself). */
 int sml_train_symmetrize(double *c_dev, int n_aug, void *stream);

@@ -97,6 +97,33 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
     }
 }
 
+// states(:, col) <- x with the even (1-based) rows squared, in the REFERENCE's row order (src/mod_reservoir.f90:1133):
+// the Gram matrices and W_out are defined over the reference's state indices.  One workgroup row per slot.
+struct TrainSlot { double *states; int n; };
+__global__ void k_store_state(const ResDesc *__restrict__ descs, const TrainSlot *__restrict__ ts, int nslots, int col, int cur)
+{
+    const int slot = blockIdx.y;
+    if (slot >= nslots) return;
+    const ResDesc &D = descs[slot];
+    const TrainSlot t = ts[slot];
+    if (!D.loaded || !t.states) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.n) return;
+    const double v = D.x[cur][p];
+    const int r = D.perm[p];                       // device position -> reference row (same parity as p)
+    t.states[(size_t)col * D.n + r] = (r & 1) ? v * v : v;
+}
+
+__global__ void k_zero_state(const ResDesc *__restrict__ descs, int nslots, int cur)
+{
+    const int slot = blockIdx.y;
+    if (slot >= nslots) return;
+    const ResDesc &D = descs[slot];
+    if (!D.loaded) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < D.n) D.x[cur][p] = 0.0;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -629,6 +656,62 @@ int sml_bank_timing_collect(sml_bank *b, double *update_ms, int *update_launches
     int rc;
     if ((rc = drain(b->ev_update, update_ms, update_launches))) return rc;
     return drain(b->ev_readout, readout_ms, readout_launches);
+}
+
+int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int discard, int batch,
+                        const double *const *model_dev, const double *const *targets_dev,
+                        double *const *c_dev, double *const *b_dev, void *stream)
+{
+    SML_REQUIRE(b && noisy_inputs_dev && model_dev && targets_dev && c_dev && b_dev, "sml_bank_train_pass: null argument");
+    SML_REQUIRE(T > discard && discard >= 0 && batch > 0, "sml_bank_train_pass: need T > discard >= 0 and batch > 0 (T=%d discard=%d batch=%d)", T, discard, batch);
+    hipStream_t st = sml::as_stream(stream);
+    int rc = sync_descs(b);
+    if (rc) return rc;
+    // per-slot states(n, batch) buffers
+    std::vector<TrainSlot> ts(b->capacity, TrainSlot{nullptr, 0});
+    std::vector<double *> owned;
+    int nmax = 0;
+    for (int s = 0; s < b->capacity; ++s) {
+        const ResDesc &D = b->res[s].desc;
+        if (!D.loaded || !c_dev[s] || !b_dev[s] || !targets_dev[s]) continue;
+        double *p = nullptr;
+        if (hipMalloc((void **)&p, (size_t)D.n * batch * sizeof(double)) != hipSuccess) {
+            for (double *q : owned) (void)hipFree(q);
+            return sml::fail(SML_ERR_HIP, "sml_bank_train_pass: out of device memory for the states buffers");
+        }
+        owned.push_back(p);
+        ts[s] = TrainSlot{p, D.n};
+        nmax = std::max(nmax, D.n);
+    }
+    TrainSlot *d_ts = nullptr;
+    auto cleanup = [&]() { for (double *q : owned) (void)hipFree(q); if (d_ts) (void)hipFree(d_ts); };
+    if ((rc = sml::dev_upload(&d_ts, ts.data(), ts.size()))) { cleanup(); return rc; }
+    const dim3 sgrid((nmax + 255) / 256, b->capacity);
+    const size_t step = (size_t)b->capacity * b->max_d;
+    hipLaunchKernelGGL(k_zero_state, sgrid, dim3(256), 0, st, b->d_descs, b->capacity, b->cur);          // x = 0 (:1089)
+    for (int c = 0; c < discard && rc == SML_OK; ++c) rc = launch_update(b, 0, b->capacity, noisy_inputs_dev + step * c, st);
+    if (rc == SML_OK) hipLaunchKernelGGL(k_store_state, sgrid, dim3(256), 0, st, b->d_descs, d_ts, b->capacity, 0, b->cur);   // states(:,1) = x
+    int flushed = 0;
+    const int training_length = T - discard;
+    for (int i = 1; i <= training_length - 1 && rc == SML_OK; ++i) {
+        // the running (unsquared) state lives in the bank, so "restart from saved_state after a flush" (quirk Q6) is implicit
+        rc = launch_update(b, 0, b->capacity, noisy_inputs_dev + step * (discard + i - 1), st);
+        if (rc) break;
+        hipLaunchKernelGGL(k_store_state, sgrid, dim3(256), 0, st, b->d_descs, d_ts, b->capacity, i % batch, b->cur);
+        if ((i + 1) % batch == 0) {
+            ++flushed;
+            const size_t c0 = (size_t)discard + (size_t)(flushed - 1) * batch;        // first data column of the batch
+            for (int s = 0; s < b->capacity && rc == SML_OK; ++s) {
+                if (!ts[s].states) continue;
+                const ResDesc &D = b->res[s].desc;
+                rc = sml_train_accumulate(ts[s].states, D.n_model ? model_dev[s] + c0 * D.n_model : nullptr, targets_dev[s] + c0 * D.n_out,
+                                          D.n, D.n_model, D.n_out, batch, c_dev[s], b_dev[s], stream);
+            }
+        }
+    }
+    if (rc == SML_OK && hipStreamSynchronize(st) != hipSuccess) rc = sml::fail(SML_ERR_HIP, "sml_bank_train_pass: stream synchronise failed");
+    cleanup();
+    return rc == SML_OK ? flushed : rc;
 }
 
 int sml_bank_algorithmic_bytes(sml_bank *b, uint64_t *update_bytes, uint64_t *readout_bytes)

@@ -124,3 +124,29 @@ class ReservoirBank:
         u, r = C.c_uint64(), C.c_uint64()
         check(_lib.lib().sml_bank_algorithmic_bytes(self._h, C.byref(u), C.byref(r)))
         return u.value, r.value
+
+    def train_pass(self, noisy_inputs, discard, batch, models, targets, cs, bs, stream=None):
+        """reservoir_layer_chunking_hybrid (src/mod_reservoir.f90:1067-1175) for every loaded slot.
+        noisy_inputs: device tensor [T, capacity, max_d]; models/targets/cs/bs: per-slot lists of device tensors
+        (column-major buffers, see speedy_ml_amd.train) or None for slots to skip.  Returns #batches flushed."""
+        T = noisy_inputs.shape[0]
+        assert tuple(noisy_inputs.shape[1:]) == (self.capacity, self.max_d) and noisy_inputs.is_contiguous()
+
+        def table(lst):
+            arr = (C.c_void_p * self.capacity)()
+            for i in range(self.capacity):
+                t = lst[i] if i < len(lst) else None
+                arr[i] = None if t is None else t.data_ptr()
+            return arr
+        tm, tt, tc, tb = table(models), table(targets), table(cs), table(bs)
+        return check(_lib.lib().sml_bank_train_pass(self._h, dp(noisy_inputs.data_ptr()), T, discard, batch,
+                                                    tm, tt, tc, tb, vp(stream)))
+
+
+def gen_res(n, k, radius, seed):
+    """gen_res (src/mod_reservoir.f90:182-212): makesparse + spectral-radius rescale. Returns rows, cols, vals, eigs."""
+    rows, cols = np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.int32)
+    vals = np.zeros(k)
+    eigs = C.c_double()
+    check(_lib.lib().sml_gen_res(n, k, C.c_double(radius), C.c_uint64(seed), ip(rows), ip(cols), dp(vals), C.byref(eigs)))
+    return rows, cols, vals, eigs.value

@@ -124,3 +124,38 @@ def test_full_size_gram_against_torch_fp64():
     bref = aug.T @ y                                  # torch [n_aug, n_out] == column-major (n_out, n_aug)
     assert float((c - cref).abs().max()) <= 1e-12 * float(cref.abs().max())
     assert float((b - bref).abs().max()) <= 1e-12 * float(bref.abs().max())
+
+
+def test_device_training_pass_matches_oracle(oracle):
+    """K7 on the device (reservoir recurrence + batch flushes into the MFMA Gram update) for two reservoirs of different
+    size in one bank, against the oracle's restatement of reservoir_layer_chunking_hybrid."""
+    from speedy_ml_amd.reservoir import ReservoirBank
+    from speedy_ml_amd.synth import make_reservoir
+    rs = [make_reservoir(n=120, d=12, n_model=4, n_out=6, seed=8), make_reservoir(n=256, d=8, n_model=2, n_out=3, seed=9)]
+    bank = ReservoirBank(3, max_d=12, max_n_model=4, max_n_out=6)
+    for i, r in enumerate(rs):
+        bank.load(i, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
+    rng = np.random.default_rng(12)
+    T, discard, batch = 4 + 3 * 5, 4, 5
+    noisy = rng.standard_normal((T, 3, 12))
+    dev_in = torch.from_numpy(noisy).cuda()
+    models, targets, cs, bs, want = [], [], [], [], []
+    for i, r in enumerate(rs):
+        model, targ = rng.standard_normal((r.n_model, T)), rng.standard_normal((r.n_out, T))
+        models.append(to_dev(model)); targets.append(to_dev(targ))
+        cs.append(train.fortran_zeros(r.n_aug, r.n_aug)); bs.append(train.fortran_zeros(r.n_out, r.n_aug))
+        co, bo = np.zeros((r.n_aug, r.n_aug), order="F"), np.zeros((r.n_out, r.n_aug), order="F")
+        nb = oracle.train_states(r.n, r.d, r.rows, r.cols, r.vals, r.win, 1.0, np.asfortranarray(noisy[:, i, :r.d].T), discard,
+                                 batch, model, targ, co, bo)
+        want.append((nb, co, bo))
+    nb = bank.train_pass(dev_in, discard, batch, models, targets, cs, bs)
+    for i, r in enumerate(rs):
+        nbo, co, bo = want[i]
+        assert nb == nbo == 3          # flushes at i = 4, 9, 14 (i+1 divisible by the batch size)
+        cg, bg = to_host(cs[i]), to_host(bs[i])
+        low = np.tril_indices(r.n_aug)
+        assert np.max(np.abs(cg[low] - co[low])) <= 1e-12 * np.max(np.abs(co))
+        assert np.max(np.abs(bg - bo)) <= 1e-12 * np.max(np.abs(bo))
+    # end to end: fit W_out from the device-accumulated matrices and load it back into the bank
+    wout = train.fit_chunk_hybrid(cs[0], bs[0], rs[0].n, rs[0].n_model, rs[0].n_out, 1e-3, 1.0, 0.0, True)
+    bank.set_wout(0, to_host(wout))
