@@ -5,8 +5,9 @@ generators.  Pure numpy, no device code: the same arrays feed the HIP path and t
 
 Reservoir construction mirrors the reference's generators in *distribution* (not bit-for-bit: the
 reference uses the Fortran compiler's RNG):
-  * A  : k = int(deg/m * n * n) COO entries, rows/cols ~ U{1..n} (1-based, unsorted, duplicates possible),
-         vals ~ U(0,1) rescaled to spectral radius ~rho            (mod_linalg.f90:180-218, mod_reservoir.f90:182-212)
+  * A  : k = int(deg/m * n * n) COO entries; rows and cols are concatenated random permutations of 1..n (1-based,
+         unsorted, duplicate (row,col) pairs possible), vals ~ U(0,1) rescaled to spectral radius ~rho
+                                                                    (mod_linalg.f90:180-218, mod_reservoir.f90:182-212)
   * Win: one nonzero per row, rows (i-1)q+1..iq of column i ~ sigma*U(-1,1), q = n/d   (mod_reservoir.f90:262-283)
   * Wout ~ N(0, 1e-2), mean ~ U(-1,1), std ~ U(0.5,2)
 """
@@ -46,8 +47,14 @@ def make_reservoir(n=5760, d=576, n_model=132, n_out=136, seed=20240954, deg=6, 
                    dense_win=True):
     rng = np.random.default_rng(seed)
     k = int((deg / float(m)) * n * n)
-    rows = rng.integers(1, n + 1, size=k, dtype=np.int32)
-    cols = rng.integers(1, n + 1, size=k, dtype=np.int32)
+    # makesparse (src/mod_linalg.f90:180-218): rows and cols are concatenated random permutations of 1..n, so every
+    # row/column of A carries floor(k/n) or floor(k/n)+1 entries
+    def perm_list():
+        blocks = [rng.permutation(n) + 1 for _ in range(k // n)]
+        if k % n:
+            blocks.append(rng.permutation(n)[:k % n] + 1)
+        return np.concatenate(blocks).astype(np.int32) if blocks else np.zeros(0, dtype=np.int32)
+    rows, cols = perm_list(), perm_list()
     vals = rng.random(k)
     # spectral radius of a non-negative random matrix ~ mean row sum
     lam = max(k / float(n) * 0.5, 1e-3)
