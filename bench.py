@@ -92,6 +92,18 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
+        # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md): collected by
+        # profiles/collect.sh with the same bank at N=1, so it is only quoted when this run is N=1 with all 1152 regions.
+        traffic = None
+        try:
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[-1]
+            traffic = json.load(open(latest))["kernels"]["k_readout"].get("hbm_traffic_bytes_per_launch")
+            if world != 1 or len(regions) != hybrid.NREG:
+                traffic = None
+        except Exception:
+            traffic = None
         ms = elapsed / args.steps * 1e3
         upd_b, ro_b = model.bank.algorithmic_bytes()
         ro_ms = kern["readout_ms"] / max(kern["readout_launches"], 1)
@@ -111,7 +123,7 @@ def main():
             "config": model.describe(),
             "roofline": {"bound": "hbm", "kernel": "k_readout<17> (W_out [local_model;x~] GEMV, all resident reservoirs)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None,
+                         "traffic": traffic,
                          "algorithmic_bytes_per_launch": ro_b, "avg_launch_ms": ro_ms,
                          "secondary": {"kernel": "k_update (SELL-64 [A|Win]x + tanh)", "achieved":
                                        (upd_b / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0), "unit": "GB/s",

@@ -260,18 +260,23 @@ class HybridRank:
                   f"reservoir: {per_predict * 1e3:.3f} ms each, x1152 per step")
         total = per_predict * NREG
         if self.mode == "hybrid":
+            from _oracle import RefSpectral
             rng = np.random.default_rng(1)
             v = rng.standard_normal((MX2, NX))
             gfield = rng.standard_normal((IX, IL))
+            # the transform leg uses the COMPILED REFERENCE (oracle/_ref: the reference's own FFTPACK + Legendre code) when
+            # its .so travelled with the snapshot, else the oracle's direct-DFT restatement (5x slower: flattering)
+            eng = RefSpectral() if RefSpectral.available() else o
+            which = "compiled reference spe_spectral.f90/FFTPACK (oracle/_ref)" if RefSpectral.available() else "oracle direct-DFT restatement"
             t1 = time.perf_counter()
             m = 0
             while time.perf_counter() - t1 < 3.0:
-                o.grid(v, 1)
-                o.spec(gfield)
+                eng.grid(v, 1)
+                eng.spec(gfield)
                 m += 1
             per_pair = (time.perf_counter() - t1) / m
             ntr = 66 + 164 * self.replay_steps
             total += per_pair * ntr / 2.0
-            sample += (f"; {m} oracle grid+spec pairs (direct-DFT restatement): {per_pair * 1e6:.0f} us per pair, "
+            sample += (f"; {m} grid+spec pairs with the {which}: {per_pair * 1e6:.0f} us per pair (incl. ctypes call overhead), "
                        f"x{ntr // 2} pairs per step; exchange tilers not timed (small)")
         return {"value": 1.0 / total, "unit": "steps/s", "cores": 1, "kind": "port", "sample": sample}

@@ -132,3 +132,26 @@ def test_errors_are_loud():
         bank.load(0, r.n, r.d, r.n_model, r.n_out, bad, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
     with pytest.raises(SmlError):
         bank.load(5, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
+
+
+def test_slab_ocean_shapes(oracle):
+    """the slab-ocean reservoirs reuse the same kernels with m=4000, d=128 -> n=3968, k=23617,
+    8 outputs (SST 4 + OHTC 4), no model rows, and one statistics slot for every output
+    (predict_slab_ml, src/mod_slab_ocean_reservoir.f90:1318-1363)."""
+    n, d, n_out = 3968, 128, 8
+    r = make_reservoir(n=n, d=d, n_model=0, n_out=n_out, seed=77, m=4000, sigma=0.6)
+    assert r.k == 23617
+    stat = np.full(n_out, 3, dtype=np.int32)          # grid%sst_mean_std_idx for every output
+    banks = ReservoirBank(4, max_d=d, max_n_model=0, max_n_out=n_out)
+    rng = np.random.default_rng(3)
+    x0 = rng.standard_normal(n) * 0.2
+    for slot in (0, 3):
+        banks.load(slot, r.n, r.d, 0, n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, stat)
+        banks.set_state(slot, x0)
+        banks.set_feedback(slot, r.feedback)
+    banks.predict()
+    xw, ow = oracle.predict_raw(r.n, r.d, 0, n_out, r.rows, r.cols, r.vals, r.win, r.wout, 1.0, r.feedback, None, x0)
+    ow = ow * r.std[3] + r.mean[3]
+    for slot in (0, 3):
+        assert np.max(np.abs(banks.get_state(slot) - xw)) <= X_TOL
+        assert np.max(np.abs(banks.get_outvec(slot) - ow)) <= OUT_TOL * np.max(np.abs(ow))
