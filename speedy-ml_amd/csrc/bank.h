@@ -10,10 +10,10 @@ namespace sml {
 struct ResDesc {
     int n, d, n_model, n_out, n_aug, n_aug_pad, nslices, loaded;
     const int *slice_off;      // [nslices+1] first entry of each 64-row slice (entries are width*64 per slice)
-    const int *sell_col;       // column into [x ; u]
+    const unsigned short *sell_col;   // column into [x ; u] as uint16 (n + d <= 65535): 10 B per stored nonzero
     const double *sell_val;
     const int *perm;           // device position -> original row (kept for diagnostics; the kernels do not need it)
-    const int *row_len;        // nonzeros of the row at each sorted position
+    const unsigned char *row_len;     // nonzeros of the row at each device position (<= 255)
     double *x[2];              // ping-pong state
     const double *wout;        // [n_out][n_aug_pad] row-major, zero padded
     const double *mean, *stdv;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
         const int width = (D.slice_off[s + 1] - off) >> 6;
         const int len = D.row_len[s * 64 + lane];
         const int r = s * 64 + lane;                      // device position == sorted position: contiguous stores
-        const int *__restrict__ cp = D.sell_col + off + lane;
+        const unsigned short *__restrict__ cp = D.sell_col + off + lane;
         const double *__restrict__ vp = D.sell_val + off + lane;
         double acc = 0.0;
         int j = 0;
@@ -295,16 +295,19 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
     std::vector<int> inv(n);
     for (int p = 0; p < n; ++p) inv[order[p]] = p;
     const int nslices = (n + 63) / 64;
-    std::vector<int> slice_off(nslices + 1, 0), perm(nslices * 64, -1), row_len(nslices * 64, 0);
+    SML_REQUIRE(n + d <= 65535, "sml_bank_load: n + d = %d exceeds the 16-bit column index of the device layout", n + d);
+    for (int i = 0; i < n; ++i) SML_REQUIRE(cnt[i] <= 255, "sml_bank_load: row %d has %d nonzeros (> 255)", i, cnt[i]);
+    std::vector<int> slice_off(nslices + 1, 0), perm(nslices * 64, -1);
+    std::vector<unsigned char> row_len(nslices * 64, 0);
     for (int s = 0; s < nslices; ++s) {
         int width = 0;
         for (int l = 0; l < 64; ++l) {
             const int pos = s * 64 + l;
-            if (pos < n) { perm[pos] = order[pos]; row_len[pos] = cnt[order[pos]]; width = std::max(width, cnt[order[pos]]); }
+            if (pos < n) { perm[pos] = order[pos]; row_len[pos] = (unsigned char)cnt[order[pos]]; width = std::max(width, cnt[order[pos]]); }
         }
         slice_off[s + 1] = slice_off[s] + width * 64;
     }
-    std::vector<int> scol(slice_off[nslices], 0);
+    std::vector<unsigned short> scol(slice_off[nslices], 0);
     std::vector<double> sval(slice_off[nslices], 0.0);
     for (int s = 0; s < nslices; ++s)
         for (int l = 0; l < 64; ++l) {
@@ -313,7 +316,7 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
             const int r = order[pos];
             for (int j = 0; j < cnt[r]; ++j) {
                 const int c = ccol[ptr[r] + j];
-                scol[slice_off[s] + j * 64 + l] = c < n ? inv[c] : c;           // state columns refer to device positions
+                scol[slice_off[s] + j * 64 + l] = (unsigned short)(c < n ? inv[c] : c);           // state columns refer to device positions
                 sval[slice_off[s] + j * 64 + l] = cval[ptr[r] + j];
             }
         }
