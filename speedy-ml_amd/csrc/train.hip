@@ -42,40 +42,52 @@ __device__ __forceinline__ WavePos wave_pos()
     return {(wave & 1) * 64, (wave >> 1) * 64, lane & 15, lane >> 4, lane & 3};
 }
 
+template <int KTILE>
 __device__ __forceinline__ void mma_ktile(const double (*As)[LDS_LD], const double (*Bs)[LDS_LD], const WavePos &w, double (&acc)[4][16])
 {
+    // All 20 operand reads of a k-step are issued before its 64 MFMAs (profiles/micro/mfma_f64_pattern.hip: this shape
+    // sustains 71-74 TFLOP/s with the operands re-read from LDS every k-step; splitting the B fragment in halves to save
+    // registers put a wait in front of every 32 MFMAs and ran at 29 TFLOP/s).
 #pragma unroll
-    for (int kk = 0; kk < KT; kk += 4) {
-        double af[4];
+    for (int kk = 0; kk < KTILE; kk += 4) {
+        double af[4], bf[16];
 #pragma unroll
         for (int t = 0; t < 4; ++t) af[t] = As[kk + w.l4][w.wi + 16 * t + w.l15];       // A(I0 + 4 blk + j, k): MFMA "B" operand
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                                                    // two halves keep 16 fewer VGPRs live
-            double bf[8];
+        for (int u = 0; u < 16; ++u) bf[u] = Bs[kk + w.l4][w.wj + 4 * u + w.l3];        // B(J0 + i, k): MFMA "A" operand
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bf[u] = Bs[kk + w.l4][w.wj + 4 * (8 * h + u) + w.l3];   // B(J0 + i, k): MFMA "A" operand
+        for (int u = 0; u < 16; ++u)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[t][8 * h + u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bf[u], af[t], acc[t][8 * h + u], 0, 0, 0);
-        }
+            for (int t = 0; t < 4; ++t)
+                acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bf[u], af[t], acc[t][u], 0, 0, 0);
     }
 }
 
-// lane l holds C(I0 + 16 t + (l & 15), J0 + 4 u + (l >> 4))
+// lane l holds C(I0 + 16 t + (l & 15), J0 + 4 u + (l >> 4)).  C += alpha * acc as a read-modify-write in chunks of 16
+// elements per lane: the 16 loads of a chunk are issued together (one exposed round trip per chunk, not per element).
 __device__ __forceinline__ void store_tile(double *__restrict__ C, long ldc, int M, int N, int i0, int j0, const WavePos &w, double alpha,
                                            const double (&acc)[4][16])
 {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int j = j0 + w.wj + 4 * u + w.l4;
-        if (j >= N) continue;
-        double *cj = C + (long)j * ldc;
+    for (int u0 = 0; u0 < 16; u0 += 4) {
+        double cv[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = i0 + w.wi + 16 * t + w.l15;
-            if (i < M) cj[i] = cj[i] + alpha * acc[t][u];
+        for (int uu = 0; uu < 4; ++uu) {
+            const int j = j0 + w.wj + 4 * (u0 + uu) + w.l4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = i0 + w.wi + 16 * t + w.l15;
+                cv[uu][t] = (i < M && j < N) ? C[(long)j * ldc + i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+            const int j = j0 + w.wj + 4 * (u0 + uu) + w.l4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = i0 + w.wi + 16 * t + w.l15;
+                if (i < M && j < N) C[(long)j * ldc + i] = cv[uu][t] + alpha * acc[t][u0 + uu];
+            }
         }
     }
 }
@@ -145,23 +157,26 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_acc(const double *__restrict__ A
             stage_load<A_KC>(A, sai, sak, i0, M, k0 + KT, K, ra);
             stage_load<B_KC>(B, sbj, sbk, j0, N, k0 + KT, K, rb);
         }
-        mma_ktile(As, Bs, w, acc);
+        mma_ktile<KT>(As, Bs, w, acc);
     }
     store_tile(C, ldc, M, N, i0, j0, w, alpha, acc);
 }
 
 // Fast path for the Gram updates: both operands row-contiguous (A(i,k) = A[i + k*lda], B(j,k) = B[j + k*ldb]), 16-byte
-// aligned columns, K a multiple of 16.  Operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): one
+// aligned columns, K a multiple of 8.  Operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): one
 // wavefront instruction moves 64 lanes x 16 B = one 128-row k-column of the tile straight into its (padded) LDS row --
-// no staging registers, no ds_write -- double-buffered so the DMA of K-tile t+1 runs under the MFMAs of K-tile t with
-// one barrier per K-tile.  Rows past M/N are clamped to valid memory (their products only feed rows that are never stored).
+// no staging registers, no ds_write.  Four LDS buffers of 8 k-columns form a ring; the DMA runs THREE K-tiles ahead of
+// the MFMAs (a counted s_waitcnt vmcnt(N) + a raw s_barrier per K-tile; __syncthreads would drain the ring), because
+// one tile of look-ahead (2048 MFMA cycles) does not cover a loaded HBM/Infinity-Cache round trip.
+// Rows past M/N are clamped to valid memory (their products only feed rows that are never stored).
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
+constexpr int DKT = 8, NBUF = 4, AHEAD = 3;
 
 __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
                                                         double *__restrict__ C, long ldc, int M, int N, int K, double alpha, int lower_only)
 {
-    __shared__ __attribute__((aligned(16))) double S[2][2][KT][LDS_LD];       // [buffer][operand][k][row]
+    __shared__ __attribute__((aligned(16))) double S[NBUF][2][DKT][LDS_LD];       // [ring slot][operand][k][row]  73.7 KB
     const int ti = blockIdx.x, tj = blockIdx.y;
     if (lower_only && tj > ti) return;
     const int i0 = ti * BM, j0 = tj * BN;
@@ -175,20 +190,26 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict_
 #pragma unroll
         for (int b = 0; b < 16; ++b) acc[a][b] = 0.0;
 
-    auto issue = [&](int buf, int k0) {
+    // each wave moves 2 of the 8 k-columns of each operand: 4 DMAs per wave per K-tile
+    auto issue = [&](int slot, int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = wave * 4 + q;
-            __builtin_amdgcn_global_load_lds((gptr_t)(pa + (long)(k0 + k) * lda), (lptr_t)&S[buf][0][k][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(pb + (long)(k0 + k) * ldb), (lptr_t)&S[buf][1][k][0], 16, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+            const int k = wave * 2 + q;
+            __builtin_amdgcn_global_load_lds((gptr_t)(pa + (long)(k0 + k) * lda), (lptr_t)&S[slot][0][k][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(pb + (long)(k0 + k) * ldb), (lptr_t)&S[slot][1][k][0], 16, 0, 0);
         }
     };
-    issue(0, 0);
-    int cur = 0;
-    for (int k0 = 0; k0 < K; k0 += KT, cur ^= 1) {
-        __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) here; all waves also finished reading buffer cur^1
-        if (k0 + KT < K) issue(cur ^ 1, k0 + KT);
-        mma_ktile(S[cur][0], S[cur][1], w, acc);
+    const int ntiles = K / DKT;
+    for (int t = 0; t < AHEAD && t < ntiles; ++t) issue(t, t * DKT);
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t must have landed; the younger tiles (4 DMAs each, at most two of them) may stay in flight
+        const int younger = min(AHEAD - 1, ntiles - 1 - t);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();        // every wave's share of tile t is in LDS; everyone is done with slot (t-1)%4
+        if (t + AHEAD < ntiles) issue((t + AHEAD) % NBUF, (t + AHEAD) * DKT);
+        mma_ktile<DKT>(S[t % NBUF][0], S[t % NBUF][1], w, acc);
     }
     store_tile(C, ldc, M, N, i0, j0, w, alpha, acc);
 }
@@ -389,7 +410,7 @@ int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, lon
     // short K (the shipped batch size m = 98) is bound by the read-modify-write of C: one pass with the general kernel
     // beats main + tail passes.  Long K (m = 2920, the 40-year configuration) takes the LDS-DMA kernel.
     if (ok(A, lda) && ok(B, ldb) && M >= 2 && N >= 2 && K >= 512) {
-        kmain = (K / KT) * KT;
+        kmain = (K / DKT) * DKT;
         dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
         hipLaunchKernelGGL(k_gemm_nt_dma, grid, dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, lower_only);
         SML_HIP(hipGetLastError());
@@ -413,15 +434,34 @@ int sml_train_accumulate(const double *states, const double *model, const double
     int rc;
     // aug = [model ; states] is never materialised: the four (model|states) x (model|states) blocks of C and the two
     // blocks of B are separate launches on the original arrays.  Only tiles on/below the diagonal of C are updated.
+    // The skinny products (132- and 136-row operands: 90 tiles each) would each cost a full tile latency (the K loop of
+    // a tile is sequential: 0.36 ms at m = 2920) if they queued behind the big one; they are forked onto two side
+    // streams so they fill the SYRK's ragged last round instead.
+    static hipStream_t side[2] = {nullptr, nullptr};
+    static hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    if (!side[0]) {
+        for (int i = 0; i < 2; ++i) {
+            SML_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+            SML_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
+        SML_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    }
+    SML_HIP(hipEventRecord(ev_fork, st));
+    for (int i = 0; i < 2; ++i) SML_HIP(hipStreamWaitEvent(side[i], ev_fork, 0));
     double *c_ss = c + (long)n_model + (long)n_model * n_aug;
     if ((rc = gemm_nt(states, n, states, n, c_ss, n_aug, n, n, m, 1.0, 1, st))) return rc;
     if (n_model) {
-        if ((rc = gemm_nt(model, n_model, model, n_model, c, n_aug, n_model, n_model, m, 1.0, 0, st))) return rc;
+        if ((rc = gemm_nt(model, n_model, model, n_model, c, n_aug, n_model, n_model, m, 1.0, 0, side[0]))) return rc;
         // lower-left block: rows = states, cols = model
-        if ((rc = gemm_nt(states, n, model, n_model, c + n_model, n_aug, n, n_model, m, 1.0, 0, st))) return rc;
-        if ((rc = gemm_nt(y, n_out, model, n_model, b, n_out, n_out, n_model, m, 1.0, 0, st))) return rc;
+        if ((rc = gemm_nt(states, n, model, n_model, c + n_model, n_aug, n, n_model, m, 1.0, 0, side[0]))) return rc;
+        if ((rc = gemm_nt(y, n_out, model, n_model, b, n_out, n_out, n_model, m, 1.0, 0, side[1]))) return rc;
     }
-    return gemm_nt(y, n_out, states, n, b + (long)n_model * n_out, n_out, n_out, n, m, 1.0, 0, st);
+    if ((rc = gemm_nt(y, n_out, states, n, b + (long)n_model * n_out, n_out, n_out, n, m, 1.0, 0, side[1]))) return rc;
+    for (int i = 0; i < 2; ++i) {
+        SML_HIP(hipEventRecord(ev_join[i], side[i]));
+        SML_HIP(hipStreamWaitEvent(st, ev_join[i], 0));
+    }
+    return SML_OK;
 }
 
 int sml_train_symmetrize(double *c, int n_aug, void *stream)
