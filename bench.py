@@ -51,10 +51,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    _lib.check(_lib.lib().sml_set_device(local_rank))
+    # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm).  SML_DIST_BACKEND=gloo lets several ranks share one GPU so that
+    # the N>1 code path can be rehearsed on a 1-GPU box (the slab is then staged through the host); never used for numbers.
+    backend = os.environ.get("SML_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    _lib.check(_lib.lib().sml_set_device(device_index))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
@@ -86,7 +93,7 @@ def main():
     kern = model.timing_collect()
     model.timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -91,6 +91,12 @@ def gather_outvec_slab(local_outvec, regions, all_out, even_split):
     src/res_domain.f90:53-60) the blocks are ragged: every rank writes its rows into a zeroed slab and the slabs
     are summed -- each row has exactly one owner, so the sum is exact."""
     import torch.distributed as dist
+    if all_out.is_cuda and dist.get_backend() != "nccl":
+        # rehearsal only (several ranks sharing one GPU over gloo): stage the slab through the host
+        host = all_out.cpu()
+        gather_outvec_slab(local_outvec.cpu(), regions, host, even_split)
+        all_out.copy_(host)
+        return all_out
     if even_split:
         dist.all_gather_into_tensor(all_out, local_outvec)
     else:
