@@ -68,6 +68,12 @@ int sml_domain_region(int number_of_regions, int region_num, int overlap, int nu
 int sml_domain_sizes(const sml_region *g, int m, int deg, int local_predictvars, int logp_bool, int precip_bool,
                      int sst_bool_input, int tisr_input_bool, int ml_only, sml_res_sizes *out);
 
+/* getsend_receive_size_{res,speedy,input,res_slab,input_slab} (src/mpires.f90:806-925) -> sizes5[0..4] */
+int sml_domain_message_sizes(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
+                             int vert_overlap, int precip_bool, int ohtc_bool_input, int32_t *sizes5);
+/* find_closest_divisor (src/mod_utilities.f90:1598-1636); returns the divisor (>0) or <0 on bad arguments */
+int sml_find_closest_divisor(int target, int number);
+
 /* Global state buffer ("G") layout used by the device-resident step loop (doubles):
  *   [0, 147456)            grid4d(4,96,48,8)  Fortran order: ((z*48+y)*96+x)*4+v
  *   [147456, +4608)        logp(96,48)        y*96+x

@@ -248,4 +248,33 @@ int sml_domain_in_map(int number_of_regions, int region_num, int overlap, int nu
     return q;
 }
 
+// getsend_receive_size_{res,speedy,input,res_slab,input_slab} (src/mpires.f90:806-925): lengths of the per-region vectors
+// the reference ships between ranks; here they size the outvec / local_model / feedback slabs.
+int sml_domain_message_sizes(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
+                             int vert_overlap, int precip_bool, int ohtc_bool_input, int32_t *sizes5)
+{
+    Patch p; Vert v;
+    SML_REQUIRE(sizes5, "sml_domain_message_sizes: null output");
+    SML_REQUIRE(patch(number_of_regions, region_num, overlap, p), "sml_domain_message_sizes: bad region");
+    SML_REQUIRE(vert(num_vert_levels, vert_level, vert_overlap, v), "sml_domain_message_sizes: bad level");
+    const int res2d = p.rxc * p.ryc, in2d = p.ixc * p.iyc;
+    sizes5[0] = res2d * v.rzc * NV + (v.bottom ? res2d * (1 + (precip_bool ? 1 : 0)) : 0);     // _res    (:806-830)
+    sizes5[1] = res2d * v.rzc * NV + (v.bottom ? res2d : 0);                                   // _speedy (:832-853)
+    sizes5[2] = in2d * v.izc * NV + (v.bottom ? in2d * (1 + (precip_bool ? 1 : 0)) : 0);       // _input  (:877-902)
+    sizes5[3] = res2d * (1 + (ohtc_bool_input ? 1 : 0));                                       // _res_slab (:855-875)
+    sizes5[4] = in2d * (1 + (ohtc_bool_input ? 1 : 0));                                        // _input_slab (:904-925)
+    return SML_OK;
+}
+
+// find_closest_divisor (src/mod_utilities.f90:1598-1636): batch size for the chunked training
+// (initialize_chunk_training, src/mod_reservoir.f90:1561-1592: approx = (traininglength-discardlength)/(20*timestep))
+int sml_find_closest_divisor(int target, int number)
+{
+    SML_REQUIRE(target > 0 && number > 0, "sml_find_closest_divisor: arguments must be positive");
+    if (number % target == 0) return target;
+    for (int radius = 2;; ++radius)
+        for (int i = target - radius; i <= target + radius; ++i)
+            if (i > 0 && number % i == 0) return i;
+}
+
 }  // extern "C"

@@ -100,3 +100,17 @@ def test_bad_arguments_fail_loudly():
         domain.initializedomain(1152, 1152)
     with pytest.raises(SmlError):
         domain.processor_decomposition_manual(8, 8, 1152)
+
+
+def test_message_sizes_and_batch_divisor(oracle):
+    import numpy as np
+    from speedy_ml_amd import _lib
+    sizes = np.zeros(5, dtype=np.int32)
+    # interior region: outvec 136, SPEEDY patch 132, input without sst/tisr 544, slab 8 / 32
+    _lib.check(_lib.lib().sml_domain_message_sizes(1152, 954, 1, 1, 1, 0, 1, 1, _lib.ip(sizes)))
+    assert list(sizes) == [136, 132, 544, 8, 32]
+    _lib.check(_lib.lib().sml_domain_message_sizes(1152, 0, 1, 1, 1, 0, 1, 1, _lib.ip(sizes)))
+    assert list(sizes) == [136, 132, 408, 8, 24]          # polar: 4x3 input patch
+    for target, number in ((98, 1960), (7, 64), (2920, 58400), (13, 100), (97, 1960)):
+        assert _lib.lib().sml_find_closest_divisor(target, number) == oracle.find_closest_divisor(target, number)
+    assert _lib.lib().sml_find_closest_divisor(98, 1960) == 98
