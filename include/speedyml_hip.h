@@ -286,6 +286,12 @@ int sml_train_symmetrize(double *c_dev, int n_aug, void *stream);
 int sml_train_fit(double *c_dev, const double *b_dev, int n, int n_model, int n_out, double beta_res, double beta_model,
                   double prior_val, int using_prior, double *wout_dev, void *stream);
 
+/* Several ridge solves of equal size at once (host arrays of device pointers): up to 8 systems are kept in flight on
+ * separate streams, because a single LU is latency-bound on its one-workgroup pivot search. */
+int sml_train_fit_batched(int count, double *const *c_dev, const double *const *b_dev, int n, int n_model, int n_out,
+                          double beta_res, double beta_model, double prior_val, int using_prior, double *const *wout_dev,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ EXPORTS = [
     "sml_spectral_lap", "sml_spectral_invlap", "sml_spectral_trunct",
     "parmtr_", "inifft_", "grid_", "spec_", "vdspec_", "uvspec_", "vds_", "grad_", "lap_", "invlap_", "trunct_",
     "sml_makesparse", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",
-    "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit",
+    "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit", "sml_train_fit_batched",
 ]
 
 

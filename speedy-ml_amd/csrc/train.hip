@@ -475,20 +475,14 @@ int sml_train_symmetrize(double *c, int n_aug, void *stream)
     return SML_OK;
 }
 
-int sml_train_fit(double *c, const double *b, int n, int n_model, int n_out, double beta_res, double beta_model,
-                  double prior_val, int using_prior, double *wout, void *stream)
+// enqueue one ridge solve on `st` (no synchronisation): W, ipiv are scratch of size n_aug*(n_aug+n_out) / n_aug, info_dev one int
+static int fit_enqueue(double *c, const double *b, int n, int n_model, int n_out, double beta_res, double beta_model, double prior_val,
+                       int using_prior, double *wout, double *w, int *ipiv, int *info, hipStream_t st)
 {
-    SML_REQUIRE(c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit: bad arguments");
-    hipStream_t st = sml::as_stream(stream);
     const int n_aug = n + n_model, ncols = n_aug + n_out;
     constexpr int NB = LU_NB;
     int rc;
-    if ((rc = sml_train_symmetrize(c, n_aug, stream))) return rc;
-    double *w = nullptr;
-    int *ipiv = nullptr, *info = nullptr;
-    SML_HIP(hipMalloc((void **)&w, (size_t)n_aug * ncols * sizeof(double)));
-    SML_HIP(hipMalloc((void **)&ipiv, (size_t)n_aug * sizeof(int)));
-    SML_HIP(hipMalloc((void **)&info, sizeof(int)));
+    if ((rc = sml_train_symmetrize(c, n_aug, (void *)st))) return rc;
     SML_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
     // with a prior the betas enter squared (quirk Q8, src/mod_reservoir.f90:1271-1290)
     const double reg_model = using_prior ? beta_model * beta_model : beta_model;
@@ -525,14 +519,74 @@ int sml_train_fit(double *c, const double *b, int n, int n_model, int n_out, dou
         hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, st, w, wout, n_aug, n_out);
         if (hipGetLastError() != hipSuccess) rc = sml::fail(SML_ERR_HIP, "k_extract_wout launch failed");
     }
-    int hinfo = 0;
-    hipError_t e = hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(w); (void)hipFree(ipiv); (void)hipFree(info);
-    if (e != hipSuccess) return sml::fail(SML_ERR_HIP, "sml_train_fit: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// Several independent ridge solves at once.  One LU is latency-bound on its panel kernel (a single workgroup finds each
+// pivot), so up to FIT_STREAMS systems are kept in flight on separate streams: the panels of one system run beside the
+// trailing updates of the others.  All systems share the sizes (n, n_model, n_out); c/b/wout are host arrays of device
+// pointers.  Synchronises; returns SML_ERR_NUMERIC if any system is singular (sml_last_error names the first).
+constexpr int FIT_STREAMS = 8;
+int sml_train_fit_batched(int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res,
+                          double beta_model, double prior_val, int using_prior, double *const *wout, void *stream)
+{
+    SML_REQUIRE(count > 0 && c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit_batched: bad arguments");
+    for (int i = 0; i < count; ++i) SML_REQUIRE(c[i] && b[i] && wout[i], "sml_train_fit_batched: null system %d", i);
+    hipStream_t st = sml::as_stream(stream);
+    const int n_aug = n + n_model, ncols = n_aug + n_out;
+    const int ns = std::min(count, FIT_STREAMS);
+    std::vector<hipStream_t> streams(ns, nullptr);
+    std::vector<double *> w(ns, nullptr);
+    std::vector<int *> ipiv(ns, nullptr);
+    int *info = nullptr;
+    hipEvent_t fork = nullptr;
+    int rc = SML_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < ns; ++i) {
+            if (w[i]) (void)hipFree(w[i]);
+            if (ipiv[i]) (void)hipFree(ipiv[i]);
+            if (streams[i] && ns > 1) (void)hipStreamDestroy(streams[i]);
+        }
+        if (info) (void)hipFree(info);
+        if (fork) (void)hipEventDestroy(fork);
+    };
+#define FB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return sml::fail(SML_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    FB_HIP(hipMalloc((void **)&info, sizeof(int) * count));
+    FB_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    FB_HIP(hipEventRecord(fork, st));
+    for (int i = 0; i < ns; ++i) {
+        if (ns == 1) streams[i] = st;
+        else { FB_HIP(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking)); FB_HIP(hipStreamWaitEvent(streams[i], fork, 0)); }
+        FB_HIP(hipMalloc((void **)&w[i], (size_t)n_aug * ncols * sizeof(double)));
+        FB_HIP(hipMalloc((void **)&ipiv[i], (size_t)n_aug * sizeof(int)));
+    }
+    for (int i = 0; i < count && rc == SML_OK; ++i) {
+        const int s_ = i % ns;
+        rc = fit_enqueue(c[i], b[i], n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout[i], w[s_], ipiv[s_], info + i, streams[s_]);
+    }
+    std::vector<int> hinfo(count, 0);
+    for (int i = 0; i < ns; ++i) {
+        hipError_t e = hipStreamSynchronize(streams[i]);
+        if (e != hipSuccess && rc == SML_OK) rc = sml::fail(SML_ERR_HIP, "sml_train_fit_batched: %s", hipGetErrorString(e));
+    }
+    if (rc == SML_OK && hipMemcpy(hinfo.data(), info, sizeof(int) * count, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = sml::fail(SML_ERR_HIP, "sml_train_fit_batched: reading info failed");
+#undef FB_HIP
+    cleanup();
     if (rc) return rc;
-    if (hinfo) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", hinfo, hinfo, hinfo);
+    for (int i = 0; i < count; ++i)
+        if (hinfo[i]) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", i, hinfo[i], hinfo[i], hinfo[i]);
     return SML_OK;
+}
+
+int sml_train_fit(double *c, const double *b, int n, int n_model, int n_out, double beta_res, double beta_model,
+                  double prior_val, int using_prior, double *wout, void *stream)
+{
+    SML_REQUIRE(c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit: bad arguments");
+    double *cc[1] = {c};
+    const double *bb[1] = {b};
+    double *ww[1] = {wout};
+    return sml_train_fit_batched(1, cc, bb, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, ww, stream);
 }
 
 }  // extern "C"

@@ -35,3 +35,15 @@ def fit_chunk_hybrid(c, b, n, n_model, n_out, beta_res=0.001, beta_model=1.0, pr
     check(_lib.lib().sml_train_fit(dp(c.data_ptr()), dp(b.data_ptr()), n, n_model, n_out, C.c_double(beta_res),
                                    C.c_double(beta_model), C.c_double(prior_val), int(using_prior), dp(wout.data_ptr()), vp(stream)))
     return wout
+
+
+def fit_chunk_hybrid_batched(cs, bs, n, n_model, n_out, beta_res=0.001, beta_model=1.0, prior_val=0.0, using_prior=True, stream=None):
+    """fit_chunk_hybrid for several reservoirs of one size class at once (up to 8 LU factorisations in flight)."""
+    count = len(cs)
+    wouts = [fortran_zeros(n_out, n + n_model, device=cs[0].device) for _ in range(count)]
+    tc = (C.c_void_p * count)(*[t.data_ptr() for t in cs])
+    tb = (C.c_void_p * count)(*[t.data_ptr() for t in bs])
+    tw = (C.c_void_p * count)(*[t.data_ptr() for t in wouts])
+    check(_lib.lib().sml_train_fit_batched(count, tc, tb, n, n_model, n_out, C.c_double(beta_res), C.c_double(beta_model),
+                                           C.c_double(prior_val), int(using_prior), tw, vp(stream)))
+    return wouts

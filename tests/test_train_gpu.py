@@ -159,3 +159,20 @@ def test_device_training_pass_matches_oracle(oracle):
     # end to end: fit W_out from the device-accumulated matrices and load it back into the bank
     wout = train.fit_chunk_hybrid(cs[0], bs[0], rs[0].n, rs[0].n_model, rs[0].n_out, 1e-3, 1.0, 0.0, True)
     bank.set_wout(0, to_host(wout))
+
+
+def test_batched_fit_equals_single(oracle):
+    rng = np.random.default_rng(31)
+    n, n_model, n_out, m = 200, 8, 6, 150
+    n_aug = n + n_model
+    cs, bs = [], []
+    for i in range(11):                          # more systems than streams: scratch is reused in stream order
+        states, model, y = rng.standard_normal((n, m)), rng.standard_normal((n_model, m)), rng.standard_normal((n_out, m))
+        c, b = train.fortran_zeros(n_aug, n_aug), train.fortran_zeros(n_out, n_aug)
+        for _ in range(2):
+            train.chunking_matmul(to_dev(states), to_dev(model), to_dev(y), c, b)
+        cs.append(c); bs.append(b)
+    single = [to_host(train.fit_chunk_hybrid(c.clone(), b, n, n_model, n_out)) for c, b in zip(cs, bs)]
+    batched = train.fit_chunk_hybrid_batched(cs, bs, n, n_model, n_out)
+    for w1, w2 in zip(single, batched):
+        assert np.array_equal(w1, to_host(w2))
