@@ -65,30 +65,41 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = THREADS / 64;
-    for (int s = part * NW + wave; s < D.nslices; s += parts * NW) {
-        const int off = D.slice_off[s];
-        const int width = (D.slice_off[s + 1] - off) >> 6;
-        const int len = D.row_len[s * 64 + lane];
+    const int stride = parts * NW;
+    int s = part * NW + wave;
+    // slice metadata is fetched one slice ahead (and, for the first slice, before [x ; u] is staged), so each slice costs
+    // one exposed memory round trip (its entries) instead of two
+    int off_n = 0, end_n = 0, len_n = 0;
+    if (s < D.nslices) { off_n = D.slice_off[s]; end_n = D.slice_off[s + 1]; len_n = D.row_len[s * 64 + lane]; }
+    for (; s < D.nslices; s += stride) {
+        const int off = off_n, width = (end_n - off_n) >> 6, len = len_n;
+        if (s + stride < D.nslices) { off_n = D.slice_off[s + stride]; end_n = D.slice_off[s + stride + 1]; len_n = D.row_len[(s + stride) * 64 + lane]; }
         const int r = s * 64 + lane;                      // device position == sorted position: contiguous stores
         const unsigned short *__restrict__ cp = D.sell_col + off + lane;
         const double *__restrict__ vp = D.sell_val + off + lane;
         double acc = 0.0;
-        int j = 0;
-        // four entries per trip: the eight global loads are issued before the first LDS gather; accumulation stays in
-        // storage order (A entries in COO order, then W_in).  (Deeper software pipelining across slices and an LDS-free
-        // variant gathering x from L2 were measured slower: 0.23-0.45 ms vs 0.21 ms per 1152-reservoir launch.)
-        for (; j + 4 <= width; j += 4) {
-            const int c0 = cp[j * 64], c1 = cp[(j + 1) * 64], c2 = cp[(j + 2) * 64], c3 = cp[(j + 3) * 64];
-            const double v0 = vp[j * 64], v1 = vp[(j + 1) * 64], v2 = vp[(j + 2) * 64], v3 = vp[(j + 3) * 64];
-            if (j < len) acc += v0 * xu[c0];
-            if (j + 1 < len) acc += v1 * xu[c1];
-            if (j + 2 < len) acc += v2 * xu[c2];
-            if (j + 3 < len) acc += v3 * xu[c3];
+        // The whole row (makesparse gives 6-8 stored entries per row incl. W_in) is fetched in ONE batch of loads before
+        // the first LDS gather: PMC showed 78 % of the wave cycles parked in s_waitcnt, and a 4-wide loop plus a scalar tail
+        // exposed the memory latency four times per slice.  Accumulation stays in storage order (A in COO order, then W_in).
+        constexpr int WB = 8;
+        int cc[WB];
+        double vv[WB];
+#pragma unroll
+        for (int q = 0; q < WB; ++q) {
+            cc[q] = 0; vv[q] = 0.0;
+            if (q < width) { cc[q] = cp[q * 64]; vv[q] = vp[q * 64]; }      // width is wave-uniform
         }
-        for (; j < width; ++j) {
-            const int c = cp[j * 64];
-            const double v = vp[j * 64];
-            if (j < len) acc += v * xu[c];
+#pragma unroll
+        for (int q = 0; q < WB; ++q)
+            if (q < len) acc += vv[q] * xu[cc[q]];
+        for (int j = WB; j < width; j += 4) {                                // long rows (rare): four more per trip
+            int c4[4];
+            double v4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c4[q] = 0; v4[q] = 0.0; if (j + q < width) { c4[q] = cp[(j + q) * 64]; v4[q] = vp[(j + q) * 64]; } }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j + q < len) acc += v4[q] * xu[c4[q]];
         }
         if (r < D.n) {
             const double xt = tanh(acc);
