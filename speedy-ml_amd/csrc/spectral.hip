@@ -158,7 +158,9 @@ constexpr int MG = 4;                   // zonal wavenumbers per workgroup (forw
 constexpr int NMG = (MX + MG - 1) / MG; // 8 workgroups per field
 
 // inverse transform: vorm[32][62] -> vorg[48][96]; workgroup = (field, group of LATG latitude pairs)
-__global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos_all,
+constexpr int TG = 512;     // phase ablation: staging+launch floor 6.7 us, Legendre 2.6 us, Fourier 6.5 us at 256 threads (two
+                            // rounds of the 392 Fourier items); 512 threads do them in one round
+__global__ __launch_bounds__(TG) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos_all,
                                               const int *__restrict__ kcos_of_field)
 {
     __shared__ double sv[SPEC_N];              // spectral coefficients
@@ -171,13 +173,13 @@ __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restri
     const double *v = vorm + (size_t)f * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
     // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
-    for (int i = threadIdx.x; i < SPEC_N; i += TT) sv[i] = v[i];
+    for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = v[i];
     {
         const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
         double *pl = &sp[0][0][0];
-        for (int i = threadIdx.x; i < LATG * NX * MX; i += TT) pl[i] = pg[i];
+        for (int i = threadIdx.x; i < LATG * NX * MX; i += TG) pl[i] = pg[i];
     }
-    for (int i = threadIdx.x; i < IX; i += TT) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
+    for (int i = threadIdx.x; i < IX; i += TG) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
     if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
     __syncthreads();
     // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O.
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(TT) void k_grid(DevTables T, const double *__restri
     __syncthreads();
     // Fourier synthesis (gridx) of the 31 retained modes, two longitudes per work item: with A = sum_k Re_k cos(k i t)
     // and B = sum_k Im_k sin(k i t),  x_i = a0 + 2(A - B)  and  x_{96-i} = a0 + 2(A + B)   (i = 0..48).
-    for (int w = threadIdx.x; w < 2 * LATG * (IX / 2 + 1); w += TT) {
+    for (int w = threadIdx.x; w < 2 * LATG * (IX / 2 + 1); w += TG) {
         const int i = w % (IX / 2 + 1), r = w / (IX / 2 + 1);
         const int j = lg * LATG + (r >> 1);
         const int row = (r & 1) ? IL - 1 - j : j;
@@ -481,7 +483,7 @@ int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf
 {
     SML_REQUIRE(sp && nf >= 0 && (kcos == 1 || kcos == 2) && (nf == 0 || (vorm && vorg)), "sml_spectral_grid: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
@@ -497,7 +499,7 @@ int sml_spectral_grid_mixed(sml_spectral *sp, const double *vorm, double *vorg, 
 {
     SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg && kcos_dev)), "sml_spectral_grid_mixed: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
