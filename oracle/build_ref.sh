@@ -23,3 +23,16 @@ done
 "$FC" $FLAGS -c "$HERE/ref_spectral_driver.f90" -o ref_spectral_driver.o 2>/dev/null
 "$FC" -shared -o "$OUT/libref_spectral.so" ref_spectral_driver.o spe_spectral.o spe_subfft_fftpack.o mod_atparam.o mod_spectral.o mod_fft.o
 echo "build_ref: wrote $OUT/libref_spectral.so"
+
+# ---- dynamical-core subset (tables + spectral-space routines): pure Fortran, no dependency outside these files ----
+# dyn_step.f90 defines hordif/timint but also step(), whose calls to grtend (-> phypar, the column physics: out of scope,
+# not built) stay unresolved.  They are never called; the two references are made weak so the library loads.
+for f in mod_tsteps mod_dyncon0 mod_dyncon1 mod_dyncon2 mod_hdifcon mod_dynvar spe_matinv dyn_geop dyn_sptend dyn_implic dyn_step ini_indyns ini_impint; do
+  "$FC" $FLAGS -I"$REF" -c "$REF/$f.f90" -o "$f.o" 2>/dev/null
+done
+OBJCOPY=/opt/rocm/lib/llvm/bin/llvm-objcopy
+"$OBJCOPY" --weaken-symbol=grtend_ dyn_step.o
+"$FC" $FLAGS -c "$HERE/ref_dyn_driver.f90" -o ref_dyn_driver.o 2>/dev/null
+"$FC" -shared -o "$OUT/libref_dyn.so" ref_dyn_driver.o dyn_geop.o dyn_sptend.o dyn_implic.o dyn_step.o ini_indyns.o ini_impint.o spe_matinv.o \
+    spe_spectral.o spe_subfft_fftpack.o mod_atparam.o mod_spectral.o mod_fft.o mod_tsteps.o mod_dyncon0.o mod_dyncon1.o mod_dyncon2.o mod_hdifcon.o mod_dynvar.o
+echo "build_ref: wrote $OUT/libref_dyn.so"

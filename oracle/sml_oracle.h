@@ -10,6 +10,8 @@
  *   - domain_oracle.c   : pinned only by the reference's one usable known answer
  *                         (tests/mod_unit_test.f90:63-96, x-extent/chunk) and the reference-run facts
  *                         recorded in SURVEY.md Appendix A; otherwise PARITY UNPINNED.
+ *   - dynamics_oracle.c : tables/geop/sptend/implic/hordif/timint PINNED against oracle/_ref/libref_dyn.so (reference
+ *                         dyn_*.f90/ini_*.f90 compiled in place); grtend (needs phypar) restated, checked by invariants.
  *   - reservoir_oracle.c: PARITY UNPINNED (mod_reservoir.f90 cannot be built here without stand-ins
  *                         for MKL_SPBLAS/mpi/NetCDF); line-by-line restatement, cross-checked in
  *                         tests against an independent numpy/scipy evaluation.
@@ -141,6 +143,27 @@ int  ro_train_states(int n, int d, int k, const int32_t *rows, const int32_t *co
                      int n_model, int n_out, const double *model /* (n_model,T) */, const double *targets /* (n_out,T) */,
                      double *c /* (n_aug,n_aug) += */, double *b /* (n_out,n_aug) += */);   /* :1067-1175, Appendix D */
 int  ro_find_closest_divisor(int approx, int number);   /* mod_utilities.f90:1598-1636 */
+
+/* ---------------- SPEEDY adiabatic dynamical core (dynamics_oracle.c; src/dyn_*.f90, ini_indyns/impint.f90) ----------------
+ * Spectral 3-D arrays: Fortran a(mx,nx,kx[,2]) -> [((j*8+k)*32+n)*62+2m+ri].  PINNED pieces: tables, geop, sptend, implic,
+ * hordif, timint (against oracle/_ref/libref_dyn.so).  do_grtend_dry / do_step_dry: restated, reference routine needs phypar. */
+typedef struct do_tables do_tables;
+do_tables *do_tables_new(void);
+void do_tables_free(do_tables *t);
+void do_indyns(do_tables *d, const so_tables *s);                          /* src/ini_indyns.f90 */
+void do_impint(do_tables *d, double dt, double alph);                      /* src/ini_impint.f90 */
+void do_get_table(const do_tables *d, int which, double *out);             /* numbering of refd_get */
+void do_geop(const do_tables *d, const double *t, const double *phis, double *phi);              /* src/dyn_geop.f90 */
+void do_sptend(const do_tables *d, const so_tables *s, const double *div, const double *t, const double *ps, const double *phis,
+               double *divdt, double *tdt, double *psdt, double *phi);                         /* src/dyn_sptend.f90 */
+void do_implic(const do_tables *d, double *divdt, double *tdt, double *psdt);                    /* src/dyn_implic.f90 */
+void do_hordif(const do_tables *d, int nlev, const double *field, double *fdt, int which);       /* src/dyn_step.f90:130-150 */
+void do_timint(const so_tables *s, int j1, double dt, double eps, double wil, int nlev, double *field, double *fdt); /* :152-190 */
+void do_grtend_dry(const do_tables *d, const so_tables *s, const double *vor, const double *div, const double *t, const double *tr,
+                   const double *ps, double *vordt, double *divdt, double *tdt, double *psdt, double *trdt); /* src/dyn_grtend.f90 */
+void do_step_dry(const do_tables *d, const so_tables *s, int j1, int j2, double dt, double alph, double rob, double wil,
+                 double *vor, double *div, double *t, double *tr, double *ps, const double *phis, const double *tcorh,
+                 const double *qcorh);                                                          /* src/dyn_step.f90:1-128 */
 
 #ifdef __cplusplus
 }

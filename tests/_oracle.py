@@ -40,7 +40,7 @@ def _pi(a):
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in
-            ("spectral_oracle.c", "domain_oracle.c", "reservoir_oracle.c", "sml_oracle.h")]
+            ("spectral_oracle.c", "domain_oracle.c", "reservoir_oracle.c", "dynamics_oracle.c", "sml_oracle.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -351,3 +351,168 @@ class RefSpectral:
         a = np.array(r, dtype=np.float64).copy()
         self.lib.ref_rfftb(_p(a))
         return a
+
+
+# ---------------------------------------------------------------- SPEEDY adiabatic core (dynamics_oracle.c / libref_dyn.so)
+KX, KXP, LMAX = 8, 9, 61
+DYN_TABLES = {  # which -> (name, Fortran shape); numbering of refd_get / do_get_table
+    1: ("hsg", (KXP,)), 2: ("dhs", (KX,)), 3: ("fsg", (KX,)), 4: ("dhsr", (KX,)), 5: ("fsgr", (KX,)), 6: ("coriol", (IL,)),
+    7: ("xgeop1", (KX,)), 8: ("xgeop2", (KX,)), 9: ("dmp", (MX, NX)), 10: ("dmpd", (MX, NX)), 11: ("dmps", (MX, NX)),
+    12: ("dmp1", (MX, NX)), 13: ("dmp1d", (MX, NX)), 14: ("dmp1s", (MX, NX)), 15: ("tcorv", (KX,)), 16: ("qcorv", (KX,)),
+    17: ("tref", (KX,)), 18: ("tref1", (KX,)), 19: ("tref2", (KX,)), 20: ("tref3", (KX,)), 21: ("xc", (KX, KX)),
+    22: ("xd", (KX, KX)), 23: ("xj", (KX, KX, LMAX)), 24: ("dhsx", (KX,)), 25: ("elz", (MX, NX)), 26: ("alph", (1,)),
+}
+S3 = (MX2, NX, KX)          # one time level of a 3-D spectral array, interleaved re/im (Fortran order)
+S2 = (MX2, NX)
+
+
+def _flat(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F")).copy()
+
+
+class DynOracle:
+    """dynamics_oracle.c over an Oracle's spectral tables.  Arrays are numpy, Fortran-ordered, interleaved complex:
+    3-D (62,32,8[,2]), 2-D (62,32[,2])."""
+
+    def __init__(self, oracle=None):
+        self.o = oracle or Oracle()
+        L = self.lib = self.o.lib
+        L.do_tables_new.restype = C.c_void_p
+        L.do_indyns.argtypes = [C.c_void_p, C.c_void_p]
+        L.do_impint.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.do_get_table.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.do_geop.argtypes = [C.c_void_p] + [_dp] * 3
+        L.do_sptend.argtypes = [C.c_void_p, C.c_void_p] + [_dp] * 8
+        L.do_implic.argtypes = [C.c_void_p] + [_dp] * 3
+        L.do_hordif.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int]
+        L.do_timint.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
+        L.do_grtend_dry.argtypes = [C.c_void_p, C.c_void_p] + [_dp] * 10
+        L.do_step_dry.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 4 + [_dp] * 8
+        self.d = C.c_void_p(L.do_tables_new())
+        L.do_indyns(self.d, self.o.t)
+
+    def impint(self, dt, alph):
+        self.lib.do_impint(self.d, dt, alph)
+
+    def table(self, which):
+        name, shape = DYN_TABLES[which]
+        out = np.zeros(int(np.prod(shape)))
+        self.lib.do_get_table(self.d, which, _p(out))
+        return out.reshape(shape, order="F")
+
+    def tables(self):
+        return {DYN_TABLES[w][0]: self.table(w) for w in DYN_TABLES}
+
+    def geop(self, t, phis):
+        t, phis, phi = _flat(t), _flat(phis), np.zeros(int(np.prod(S3)))
+        self.lib.do_geop(self.d, _p(t), _p(phis), _p(phi))
+        return phi.reshape(S3, order="F")
+
+    def sptend(self, div, t, ps, phis, divdt, tdt, psdt):
+        a = [_flat(x) for x in (div, t, ps, phis, divdt, tdt, psdt)]
+        phi = np.zeros(int(np.prod(S3)))
+        self.lib.do_sptend(self.d, self.o.t, *[_p(x) for x in a], _p(phi))
+        return a[4].reshape(S3, order="F"), a[5].reshape(S3, order="F"), a[6].reshape(S2, order="F"), phi.reshape(S3, order="F")
+
+    def implic(self, divdt, tdt, psdt):
+        a = [_flat(x) for x in (divdt, tdt, psdt)]
+        self.lib.do_implic(self.d, *[_p(x) for x in a])
+        return a[0].reshape(S3, order="F"), a[1].reshape(S3, order="F"), a[2].reshape(S2, order="F")
+
+    def hordif(self, nlev, field, fdt, which):
+        f, g = _flat(field), _flat(fdt)
+        self.lib.do_hordif(self.d, nlev, _p(f), _p(g), which)
+        return g.reshape(np.shape(fdt), order="F")
+
+    def timint(self, j1, dt, eps, wil, nlev, field, fdt):
+        f, g = _flat(field), _flat(fdt)
+        self.lib.do_timint(self.o.t, j1, dt, eps, wil, nlev, _p(f), _p(g))
+        return f.reshape(np.shape(field), order="F"), g.reshape(np.shape(fdt), order="F")
+
+    def grtend_dry(self, vor, div, t, tr, ps):
+        a = [_flat(x) for x in (vor, div, t, tr, ps)]
+        outs = [np.zeros(int(np.prod(S3))), np.zeros(int(np.prod(S3))), np.zeros(int(np.prod(S3))), np.zeros(int(np.prod(S2))),
+                np.zeros(int(np.prod(S3)))]
+        self.lib.do_grtend_dry(self.d, self.o.t, *[_p(x) for x in a], *[_p(x) for x in outs])
+        shp = [S3, S3, S3, S2, S3]
+        return [o.reshape(s, order="F") for o, s in zip(outs, shp)]      # vordt, divdt, tdt, psdt, trdt
+
+    def step_dry(self, j1, j2, dt, alph, rob, wil, state, phis, tcorh, qcorh):
+        """state: dict vor/div/t/tr (62,32,8,2), ps (62,32,2); returns a new dict."""
+        keys = ("vor", "div", "t", "tr", "ps")
+        a = [_flat(state[k]) for k in keys]
+        c = [_flat(x) for x in (phis, tcorh, qcorh)]
+        self.lib.do_step_dry(self.d, self.o.t, j1, j2, dt, alph, rob, wil, *[_p(x) for x in a], *[_p(x) for x in c])
+        return {k: x.reshape(np.shape(state[k]), order="F") for k, x in zip(keys, a)}
+
+
+class RefDyn:
+    """The compiled reference dynamics subset (oracle/_ref/libref_dyn.so: ini_indyns, ini_impint, spe_matinv, dyn_geop,
+    dyn_sptend, dyn_implic, dyn_step compiled from /root/reference/src in place).  Optional."""
+
+    PATH = os.path.join(ORACLE_DIR, "_ref", "libref_dyn.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        L = self.lib = C.CDLL(self.PATH)
+        L.refd_impint.argtypes = [C.c_double, C.c_double]
+        L.refd_get.argtypes = [C.c_int, _dp, C.c_int]
+        L.refd_set_state.argtypes = [_dp] * 8
+        L.refd_get_state.argtypes = [_dp] * 6
+        L.refd_geop.argtypes = [C.c_int]
+        L.refd_sptend.argtypes = [_dp, _dp, _dp, C.c_int]
+        L.refd_implic.argtypes = [_dp, _dp, _dp]
+        L.refd_hordif.argtypes = [C.c_int, _dp, _dp, C.c_int]
+        L.refd_timint.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
+        L.refd_init()
+
+    def impint(self, dt, alph):
+        self.lib.refd_impint(dt, alph)
+
+    def table(self, which):
+        name, shape = DYN_TABLES[which]
+        n = int(np.prod(shape))
+        out = np.zeros(n)
+        self.lib.refd_get(which, _p(out), n)
+        return out.reshape(shape, order="F")
+
+    def tables(self):
+        return {DYN_TABLES[w][0]: self.table(w) for w in DYN_TABLES}
+
+    def set_state(self, vor, div, t, ps, tr, phis, tcorh=None, qcorh=None):
+        z = np.zeros(S2)
+        a = [_flat(x) for x in (vor, div, t, ps, tr, phis, z if tcorh is None else tcorh, z if qcorh is None else qcorh)]
+        self.lib.refd_set_state(*[_p(x) for x in a])
+
+    def get_state(self):
+        shp = [S3 + (2,), S3 + (2,), S3 + (2,), S2 + (2,), S3 + (2,), S3]
+        outs = [np.zeros(int(np.prod(s))) for s in shp]
+        self.lib.refd_get_state(*[_p(x) for x in outs])
+        return dict(zip(("vor", "div", "t", "ps", "tr", "phi"), [o.reshape(s, order="F") for o, s in zip(outs, shp)]))
+
+    def geop(self, jj):
+        self.lib.refd_geop(jj)
+        return self.get_state()["phi"]
+
+    def sptend(self, divdt, tdt, psdt, j4):
+        a = [_flat(x) for x in (divdt, tdt, psdt)]
+        self.lib.refd_sptend(*[_p(x) for x in a], j4)
+        return a[0].reshape(S3, order="F"), a[1].reshape(S3, order="F"), a[2].reshape(S2, order="F")
+
+    def implic(self, divdt, tdt, psdt):
+        a = [_flat(x) for x in (divdt, tdt, psdt)]
+        self.lib.refd_implic(*[_p(x) for x in a])
+        return a[0].reshape(S3, order="F"), a[1].reshape(S3, order="F"), a[2].reshape(S2, order="F")
+
+    def hordif(self, nlev, field, fdt, which):
+        f, g = _flat(field), _flat(fdt)
+        self.lib.refd_hordif(nlev, _p(f), _p(g), which)
+        return g.reshape(np.shape(fdt), order="F")
+
+    def timint(self, j1, dt, eps, wil, nlev, field, fdt):
+        f, g = _flat(field), _flat(fdt)
+        self.lib.refd_timint(j1, dt, eps, wil, nlev, _p(f), _p(g))
+        return f.reshape(np.shape(field), order="F"), g.reshape(np.shape(fdt), order="F")
