@@ -245,6 +245,40 @@ void invlap_(const double *vorm, double *strm);
 void trunct_(double *vor);
 
 /* ===================================================================================================
+ * 4a. SPEEDY adiabatic time step on the device -- replaces, inside the hybrid window between iogrid(30) and
+ *     iogrid(31), src/dyn_step.f90 (step, hordif, timint), src/dyn_grtend.f90 (without its phypar call: the column
+ *     physics is out of scope), src/dyn_sptend.f90, src/dyn_geop.f90, src/dyn_implic.f90, and the set-up routines
+ *     src/ini_indyns.f90, src/ini_impint.f90 (+ src/spe_matinv.f90), src/ini_stepone.f90, src/dyn_stloop.f90:28-43.
+ *     State (device, caller-owned): double state[2][33][32][62] = time level (mod_dynvar.f90's last index), then the
+ *     fields vor(8) | div(8) | t(8) | tr(:,:,:,1)(8) | ps, each a Fortran complex (mx,nx) array.
+ *     Tendencies: double tend[33][32][62] in the same field order.
+ * =================================================================================================== */
+typedef struct sml_dyn sml_dyn;
+/* indyns (src/ini_indyns.f90): level and diffusion tables from the spectral handle's Gaussian latitudes */
+int sml_dyn_create(sml_spectral *sp, sml_dyn **out);
+int sml_dyn_destroy(sml_dyn *dyn);
+/* impint(dt, alph) (src/ini_impint.f90): the semi-implicit tables become current for the following steps; tables of
+ * every (dt, alph) seen are kept on the device, so alternating dt (stepone) costs no upload after the first window. */
+int sml_dyn_impint(sml_dyn *dyn, double dt, double alph);
+/* host copy of a table, numbered as oracle/ref_dyn_driver.f90: 1 hsg .. 11 dmps (indyns), 12 dmp1 .. 25 elz (current
+ * impint), 26 alph */
+int sml_dyn_get_table(sml_dyn *dyn, int which, double *out_host, int capacity);
+/* phis (mod_surfcon / mod_dynvar), tcorh, qcorh (mod_hdifcon.f90:19, set by ini_fordate.f90:86,113): spectral [32][62] */
+int sml_dyn_set_boundary(sml_dyn *dyn, const double *phis_dev, const double *tcorh_dev, const double *qcorh_dev, void *stream);
+/* grtend(vordt,divdt,tdt,psdt,trdt,1,j2) without physics (src/dyn_grtend.f90): tend_dev receives the 33 tendencies */
+int sml_dyn_grtend(sml_dyn *dyn, const double *state_dev, int j2, double *tend_dev, void *stream);
+/* the rest of step() from given grid-point tendencies (src/dyn_step.f90:45-127): sptend [+ implic when alph != 0],
+ * hordif, and when dt > 0 timint on both time levels.  tend_dev is updated in place to the diffused tendencies. */
+int sml_dyn_spectral_step(sml_dyn *dyn, double *state_dev, double *tend_dev, int j1, int j2, double dt, double alph, double rob,
+                          double wil, void *stream);
+/* step(j1,j2,dt,alph,rob,wil) (src/dyn_step.f90:1-128): five launches, state updated in place */
+int sml_dyn_step(sml_dyn *dyn, double *state_dev, int j1, int j2, double dt, double alph, double rob, double wil, void *stream);
+/* start != 0: stepone (src/ini_stepone.f90: impint(delt/2), step(1,1,delt/2), impint(delt), step(1,2,delt)); then
+ * impint(2 delt) and nsteps leapfrog steps step(2,2,2 delt) (src/dyn_stloop.f90:28-43) */
+int sml_dyn_window(sml_dyn *dyn, double *state_dev, int start, int nsteps, double delt, double alph, double rob, double wil,
+                   void *stream);
+
+/* ===================================================================================================
  * 4b. reservoir construction (host, set-up time) -- replaces gen_res / makesparse / shuffle / sparse_eigen
  *     (src/mod_reservoir.f90:182-212, src/mod_linalg.f90:180-514, src/mod_utilities.f90:1569-1596)
  * =================================================================================================== */

@@ -516,3 +516,49 @@ class RefDyn:
         f, g = _flat(field), _flat(fdt)
         self.lib.refd_timint(j1, dt, eps, wil, nlev, _p(f), _p(g))
         return f.reshape(np.shape(field), order="F"), g.reshape(np.shape(fdt), order="F")
+
+
+# ---------------------------------------------------------------- the SPEEDY leg of one hybrid step, with the oracle
+def oracle_iogrid30(o, g4, logp):
+    """iogrid(30) (src/ppo_iogrid.f90:497-547): g4[z,y,x,v] (T,u,v,q), logp[y,x] -> spectral time level 1 as a dict of
+    oracle-layout arrays vor/div/t/tr (62,32,8), ps (62,32).  real(4) rounding and the q<0 clamp as in the reference."""
+    r4 = lambda a: a.astype(np.float32)
+    T, u, v, q = (r4(g4[..., i]) for i in range(4))
+    q = np.where(q < 0, np.float32(0), q)
+    out = {k: np.zeros(S3) for k in ("vor", "div", "t", "tr")}
+    for k in range(KX):
+        f = lambda a: np.asarray(a[k], dtype=np.float64).T        # [48][96] -> Fortran (ix,il)
+        vor, div = o.vdspec(f(u), f(v), 2)
+        out["vor"][..., k], out["div"][..., k] = o.trunct(vor), o.trunct(div)
+        out["t"][..., k], out["tr"][..., k] = o.trunct(o.spec(f(T))), o.trunct(o.spec(f(q)))
+    out["ps"] = o.trunct(o.spec(np.asarray(r4(logp), dtype=np.float64).T))
+    return out
+
+
+def oracle_iogrid31(o, lvl):
+    """iogrid(31) (src/ppo_iogrid.f90:579-601): spectral level-1 dict -> (F4[z,y,x,v], F2[y,x]); q floor as regrid applies it."""
+    F4 = np.zeros((KX, IL, IX, 4))
+    for k in range(KX):
+        uc, vc = o.uvspec(lvl["vor"][..., k], lvl["div"][..., k])
+        F4[k, :, :, 1] = o.grid(uc, 2).T
+        F4[k, :, :, 2] = o.grid(vc, 2).T
+        F4[k, :, :, 0] = o.grid(lvl["t"][..., k], 1).T
+        F4[k, :, :, 3] = o.grid(lvl["tr"][..., k], 1).T
+    F2 = o.grid(lvl["ps"], 1).T
+    return F4, F2
+
+
+def oracle_window(dyn, lvl1, phis, tcorh, qcorh, nsteps, delt=900.0, alph=0.5, rob=0.05, wil=0.53):
+    """stepone (istart = 2) + nsteps leapfrog steps (src/ini_stepone.f90, src/dyn_stloop.f90:28-43) from a level-1 state
+    (level 2 is whatever is passed: stepone's forward step overwrites it).  Returns the two-level state dict."""
+    two = lambda a: np.stack([a, a], axis=-1)
+    cur = {k: two(lvl1[k]) for k in ("vor", "div", "t", "tr", "ps")}
+    bc = (phis, tcorh, qcorh)
+    dyn.impint(0.5 * delt, alph)
+    cur = dyn.step_dry(1, 1, 0.5 * delt, alph, rob, wil, cur, *bc)
+    dyn.impint(delt, alph)
+    cur = dyn.step_dry(1, 2, delt, alph, rob, wil, cur, *bc)
+    dyn.impint(2 * delt, alph)
+    for _ in range(nsteps):
+        cur = dyn.step_dry(2, 2, 2 * delt, alph, rob, wil, cur, *bc)
+    return cur

@@ -55,6 +55,8 @@ def main():
         out["sptend%d_divdt" % j4], out["sptend%d_tdt" % j4], out["sptend%d_psdt" % j4] = d, t, p
     d, t, p = ref.implic(st["tend3"], st["tend3b"], st["tend2"])
     out["implic_divdt"], out["implic_tdt"], out["implic_psdt"] = d, t, p
+    d, t, p = ref.implic(*ref.sptend(st["tend3"], st["tend3b"], st["tend2"], 1))      # as step() chains them (dyn_step.f90:52-56)
+    out["chain_divdt"], out["chain_tdt"], out["chain_psdt"] = d, t, p
     for which in (1, 2, 3):
         for nlev in (8, 1):
             out["hordif%d_%d" % (which, nlev)] = ref.hordif(nlev, st["vor"][..., 0], st["tend3"], which)

@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_dir):
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
     regions = [int(r) for r in domain.processor_decomposition_manual(rank, world, NREG)]
-    m = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode="hybrid", n_override=1, replay_steps=0)
+    m = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2)
     stream = torch.cuda.current_stream()
     for _ in range(2):
         m.step(stream)
@@ -49,7 +49,7 @@ def test_two_ranks_equal_one_rank(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
-    single = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1, replay_steps=0)
+    single = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2)
     stream = torch.cuda.current_stream()
     for _ in range(2):
         single.step(stream)

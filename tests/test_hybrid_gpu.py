@@ -1,5 +1,6 @@
-"""GPU: the device-resident hybrid step (predict -> scatter+clamps -> SPEEDY hand-off -> gather+standardise) against the
-CPU oracle, stage by stage with identical inputs (the hybrid trajectory is chaotic, parity is per step).
+"""GPU: the device-resident hybrid step (predict -> scatter+clamps -> iogrid(30) -> SPEEDY 6-hour window -> iogrid(31) ->
+gather+standardise) against the CPU oracle, stage by stage with identical inputs (the hybrid trajectory is chaotic,
+parity is per step).
 
 All 1152 regions take part (full index maps, polar / periodic / land classes); the reservoirs are small (n = d) so
 that the oracle's 1152 predicts stay cheap -- full-size reservoirs are covered by tests/test_reservoir_gpu.py."""
@@ -17,37 +18,23 @@ NREG = 1152
 def model():
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
-    m = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1, replay_steps=1)
+    m = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1)
     m.classes_ = classes
     return m
 
 
-def oracle_handoff(o, G):
-    """iogrid(30) + iogrid(31) (src/ppo_iogrid.f90:497-601) with the oracle's transforms."""
+def oracle_speedy_leg(o, m, G):
+    """iogrid(30), stepone + 24 leapfrog steps, iogrid(31) with the oracle, from the device's hybrid state G."""
+    from _oracle import DynOracle, oracle_iogrid30, oracle_iogrid31, oracle_window
     g4 = G[:domain.G2_OFF].reshape(8, 48, 96, 4)
     logp = G[domain.G2_OFF:domain.GP_OFF].reshape(48, 96)
-    r4 = lambda a: a.astype(np.float32)
-    T, u, v, q = (r4(g4[..., i]) for i in range(4))
-    q = np.where(q < 0, np.float32(0), q)
-    ps = r4(logp)
-    F4 = np.zeros_like(g4)
-    spec_state = {}
-    for k in range(8):
-        f = lambda a: np.asarray(a[k], dtype=np.float64).T        # [48][96] -> Fortran (ix,il)
-        vor, div = o.vdspec(f(u), f(v), 2)
-        t_s, q_s = o.spec(f(T)), o.spec(f(q))
-        vor, div, t_s, q_s = (o.trunct(a) for a in (vor, div, t_s, q_s))
-        uc, vc = o.uvspec(vor, div)
-        F4[k, :, :, 1] = o.grid(uc, 2).T
-        F4[k, :, :, 2] = o.grid(vc, 2).T
-        F4[k, :, :, 0] = o.grid(t_s, 1).T
-        F4[k, :, :, 3] = o.grid(q_s, 1).T
-        spec_state[k] = (t_s, vor, div, q_s)
-    ps_s = o.trunct(o.spec(np.asarray(ps, dtype=np.float64).T))
-    F2 = o.grid(ps_s, 1).T
+    lvl = oracle_iogrid30(o, g4, logp)
+    sp2 = lambda t: t.cpu().numpy().T
+    cur = oracle_window(DynOracle(o), lvl, sp2(m.phis), sp2(m.tcorh), sp2(m.qcorh), m.leapfrog_steps)
+    F4, F2 = oracle_iogrid31(o, {k: cur[k][..., 0] for k in cur})
     qv = F4[..., 3]
     qv[qv < 0.000001] = 0.000001
-    return F4, F2, spec_state, ps_s
+    return F4, F2
 
 
 def test_hybrid_step_stage_parity(model, oracle):
@@ -84,15 +71,17 @@ def test_hybrid_step_stage_parity(model, oracle):
     scale = np.maximum(np.abs(want), 1.0)
     assert np.max(np.abs(got - want) / scale) <= 1e-11
 
-    # ---- stage B: SPEEDY hand-off transforms, oracle fed with the device's G ----
-    F4w, F2w, _, _ = oracle_handoff(o, G)
+    # ---- stage B: the SPEEDY leg (hand-off in, 26 adiabatic time steps, hand-off out), oracle fed with the device's G.
+    # north_star tolerance: 1e-10 relative per field after the 6-hour window
+    F4w, F2w = oracle_speedy_leg(o, m, G)
     F4g = F[:domain.G2_OFF].reshape(8, 48, 96, 4)
     for var in range(4):
         sc = np.max(np.abs(F4w[..., var]))
-        assert np.max(np.abs(F4g[..., var] - F4w[..., var])) <= 1e-11 * sc, var
-    assert np.max(np.abs(F[domain.G2_OFF:domain.GP_OFF].reshape(48, 96) - F2w)) <= 1e-11 * np.max(np.abs(F2w))
-    # (random synthetic W_out gives unphysical states, so the range guard trips here; it is tested on its own below)
-    assert int(m.safe.item()) in (0, 1)
+        assert np.max(np.abs(F4g[..., var] - F4w[..., var])) <= 1e-10 * sc, (var, np.max(np.abs(F4g[..., var] - F4w[..., var])) / sc)
+    assert np.max(np.abs(F[domain.G2_OFF:domain.GP_OFF].reshape(48, 96) - F2w)) <= 1e-10 * np.max(np.abs(F2w))
+    # the synthetic climate is physical: the range guard of iogrid(30) must not trip, and the forecast differs from the input
+    assert int(m.safe.item()) == 1
+    assert np.max(np.abs(F4g[..., 1] - G[:domain.G2_OFF].reshape(8, 48, 96, 4)[..., 1])) > 0.5
 
     # ---- stage C: next inputs, oracle tilers fed with the device's G and F: bit-exact ----
     fb1 = m.feedback.cpu().numpy()
@@ -140,11 +129,15 @@ def test_safety_guard_trips(model):
         assert int(safe.item()) == expect, (f, val)
 
 
-def test_hybrid_steps_stay_finite(model):
+def test_hybrid_closed_loop_stays_physical(model):
+    """Two days of closed-loop hybrid steps: states stay finite and inside iogrid(30)'s physical-range guard."""
     m = model
     stream = torch.cuda.current_stream()
-    for _ in range(3):
+    for _ in range(8):
         m.step(stream)
     torch.cuda.synchronize()
     assert torch.isfinite(m.G).all() and torch.isfinite(m.F[:domain.GP_OFF]).all()
     assert torch.isfinite(m.feedback).all() and torch.isfinite(m.outvec).all()
+    assert int(m.safe.item()) == 1
+    T = m.F[:domain.G2_OFF].reshape(8, 48, 96, 4)[..., 0]
+    assert 180.0 < float(T.min()) and float(T.max()) < 320.0

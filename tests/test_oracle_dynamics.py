@@ -56,6 +56,9 @@ def test_spectral_routines_match_reference(dyn, gold):
         assert rel(p, gold["sptend%d_psdt" % j4]) < 1e-14
     d, t, p = dyn.implic(st["tend3"], st["tend3b"], st["tend2"])
     assert rel(d, gold["implic_divdt"]) < 1e-14 and rel(t, gold["implic_tdt"]) < 1e-14 and rel(p, gold["implic_psdt"]) < 1e-14
+    d, t, p, _ = dyn.sptend(st["div"][..., 0], st["t"][..., 0], st["ps"][..., 0], st["phis"], st["tend3"], st["tend3b"], st["tend2"])
+    d, t, p = dyn.implic(d, t, p)
+    assert rel(d, gold["chain_divdt"]) < 1e-14 and rel(t, gold["chain_tdt"]) < 1e-14 and rel(p, gold["chain_psdt"]) < 1e-14
     for which in (1, 2, 3):
         for nlev in (8, 1):
             assert rel(dyn.hordif(nlev, st["vor"][..., 0], st["tend3"], which), gold["hordif%d_%d" % (which, nlev)]) < 1e-15
