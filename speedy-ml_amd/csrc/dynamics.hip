@@ -63,7 +63,7 @@ struct ImpSlot {                   // impint(dt, alph)
     double tref[KX], tref1[KX], tref2[KX], tref3[KX], dhsx[KX];
     double xc[KX][KX], xd[KX][KX], xj[LMAX][KX][KX];       // Fortran x(k,k1) -> x[k1][k]
     double *d_h = nullptr;         // device: dmp1 | dmp1d | dmp1s | elz   (4 x 992)
-    double *d_x = nullptr;         // device: xd(64) | xc(64) | xj(61*64)
+    double *d_x = nullptr;         // device: xd(64) | xc(64) | xj(61*64) | level tables (12 x 8, rows LV_*)
     LevelTables lv;
 };
 
@@ -379,10 +379,18 @@ struct StepArgs {
     double dt, eps, wil;
 };
 
-// k_spectral: the whole spectral-space part of step() for one coefficient (n, c) and all 8 levels.
+// k_spectral: the whole spectral-space part of step().  One 64-thread workgroup = 8 spectral coefficients x 8 levels
+// (248 workgroups): a thread owns one (coefficient, level) and the vertical couplings -- the column means and running
+// sums of sptend, the hydrostatic integration of geop, the three 8x8 mat-vecs of implic -- go through LDS.  Every thread
+// re-derives the running sums it needs in the reference's order (a handful of LDS-broadcast operands), so the arithmetic
+// is the same sequence of operations as the Fortran column loops; a first version with one thread per coefficient
+// walking its column serially took 47 us per launch (31 waves, ~250 dependent global loads each), this one 7 us.
 //   FROM_FLUX = true : tendencies start from the forward batch S[73] (dyn_grtend.f90:232-288)
-//   FROM_FLUX = false: tendencies are read from tend[33] (testing entry point sml_dyn_spectral_step)
+//   FROM_FLUX = false: tendencies are read from tend_in[33] (testing entry point sml_dyn_spectral_step)
 //   tend_out (optional): the tendencies after sptend/implic/hordif, [vordt(8) | divdt(8) | tdt(8) | trdt(8) | psdt]
+constexpr int LV_DHS = 0, LV_DHSR = 1, LV_XG1 = 2, LV_XG2 = 3, LV_TCORV = 4, LV_QCORV = 5, LV_TREF = 6, LV_TREF1 = 7, LV_TREF2 = 8,
+              LV_TREF3 = 9, LV_DHSX = 10, LV_CORF = 11, LV_ROWS = 12;
+
 template <bool FROM_FLUX>
 __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, StepArgs a, const double *__restrict__ S,
                                                   const double *tend_in, double *tend_out, int stop_after_grtend,
@@ -390,134 +398,126 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
                                                   const double *__restrict__ imp_x, const double *__restrict__ phis,
                                                   const double *__restrict__ tcorh, const double *__restrict__ qcorh)
 {
-    const int e = blockIdx.x * 64 + threadIdx.x;
-    if (e >= SP) return;
+    __shared__ double lv[LV_ROWS][KX];          // level tables, indexed by a lane-varying level
+    __shared__ double xdc[2][KX * KX];          // xd, xc
+    __shared__ double d4[KX][8], t4[KX][8];     // div and t of time level j4, [level][coefficient]
+    __shared__ double tds[KX][8], yfs[KX][8], dvs[KX][8];
+    const int tid = threadIdx.x, ci = tid & 7, k = tid >> 3;
+    const int e = blockIdx.x * 8 + ci;
     const int c = e % MX2, n = e / MX2, m = c >> 1, hm = n * MX + m;
-    double vordt[KX], divdt[KX], tdt[KX], trdt[KX], psdt;
+    {   // level tables (indexed by a lane-varying level below) and the two dense 8x8 matrices -> LDS
+        const double *lvg = imp_x + 128 + LMAX * 64;
+        double *lvf = &lv[0][0];
+        for (int i = tid; i < LV_ROWS * KX; i += 64) lvf[i] = lvg[i];
+        xdc[0][tid] = imp_x[tid];
+        xdc[1][tid] = imp_x[64 + tid];
+    }
+    double vordt, divdt, tdt, trdt, psdt;
     if (FROM_FLUX) {
         const double gx = H.gradx[m], ym = H.vddym[hm], yp = H.vddyp[hm], el2 = H.el2[hm];
-#pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            double dummy;
-            stencil(S + (size_t)k * SP, S + (size_t)(8 + k) * SP, n, c, gx, ym, yp, vordt[k], divdt[k]);
-            const double lapke = -S[(size_t)(48 + k) * SP + e] * el2;
-            divdt[k] = divdt[k] - lapke;
-            stencil(S + (size_t)(16 + k) * SP, S + (size_t)(24 + k) * SP, n, c, gx, ym, yp, dummy, tdt[k]);
-            tdt[k] = tdt[k] + S[(size_t)(56 + k) * SP + e];
-            stencil(S + (size_t)(32 + k) * SP, S + (size_t)(40 + k) * SP, n, c, gx, ym, yp, dummy, trdt[k]);
-            trdt[k] = trdt[k] + S[(size_t)(64 + k) * SP + e];
-        }
+        double dummy;
+        stencil(S + (size_t)k * SP, S + (size_t)(8 + k) * SP, n, c, gx, ym, yp, vordt, divdt);
+        const double lapke = -S[(size_t)(48 + k) * SP + e] * el2;
+        divdt = divdt - lapke;
+        stencil(S + (size_t)(16 + k) * SP, S + (size_t)(24 + k) * SP, n, c, gx, ym, yp, dummy, tdt);
+        tdt = tdt + S[(size_t)(56 + k) * SP + e];
+        stencil(S + (size_t)(32 + k) * SP, S + (size_t)(40 + k) * SP, n, c, gx, ym, yp, dummy, trdt);
+        trdt = trdt + S[(size_t)(64 + k) * SP + e];
         psdt = S[(size_t)72 * SP + e];
         if (e < 2) psdt = 0.;
     } else {
-#pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            vordt[k] = tend_in[(size_t)(F_VOR + k) * SP + e];
-            divdt[k] = tend_in[(size_t)(F_DIV + k) * SP + e];
-            tdt[k] = tend_in[(size_t)(F_T + k) * SP + e];
-            trdt[k] = tend_in[(size_t)(F_TR + k) * SP + e];
-        }
+        vordt = tend_in[(size_t)(F_VOR + k) * SP + e];
+        divdt = tend_in[(size_t)(F_DIV + k) * SP + e];
+        tdt = tend_in[(size_t)(F_T + k) * SP + e];
+        trdt = tend_in[(size_t)(F_TR + k) * SP + e];
         psdt = tend_in[(size_t)F_PS * SP + e];
     }
     double *s1 = state, *s2 = state + (size_t)NSTATE * SP;
     if (!stop_after_grtend) {
         // ---- sptend (src/dyn_sptend.f90) on time level j4
         const double *s4 = a.j4 == 1 ? s1 : s2;
-        double div4[KX], t4[KX], sig[KXP], dumk[KXP];
-#pragma unroll
-        for (int k = 0; k < KX; ++k) { div4[k] = s4[(size_t)(F_DIV + k) * SP + e]; t4[k] = s4[(size_t)(F_T + k) * SP + e]; }
+        d4[k][ci] = s4[(size_t)(F_DIV + k) * SP + e];
+        t4[k][ci] = s4[(size_t)(F_T + k) * SP + e];
         const double ps4 = s4[(size_t)F_PS * SP + e];
+        const double el2 = H.el2[hm];
+        __syncthreads();
         double dmeanc = 0.0;
 #pragma unroll
-        for (int k = 0; k < KX; ++k) dmeanc = dmeanc + div4[k] * L.dhs[k];
+        for (int j = 0; j < KX; ++j) dmeanc = dmeanc + d4[j][ci] * lv[LV_DHS][j];
         psdt = psdt - dmeanc;
         if (e < 2) psdt = 0.;
-        sig[0] = 0.0; sig[KX] = 0.0; dumk[0] = 0.0; dumk[KX] = 0.0;
+        // sigdtc(k), sigdtc(k+1) (1-based interfaces k and k+1 of this level): running sum from the top, zero at both ends
+        double sg = 0.0, sig_k = 0.0, sig_k1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < KX - 1; ++k) sig[k + 1] = sig[k] - L.dhs[k] * (div4[k] - dmeanc);
-#pragma unroll
-        for (int k = 1; k < KX; ++k) dumk[k] = sig[k] * (L.tref[k] - L.tref[k - 1]);
-#pragma unroll
-        for (int k = 0; k < KX; ++k)
-            tdt[k] = tdt[k] - (dumk[k + 1] + dumk[k]) * L.dhsr[k] + L.tref3[k] * (sig[k + 1] + sig[k]) - L.tref2[k] * dmeanc;
-        // geop (src/dyn_geop.f90)
-        double phi[KX];
-        phi[KX - 1] = phis[e] + L.xgeop1[KX - 1] * t4[KX - 1];
-#pragma unroll
-        for (int k = KX - 2; k >= 0; --k) phi[k] = phi[k + 1] + L.xgeop2[k + 1] * t4[k + 1] + L.xgeop1[k] * t4[k];
-        if (c < 2) {
-#pragma unroll
-            for (int k = 1; k < KX - 1; ++k) phi[k] = phi[k] + L.corf[k] * (t4[k + 1] - t4[k - 1]);
+        for (int j = 0; j < KX - 1; ++j) {
+            sg = sg - lv[LV_DHS][j] * (d4[j][ci] - dmeanc);
+            if (j + 1 == k) sig_k = sg;
+            if (j == k) sig_k1 = sg;
         }
-        const double el2 = H.el2[hm];
+        const double dumk_k = k > 0 ? sig_k * (lv[LV_TREF][k] - lv[LV_TREF][k > 0 ? k - 1 : 0]) : 0.0;
+        const double dumk_k1 = k < KX - 1 ? sig_k1 * (lv[LV_TREF][k < KX - 1 ? k + 1 : k] - lv[LV_TREF][k]) : 0.0;
+        tdt = tdt - (dumk_k1 + dumk_k) * lv[LV_DHSR][k] + lv[LV_TREF3][k] * (sig_k1 + sig_k) - lv[LV_TREF2][k] * dmeanc;
+        // geop (src/dyn_geop.f90): hydrostatic integration from the surface up to this level
+        double phi = phis[e] + lv[LV_XG1][KX - 1] * t4[KX - 1][ci];
 #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            const double d1 = phi[k] + L.tref1[k] * ps4;
-            const double d2 = -d1 * el2;
-            divdt[k] = divdt[k] - d2;
+        for (int j = KX - 2; j >= 0; --j)
+            if (j >= k) phi = phi + lv[LV_XG2][j + 1] * t4[j + 1][ci] + lv[LV_XG1][j] * t4[j][ci];
+        if (c < 2 && k >= 1 && k <= KX - 2) phi = phi + lv[LV_CORF][k] * (t4[k + 1][ci] - t4[k - 1][ci]);
+        {
+            const double g1 = phi + lv[LV_TREF1][k] * ps4;
+            const double g2 = -g1 * el2;
+            divdt = divdt - g2;
         }
         // ---- implic (src/dyn_implic.f90)
         if (a.implicit) {
-            const double *xd = imp_x, *xc = imp_x + 64, *xj = imp_x + 128;
             const double elz = imp_h[3 * NX * MX + hm];
-            double ye[KX], yf[KX];
-#pragma unroll
-            for (int k = 0; k < KX; ++k) ye[k] = 0.;
-#pragma unroll
-            for (int k1 = 0; k1 < KX; ++k1)
-#pragma unroll
-                for (int k = 0; k < KX; ++k) ye[k] = ye[k] + xd[k1 * KX + k] * tdt[k1];
-#pragma unroll
-            for (int k = 0; k < KX; ++k) ye[k] = ye[k] + L.tref1[k] * psdt;
-#pragma unroll
-            for (int k = 0; k < KX; ++k) { yf[k] = divdt[k] + elz * ye[k]; divdt[k] = 0.; }
             const int ll = m + n;
+            double xl[KX];
+#pragma unroll
+            for (int k1 = 0; k1 < KX; ++k1) xl[k1] = ll != 0 ? imp_x[128 + (size_t)(ll - 1) * 64 + k1 * KX + k] : 0.0;
+            tds[k][ci] = tdt;
+            __syncthreads();
+            double ye = 0.;
+#pragma unroll
+            for (int k1 = 0; k1 < KX; ++k1) ye = ye + xdc[0][k1 * KX + k] * tds[k1][ci];
+            ye = ye + lv[LV_TREF1][k] * psdt;
+            yfs[k][ci] = divdt + elz * ye;
+            __syncthreads();
+            divdt = 0.;
             if (ll != 0) {
-                const double *xl = xj + (size_t)(ll - 1) * 64;
 #pragma unroll
-                for (int k1 = 0; k1 < KX; ++k1)
-#pragma unroll
-                    for (int k = 0; k < KX; ++k) divdt[k] = divdt[k] + xl[k1 * KX + k] * yf[k1];
+                for (int k1 = 0; k1 < KX; ++k1) divdt = divdt + xl[k1] * yfs[k1][ci];
             }
+            dvs[k][ci] = divdt;
+            __syncthreads();
 #pragma unroll
-            for (int k = 0; k < KX; ++k) psdt = psdt - divdt[k] * L.dhsx[k];
+            for (int j = 0; j < KX; ++j) psdt = psdt - dvs[j][ci] * lv[LV_DHSX][j];
 #pragma unroll
-            for (int k = 0; k < KX; ++k)
-#pragma unroll
-                for (int k1 = 0; k1 < KX; ++k1) tdt[k] = tdt[k] + xc[k1 * KX + k] * divdt[k1];
+            for (int k1 = 0; k1 < KX; ++k1) tdt = tdt + xdc[1][k1 * KX + k] * dvs[k1][ci];
         }
         // ---- horizontal diffusion (src/dyn_step.f90:60-104, hordif :130-150), always on time level 1
         const double dmp = H.dmp[hm], dmpd = H.dmpd[hm], dmps = H.dmps[hm];
         const double dmp1 = imp_h[hm], dmp1d = imp_h[NX * MX + hm], dmp1s = imp_h[2 * NX * MX + hm];
-        const double tch = tcorh[e], qch = qcorh[e];
-        double ct0 = 0.;
-#pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            const double v1 = s1[(size_t)(F_VOR + k) * SP + e], d1 = s1[(size_t)(F_DIV + k) * SP + e];
-            const double ct = s1[(size_t)(F_T + k) * SP + e] + tch * L.tcorv[k];
-            const double cq = s1[(size_t)(F_TR + k) * SP + e] + qch * L.qcorv[k];
-            vordt[k] = (vordt[k] - dmp * v1) * dmp1;
-            divdt[k] = (divdt[k] - dmpd * d1) * dmp1d;
-            tdt[k] = (tdt[k] - dmp * ct) * dmp1;
-            trdt[k] = (trdt[k] - dmpd * cq) * dmp1d;
-            if (k == 0) {
-                if (c < 2) { vordt[0] = vordt[0] - L.sdrag * v1; divdt[0] = divdt[0] - L.sdrag * d1; }
-                vordt[0] = (vordt[0] - dmps * v1) * dmp1s;
-                divdt[0] = (divdt[0] - dmps * d1) * dmp1s;
-                ct0 = ct;
-                tdt[0] = (tdt[0] - dmps * ct0) * dmp1s;
-            }
+        const double v1 = s1[(size_t)(F_VOR + k) * SP + e], d1 = s1[(size_t)(F_DIV + k) * SP + e];
+        const double ct = s1[(size_t)(F_T + k) * SP + e] + tcorh[e] * lv[LV_TCORV][k];
+        const double cq = s1[(size_t)(F_TR + k) * SP + e] + qcorh[e] * lv[LV_QCORV][k];
+        vordt = (vordt - dmp * v1) * dmp1;
+        divdt = (divdt - dmpd * d1) * dmp1d;
+        tdt = (tdt - dmp * ct) * dmp1;
+        trdt = (trdt - dmpd * cq) * dmp1d;
+        if (k == 0) {
+            if (c < 2) { vordt = vordt - L.sdrag * v1; divdt = divdt - L.sdrag * d1; }
+            vordt = (vordt - dmps * v1) * dmp1s;
+            divdt = (divdt - dmps * d1) * dmp1s;
+            tdt = (tdt - dmps * ct) * dmp1s;
         }
     }
     if (tend_out) {
-#pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            tend_out[(size_t)(F_VOR + k) * SP + e] = vordt[k];
-            tend_out[(size_t)(F_DIV + k) * SP + e] = divdt[k];
-            tend_out[(size_t)(F_T + k) * SP + e] = tdt[k];
-            tend_out[(size_t)(F_TR + k) * SP + e] = trdt[k];
-        }
-        tend_out[(size_t)F_PS * SP + e] = psdt;
+        tend_out[(size_t)(F_VOR + k) * SP + e] = vordt;
+        tend_out[(size_t)(F_DIV + k) * SP + e] = divdt;
+        tend_out[(size_t)(F_T + k) * SP + e] = tdt;
+        tend_out[(size_t)(F_TR + k) * SP + e] = trdt;
+        if (k == 0) tend_out[(size_t)F_PS * SP + e] = psdt;
     }
     if (stop_after_grtend || !a.integrate) return;
     // ---- timint (src/dyn_step.f90:152-190): truncation, leapfrog, Robert-Asselin-Williams filter, both levels in place
@@ -533,14 +533,13 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
         s1[o] = n1;
         s2[o] = fnew - (1 - a.wil) * a.eps * (n1 - 2 * fj_after + fnew);
     };
-    timint(F_PS, psdt);
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        timint(F_VOR + k, vordt[k]);
-        timint(F_DIV + k, divdt[k]);
-        timint(F_T + k, tdt[k]);
-        timint(F_TR + k, trdt[k]);
-    }
+    // every level-thread of a coefficient has read its time-level-1 diffusion operands above; a column's ps is only
+    // touched by its k == 0 thread
+    timint(F_VOR + k, vordt);
+    timint(F_DIV + k, divdt);
+    timint(F_T + k, tdt);
+    timint(F_TR + k, trdt);
+    if (k == 0) timint(F_PS, psdt);
 }
 
 }  // namespace
@@ -591,7 +590,7 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
     SML_HIP(hipGetLastError());
     rc = sml_spectral_spec_mixed(d->sp, d->tend_grid, d->tend_spec, NB_GRID, d->scale, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_spectral<true>, dim3(SP / 64), dim3(64), 0, st, d->d, d->cur->lv, a, d->tend_spec, (const double *)nullptr,
+    hipLaunchKernelGGL(k_spectral<true>, dim3(SP / 8), dim3(64), 0, st, d->d, d->cur->lv, a, d->tend_spec, (const double *)nullptr,
                        tend_out, stop_after_grtend, state, d->cur->d_h, d->cur->d_x, d->bc, d->bc + SP, d->bc + 2 * SP);
     SML_HIP(hipGetLastError());
     return SML_OK;
@@ -677,7 +676,7 @@ int sml_dyn_impint(sml_dyn *d, double dt, double alph)
         if (s->dt == dt && s->alph == alph) { d->cur = s; return SML_OK; }
     ImpSlot *s = new ImpSlot;
     build_impint(*s, d->h, dt, alph);
-    std::vector<double> hh((size_t)4 * NX * MX), xx((size_t)128 + LMAX * 64);
+    std::vector<double> hh((size_t)4 * NX * MX), xx((size_t)128 + LMAX * 64 + 12 * KX);
     memcpy(&hh[0], s->dmp1, sizeof s->dmp1);
     memcpy(&hh[NX * MX], s->dmp1d, sizeof s->dmp1d);
     memcpy(&hh[2 * NX * MX], s->dmp1s, sizeof s->dmp1s);
@@ -685,6 +684,11 @@ int sml_dyn_impint(sml_dyn *d, double dt, double alph)
     memcpy(&xx[0], s->xd, sizeof s->xd);
     memcpy(&xx[64], s->xc, sizeof s->xc);
     memcpy(&xx[128], s->xj, sizeof s->xj);
+    {
+        const LevelTables &lv = s->lv;
+        const double *rows[12] = {lv.dhs, lv.dhsr, lv.xgeop1, lv.xgeop2, lv.tcorv, lv.qcorv, lv.tref, lv.tref1, lv.tref2, lv.tref3, lv.dhsx, lv.corf};
+        for (int r = 0; r < 12; ++r) memcpy(&xx[128 + LMAX * 64 + r * KX], rows[r], KX * sizeof(double));   // order = LV_* in k_spectral
+    }
     int rc = sml::dev_upload(&s->d_h, hh.data(), hh.size());
     if (!rc) rc = sml::dev_upload(&s->d_x, xx.data(), xx.size());
     if (rc) { if (s->d_h) (void)hipFree(s->d_h); delete s; return rc; }
@@ -749,7 +753,7 @@ int sml_dyn_spectral_step(sml_dyn *d, double *state_dev, double *tend_dev, int j
     SML_REQUIRE(d && state_dev && tend_dev && (j1 == 1 || j1 == 2) && (j2 == 1 || j2 == 2), "sml_dyn_spectral_step: bad arguments");
     SML_REQUIRE(d->cur, "sml_dyn_spectral_step: call sml_dyn_impint first");
     StepArgs a = make_args(j1, j2, dt, alph, rob, wil);
-    hipLaunchKernelGGL(k_spectral<false>, dim3(SP / 64), dim3(64), 0, sml::as_stream(stream), d->d, d->cur->lv, a, (const double *)nullptr,
+    hipLaunchKernelGGL(k_spectral<false>, dim3(SP / 8), dim3(64), 0, sml::as_stream(stream), d->d, d->cur->lv, a, (const double *)nullptr,
                        (const double *)tend_dev, tend_dev, 0, state_dev, d->cur->d_h, d->cur->d_x, d->bc, d->bc + SP, d->bc + 2 * SP);
     SML_HIP(hipGetLastError());
     return SML_OK;
