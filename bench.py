@@ -69,7 +69,11 @@ def main():
     if args.regions < len(regions):
         regions = regions[:args.regions]
     t0 = time.time()
-    model = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode=args.mode)
+    # SML_PIPELINE=1 selects the software-pipelined schedule (readout state block under the SPEEDY window, DESIGN.md
+    # "Software pipeline"): measured +6 % only, because the latency-bound SPEEDY kernels slow down 2x next to an
+    # HBM-saturating stream; the default is the reference's sequential order.
+    model = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode=args.mode,
+                              pipeline=os.environ.get("SML_PIPELINE", "0") == "1")
     if rank == 0:
         print(f"[bench] rank0 loaded {len(regions)} reservoirs in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
 

@@ -156,9 +156,21 @@ int sml_bank_predict_one(sml_bank *bank, int slot, double *x_inout_host, const d
 int sml_bank_synchronize_all(sml_bank *bank, const double *inputs_dev, int length, void *stream);
 /* one advance without readout (K1-K3) for every slot, feedback taken from the bank */
 int sml_bank_advance_all(sml_bank *bank, void *stream);
+/* The readout product of predict (src/mod_reservoir.f90:1450-1471) in two column blocks, because in the hybrid loop the
+ * reservoir state is known a whole SPEEDY window before the forecast is (DESIGN.md "Software pipeline"):
+ *   part 1: W_out[:, n_model:] x~  (99 % of the bytes) -> an internal buffer, needs only the advanced state;
+ *   part 2: + W_out[:, :n_model] local_model, un-standardise -> outvec.  part 1 then part 2 == the readout of
+ * sml_bank_predict_all up to the association of the column sum.  flags: bit0 as for sml_bank_predict_all.
+ * Part 1 only: bit3 (8) runs the block as a persistent work-queue kernel with a bounded footprint (one 8-wave workgroup
+ * per CU, <= 128 VGPRs, no LDS) that leaves room for kernels of other streams -- use it when part 1 is overlapped with
+ * the SPEEDY window; bit4 (16) launches a full-occupancy kernel that drains the SAME work queue (call it, on any stream,
+ * once the overlapped work is done; part 1 is complete when both launches have finished). */
+int sml_bank_readout_part(sml_bank *bank, int part, int flags, void *stream);
 
 /* byte accounting for the roofline (algorithmic bytes as defined in DESIGN.md) */
 int sml_bank_algorithmic_bytes(sml_bank *bank, uint64_t *update_bytes, uint64_t *readout_bytes);
+/* the same accounting for one column block of sml_bank_readout_part (the partial sums count as traffic of both parts) */
+int sml_bank_readout_part_bytes(sml_bank *bank, int part, uint64_t *bytes);
 /* Per-kernel timing with HIP events recorded on the launch stream (for bench.py's roofline block).
  * enable!=0 starts recording an event pair around every k_update / k_readout launch; collect synchronises the
  * recorded events, returns the summed milliseconds and launch counts since the last collect, and clears them. */
@@ -182,6 +194,7 @@ int sml_exchange_scatter(sml_exchange *ex, const double *all_outvec_dev, double 
                          void *stream);
 /* G (+ current TISR slice already in G) -> standardised feedback of every slot; forecast F (same layout as the
  * first two parts of G) -> standardised local_model of every slot (Appendix G 5-6, src/mpires.f90:580-775). */
+/* Either pointer may be NULL to skip that half (the feedback is available before the forecast is). */
 int sml_exchange_gather(sml_exchange *ex, const double *g_dev, const double *f_dev, void *stream);
 /* where each slot's outvec goes in the region-ordered slab: offset = region*max_n_out */
 int sml_exchange_pack_outvec(sml_exchange *ex, double *all_outvec_dev, void *stream);

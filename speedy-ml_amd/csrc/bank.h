@@ -37,7 +37,8 @@ struct sml_bank {
     int max_n_out_loaded = 1;       // largest n_out among loaded slots (sizes the readout grid)
     std::vector<sml::HostRes> res;
     sml::ResDesc *d_descs = nullptr;
-    double *d_feedback = nullptr, *d_local_model = nullptr, *d_outvec = nullptr;
+    double *d_feedback = nullptr, *d_local_model = nullptr, *d_outvec = nullptr, *d_partial = nullptr;
+    unsigned *d_counter = nullptr;     // work counter of the persistent readout
     bool descs_dirty = true;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_readout;

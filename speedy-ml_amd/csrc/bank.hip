@@ -146,8 +146,11 @@ __device__ __forceinline__ double wave_sum(double v)
 template <int R, int RO_THREADS, bool NT>
 __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restrict__ descs, int res_begin, int res_end, int parts,
                                                           const double *__restrict__ lm_all, int lm_stride,
-                                                          double *__restrict__ out_all, int out_stride, int cur, int flags)
+                                                          double *__restrict__ out_all, int out_stride, int cur, int flags,
+                                                          double *__restrict__ partial_all)
 {
+    // flags: bit0 raw (no un-standardisation); bits 1-2 = column split of the product (sml_bank_readout_part):
+    //   0 all columns; 2 state columns only, raw sums -> partial_all; 4 physics-model columns only, added to partial_all
     __shared__ double red[RO_THREADS / 64][R];
     int res, grp;
     decode_block(blockIdx.x, parts, res_begin, res, grp);
@@ -167,7 +170,9 @@ __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restric
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
 
     const bool aligned_model = (D.n_model & 1) == 0;
-    for (int kk = threadIdx.x * 2; kk < D.n_aug_pad; kk += RO_THREADS * 2) {
+    const int csplit = (D.n_model + 1) & ~1;      // even (16-byte column pairs); every physics-model column is below it
+    const int kk_begin = (flags & 2) ? csplit : 0, kk_end = (flags & 4) ? csplit : D.n_aug_pad;
+    for (int kk = kk_begin + threadIdx.x * 2; kk < kk_end; kk += RO_THREADS * 2) {
         double a0, a1;
         if (kk + 1 < D.n_model) { a0 = lm[kk]; a1 = lm[kk + 1]; }
         else if (aligned_model && kk >= D.n_model && kk + 1 < D.n_aug) {
@@ -205,6 +210,8 @@ __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restric
             double v = 0.0;
 #pragma unroll
             for (int w = 0; w < RO_THREADS / 64; ++w) v += red[w][threadIdx.x];
+            if (flags & 2) { partial_all[(size_t)res * out_stride + row] = v; return; }
+            if (flags & 4) v = partial_all[(size_t)res * out_stride + row] + v;
             if (!(flags & 1)) {
                 const int si = D.out_stat[row];
                 if (si >= 0) {
@@ -213,6 +220,95 @@ __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restric
                 }
             }
             out_all[(size_t)res * out_stride + row] = v;
+        }
+    }
+}
+
+// The same product as k_readout<R, 64, .>, as a PERSISTENT kernel with a bounded footprint, for the pipelined hybrid step
+// (hybrid.py): the readout then runs on a side stream underneath the SPEEDY window, whose small latency-bound kernels
+// must keep finding free wave slots and LDS.  A plain launch floods every CU with single-wave workgroups and a 512-thread
+// transform workgroup is starved until the whole readout has drained (measured: one k_grid launch waited 1.26 ms).  Here
+// one workgroup of WAVES waves is launched per CU with a capped register budget, every wave is an independent worker
+// that pulls (reservoir, row group) items from a global counter until none are left (so every wave terminates), and
+// the rest of the CU -- wave slots, half of the VGPR file, all of the LDS -- stays free for the other stream.  The
+// bounded kernel alone cannot keep HBM busy (few loads in flight), so when the SPEEDY window is over a second launch at
+// full occupancy (flags bit 4, "drain") pulls from the SAME counter until the queue is empty.
+template <int R, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_readout_persist(const ResDesc *__restrict__ descs, int res_begin, int res_end, int parts,
+                                                                 const double *__restrict__ lm_all, int lm_stride,
+                                                                 double *__restrict__ out_all, int out_stride, int cur, int flags,
+                                                                 double *__restrict__ partial_all, unsigned *__restrict__ counter,
+                                                                 unsigned total_items)
+{
+    // MINW (minimum waves per SIMD the compiler must allow) caps the VGPRs: MINW = 4 -> 128 of the SIMD's 512 per wave
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);      // wave-uniform (SGPR): descriptor and row bases stay scalar
+        if (item >= total_items) return;
+        int res, grp;
+        decode_block((int)item, parts, res_begin, res, grp);
+        if (res >= res_end) continue;
+        const ResDesc D = descs[res];
+        if (!D.loaded) continue;
+        const int r0 = grp * R;
+        if (r0 >= D.n_out) continue;
+        const double *__restrict__ x = D.x[cur];
+        const double *__restrict__ lm = lm_all + (size_t)res * lm_stride;
+        const size_t ld = (size_t)D.n_aug_pad;
+        const double *wrow[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wrow[r] = D.wout + (size_t)min(r0 + r, D.n_out - 1) * ld;
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        const bool aligned_model = (D.n_model & 1) == 0;
+        const int csplit = (D.n_model + 1) & ~1;
+        const int kk_begin = (flags & 2) ? csplit : 0, kk_end = (flags & 4) ? csplit : D.n_aug_pad;
+        for (int kk = kk_begin + lane * 2; kk < kk_end; kk += 128) {         // the loop of k_readout<R, 64, true>
+            double a0, a1;
+            if (kk + 1 < D.n_model) { a0 = lm[kk]; a1 = lm[kk + 1]; }
+            else if (aligned_model && kk >= D.n_model && kk + 1 < D.n_aug) {
+                const double2 xv = *reinterpret_cast<const double2 *>(x + (kk - D.n_model));
+                a0 = xv.x; a1 = xv.y * xv.y;
+            } else {
+                auto aug = [&](int i) -> double {
+                    if (i < D.n_model) return lm[i];
+                    if (i >= D.n_aug) return 0.0;
+                    const int j = i - D.n_model;
+                    const double v = x[j];
+                    return (j & 1) ? v * v : v;
+                };
+                a0 = aug(kk); a1 = aug(kk + 1);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const f64x2 w = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(wrow[r] + kk));
+                acc[r] += w[0] * a0;
+                acc[r] += w[1] * a1;
+            }
+        }
+        double mine = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double sum = wave_sum(acc[r]);
+            if (lane == r) mine = sum;
+        }
+        if (lane < R) {
+            const int row = r0 + lane;
+            if (row < D.n_out) {
+                double v = mine;
+                if (flags & 2) { partial_all[(size_t)res * out_stride + row] = v; }
+                else {
+                    if (flags & 4) v = partial_all[(size_t)res * out_stride + row] + v;
+                    if (!(flags & 1)) {
+                        const int si = D.out_stat[row];
+                        if (si >= 0) v = __dadd_rn(__dmul_rn(v, D.stdv[si]), D.mean[si]);
+                    }
+                    out_all[(size_t)res * out_stride + row] = v;
+                }
+            }
         }
     }
 }
@@ -430,12 +526,41 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
     static const int variant = getenv("SML_RO_VARIANT") ? atoi(getenv("SML_RO_VARIANT")) : 7;
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
+    const bool timed = b->timing && !(flags & 4);       // the small physics-model block (part 2) is not the roofline kernel
+    if (flags & (8 | 16)) {
+        // persistent work-queue variants (sml_bank_readout_part): bit 3 = bounded footprint, resets the queue;
+        // bit 4 = full-occupancy drain of the same queue (no reset)
+        static int ncu = 0;
+        if (!ncu) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            SML_HIP(hipGetDevice(&dev));
+            SML_HIP(hipGetDeviceProperties(&prop, dev));
+            ncu = prop.multiProcessorCount;
+        }
+        if (!b->d_counter) { SML_HIP(hipMalloc((void **)&b->d_counter, 256)); SML_HIP(hipMemset(b->d_counter, 0xff, 256)); }
+        const int parts = (b->max_n_out_loaded + 17 - 1) / 17;
+        const unsigned total = (unsigned)(nres8 * parts);
+        if (flags & 8) SML_HIP(hipMemsetAsync(b->d_counter, 0, sizeof(unsigned), st));
+        if (timed) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
+#define ROP_LAUNCH(W, MINW, NWG)                                                                                                     \
+        hipLaunchKernelGGL((k_readout_persist<17, W, MINW>), dim3(NWG), dim3((W) * 64), 0, st, b->d_descs, res_begin, res_end, parts, \
+                           b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags & 7, b->d_partial, b->d_counter, total)
+        // measured in the pipelined hybrid step (ms per step; sequential schedule 2.88): bounded kernel of 4 / 8 / 12 / 16
+        // waves per CU + drain 2.91 / 2.72 / 3.21 / 3.29; 8 waves without the drain 2.67
+        if (flags & 16) { ROP_LAUNCH(4, 5, ncu * 5); }               // 20 waves per CU, <= 102 VGPRs: the occupancy of k_readout<17,64>
+        else { ROP_LAUNCH(8, 4, ncu); }
+#undef ROP_LAUNCH
+        SML_HIP(hipGetLastError());
+        if (timed) { SML_HIP(hipEventRecord(e1, st)); b->ev_readout.emplace_back(e0, e1); }
+        return SML_OK;
+    }
+    if (timed) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
 #define RO_LAUNCH(R, T, NT)                                                                                             \
     {                                                                                                                   \
         const int parts = (b->max_n_out_loaded + (R) - 1) / (R);                                                        \
         hipLaunchKernelGGL((k_readout<R, T, NT>), dim3(nres8 * parts), dim3(T), 0, st, b->d_descs, res_begin, res_end, parts, \
-                           b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags);                 \
+                           b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags, b->d_partial);   \
     }
     switch (variant) {
     case 1: RO_LAUNCH(17, 512, true) break;
@@ -455,7 +580,7 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
     }
 #undef RO_LAUNCH
     SML_HIP(hipGetLastError());
-    if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_readout.emplace_back(e0, e1); }
+    if (timed) { SML_HIP(hipEventRecord(e1, st)); b->ev_readout.emplace_back(e0, e1); }
     return SML_OK;
 }
 
@@ -488,7 +613,8 @@ int sml_bank_create(int capacity, int max_d, int max_n_model, int max_n_out, sml
     int rc;
     if ((rc = sml::dev_zeros(&b->d_descs, (size_t)capacity)) || (rc = sml::dev_zeros(&b->d_feedback, (size_t)capacity * b->max_d)) ||
         (rc = sml::dev_zeros(&b->d_local_model, (size_t)capacity * b->max_n_model)) ||
-        (rc = sml::dev_zeros(&b->d_outvec, (size_t)capacity * b->max_n_out))) {
+        (rc = sml::dev_zeros(&b->d_outvec, (size_t)capacity * b->max_n_out)) ||
+        (rc = sml::dev_zeros(&b->d_partial, (size_t)capacity * b->max_n_out))) {
         delete b;
         return rc;
     }
@@ -500,7 +626,8 @@ int sml_bank_destroy(sml_bank *b)
 {
     if (!b) return SML_OK;
     for (auto &r : b->res) free_slot(r);
-    (void)hipFree(b->d_descs); (void)hipFree(b->d_feedback); (void)hipFree(b->d_local_model); (void)hipFree(b->d_outvec);
+    (void)hipFree(b->d_descs); (void)hipFree(b->d_feedback); (void)hipFree(b->d_local_model); (void)hipFree(b->d_outvec); (void)hipFree(b->d_partial);
+    if (b->d_counter) (void)hipFree(b->d_counter);
     delete b;
     return SML_OK;
 }
@@ -608,6 +735,16 @@ int sml_bank_predict_all(sml_bank *b, int flags, void *stream)
     if (rc) return rc;
     if ((rc = launch_update(b, 0, b->capacity, b->d_feedback, sml::as_stream(stream)))) return rc;
     return launch_readout(b, 0, b->capacity, flags, sml::as_stream(stream));
+}
+
+int sml_bank_readout_part(sml_bank *b, int part, int flags, void *stream)
+{
+    SML_REQUIRE(b && (part == 1 || part == 2), "sml_bank_readout_part: part must be 1 (state columns) or 2 (model columns)");
+    int rc = sync_descs(b);
+    if (rc) return rc;
+    // flags bit 3 (8): persistent bounded-footprint kernel (part 1 on a side stream); bit 4 (16): full-occupancy drain of its queue
+    SML_REQUIRE(!(flags & 24) || part == 1, "sml_bank_readout_part: the persistent variants exist for part 1 only");
+    return launch_readout(b, 0, b->capacity, (flags & 25) | (part == 1 ? 2 : 4), sml::as_stream(stream));
 }
 
 int sml_bank_predict_one(sml_bank *bank, int slot, double *x_inout, const double *lm, double *outvec)
@@ -726,6 +863,24 @@ int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int 
     if (rc == SML_OK && hipStreamSynchronize(st) != hipSuccess) rc = sml::fail(SML_ERR_HIP, "sml_bank_train_pass: stream synchronise failed");
     cleanup();
     return rc == SML_OK ? flushed : rc;
+}
+
+int sml_bank_readout_part_bytes(sml_bank *b, int part, uint64_t *bytes)
+{
+    SML_REQUIRE(b && bytes && (part == 1 || part == 2), "sml_bank_readout_part_bytes: bad arguments");
+    uint64_t r = 0;
+    for (auto &h : b->res) {
+        if (!h.desc.loaded) continue;
+        const ResDesc &D = h.desc;
+        const uint64_t csplit = (uint64_t)((D.n_model + 1) & ~1);
+        const uint64_t model_block = (uint64_t)D.n_out * std::min<uint64_t>(csplit, (uint64_t)D.n_aug) * 8;
+        // part 1: the state columns of W_out + the partial sums written; part 2: the rest of the full readout's bytes
+        // + the partial sums read back
+        const uint64_t p1 = (uint64_t)D.n_out * D.n_aug * 8 - model_block + (uint64_t)D.n_out * 8;
+        r += part == 1 ? p1 : h.readout_bytes - ((uint64_t)D.n_out * D.n_aug * 8 - model_block) + (uint64_t)D.n_out * 8;
+    }
+    *bytes = r;
+    return SML_OK;
 }
 
 int sml_bank_algorithmic_bytes(sml_bank *b, uint64_t *update_bytes, uint64_t *readout_bytes)

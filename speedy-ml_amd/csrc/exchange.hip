@@ -245,14 +245,16 @@ int sml_exchange_scatter(sml_exchange *ex, const double *all_outvec_dev, double 
 
 int sml_exchange_gather(sml_exchange *ex, const double *g_dev, const double *f_dev, void *stream)
 {
-    SML_REQUIRE(ex && g_dev, "sml_exchange_gather: bad arguments");
+    SML_REQUIRE(ex && (g_dev || f_dev), "sml_exchange_gather: bad arguments");
     int rc = sml::bank_sync_descs(ex->bank);
     if (rc) return rc;
     hipStream_t st = sml::as_stream(stream);
-    dim3 gin((ex->in_stride + 127) / 128, ex->nslots);
-    hipLaunchKernelGGL(k_gather, gin, dim3(128), 0, st, ex->bank->d_descs, g_dev, ex->d_in_map, ex->d_in_stat, ex->in_stride, ex->nslots,
-                       ex->bank->d_feedback, ex->in_stride);
-    SML_HIP(hipGetLastError());
+    if (g_dev) {
+        dim3 gin((ex->in_stride + 127) / 128, ex->nslots);
+        hipLaunchKernelGGL(k_gather, gin, dim3(128), 0, st, ex->bank->d_descs, g_dev, ex->d_in_map, ex->d_in_stat, ex->in_stride, ex->nslots,
+                           ex->bank->d_feedback, ex->in_stride);
+        SML_HIP(hipGetLastError());
+    }
     if (f_dev) {
         dim3 glm((ex->lm_stride + 127) / 128, ex->nslots);
         hipLaunchKernelGGL(k_gather, glm, dim3(128), 0, st, ex->bank->d_descs, f_dev, ex->d_lm_map, ex->d_lm_stat, ex->lm_stride, ex->nslots,

@@ -38,7 +38,9 @@ class Exchange:
                                               ip(sea_mask.data_ptr()) if sea_mask is not None else None, vp(stream)))
 
     def gather(self, g, f=None, stream=None):
-        check(_lib.lib().sml_exchange_gather(self._h, dp(g.data_ptr()), dp(f.data_ptr()) if f is not None else None, vp(stream)))
+        """g -> feedback of every slot, f -> local_model of every slot; either may be None to skip that half."""
+        check(_lib.lib().sml_exchange_gather(self._h, dp(g.data_ptr()) if g is not None else None,
+                                             dp(f.data_ptr()) if f is not None else None, vp(stream)))
 
 
 def handoff_to_fields(g, fields, stream=None):

@@ -116,6 +116,11 @@ class ReservoirBank:
     def advance(self, stream=None):
         check(_lib.lib().sml_bank_advance_all(self._h, vp(stream)))
 
+    def readout_part(self, part, raw=False, stream=None, persistent=False, drain=False):
+        """The readout of predict in two column blocks: part 1 = reservoir-state columns (needs only the advanced state),
+        part 2 = physics-model columns + un-standardisation -> outvec.  advance(); readout_part(1); readout_part(2) == predict()."""
+        check(_lib.lib().sml_bank_readout_part(self._h, int(part), (1 if raw else 0) | (8 if persistent else 0) | (16 if drain else 0), vp(stream)))
+
     def synchronize(self, inputs_dev_ptr, length, stream=None):
         """synchronize (src/mod_reservoir.f90:1354-1381); inputs: device [length][capacity][max_d]."""
         check(_lib.lib().sml_bank_synchronize_all(self._h, dp(int(inputs_dev_ptr)), length, vp(stream)))
@@ -124,6 +129,11 @@ class ReservoirBank:
         u, r = C.c_uint64(), C.c_uint64()
         check(_lib.lib().sml_bank_algorithmic_bytes(self._h, C.byref(u), C.byref(r)))
         return u.value, r.value
+
+    def readout_part_bytes(self, part):
+        r = C.c_uint64()
+        check(_lib.lib().sml_bank_readout_part_bytes(self._h, int(part), C.byref(r)))
+        return r.value
 
     def train_pass(self, noisy_inputs, discard, batch, models, targets, cs, bs, stream=None):
         """reservoir_layer_chunking_hybrid (src/mod_reservoir.f90:1067-1175) for every loaded slot.

@@ -18,7 +18,7 @@ NREG = 1152
 def model():
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
-    m = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1)
+    m = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1, pipeline=False)
     m.classes_ = classes
     return m
 
@@ -141,3 +141,28 @@ def test_hybrid_closed_loop_stays_physical(model):
     assert int(m.safe.item()) == 1
     T = m.F[:domain.G2_OFF].reshape(8, 48, 96, 4)[..., 0]
     assert 180.0 < float(T.min()) and float(T.max()) < 320.0
+
+
+def test_pipelined_step_equals_sequential_step():
+    """The software-pipelined schedule (advance + state block of the readout on a side stream under the SPEEDY window) must
+    reproduce the sequential schedule: same G, F, feedback, local_model and reservoir states after several steps.  The only
+    arithmetic difference is the association of the readout's column sum (two partial sums instead of one)."""
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = list(range(NREG))
+    seq = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, pipeline=False, leapfrog_steps=4)
+    pip = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, pipeline=True, leapfrog_steps=4)
+    stream = torch.cuda.current_stream()
+    for _ in range(4):
+        seq.step(stream)
+        pip.step(stream)
+    torch.cuda.synchronize()
+    for name in ("G", "F", "feedback", "local_model", "outvec"):
+        a, b = getattr(seq, name), getattr(pip, name)
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-11 * scale, name
+    # the pipelined bank is one advance ahead (its next step's state block is already in flight)
+    seq.bank.advance(stream=stream)
+    torch.cuda.synchronize()
+    for s in (0, 17, 1151):
+        assert np.max(np.abs(seq.bank.get_state(s) - pip.bank.get_state(s))) <= 1e-11

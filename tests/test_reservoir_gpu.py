@@ -155,3 +155,43 @@ def test_slab_ocean_shapes(oracle):
     for slot in (0, 3):
         assert np.max(np.abs(banks.get_state(slot) - xw)) <= X_TOL
         assert np.max(np.abs(banks.get_outvec(slot) - ow)) <= OUT_TOL * np.max(np.abs(ow))
+
+
+@pytest.mark.parametrize("variant", ["plain", "persistent", "persistent+drain"])
+def test_split_readout_equals_predict(oracle, variant):
+    """advance + readout_part(1) + readout_part(2) == predict, for odd/even/zero n_model, empty slots and ragged n_out;
+    the persistent work-queue kernels (bounded footprint, and bounded + full-occupancy drain of the same queue) included."""
+    shapes = [(600, 60, 12, 16), (640, 64, 0, 8), (330, 30, 7, 17), (1280, 40, 11, 35), (64, 8, 2, 1), (256, 16, 1, 20)]
+    rs = [make_reservoir(n=n, d=d, n_model=m, n_out=o, seed=300 + i) for i, (n, d, m, o) in enumerate(shapes)]
+    banks = [ReservoirBank(10, max_d=64, max_n_model=12, max_n_out=35) for _ in range(2)]
+    rng = np.random.default_rng(3)
+    x0 = [rng.standard_normal(r.n) * 0.3 for r in rs]
+    for bank in banks:
+        for i, r in enumerate(rs):
+            stat = (np.arange(r.n_out) % 36).astype(np.int32)
+            stat[::4] = -1
+            r.stat = stat
+            load(bank, i + 2, r, stat)
+            bank.set_state(i + 2, x0[i])
+            bank.set_feedback(i + 2, r.feedback)
+            if r.n_model:
+                bank.set_local_model(i + 2, r.local_model)
+    a, b = banks
+    a.predict()
+    b.advance()
+    side = torch.cuda.Stream()
+    if variant == "plain":
+        b.readout_part(1)
+    else:
+        torch.cuda.synchronize()
+        b.readout_part(1, persistent=True, stream=side)
+        if variant == "persistent+drain":
+            b.readout_part(1, drain=True, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+    b.readout_part(2)
+    torch.cuda.synchronize()
+    for i, r in enumerate(rs):
+        oa, ob = a.get_outvec(i + 2), b.get_outvec(i + 2)
+        assert np.max(np.abs(oa - ob)) <= 1e-13 * max(1.0, np.max(np.abs(oa))), (variant, i)
+        _, ow = oracle_predict(oracle, r, x0[i], r.stat)
+        assert np.max(np.abs(ob - ow)) <= OUT_TOL * max(1.0, np.max(np.abs(ow)))
