@@ -278,6 +278,13 @@ int sml_dyn_impint(sml_dyn *dyn, double dt, double alph);
 int sml_dyn_get_table(sml_dyn *dyn, int which, double *out_host, int capacity);
 /* phis (mod_surfcon / mod_dynvar), tcorh, qcorh (mod_hdifcon.f90:19, set by ini_fordate.f90:86,113): spectral [32][62] */
 int sml_dyn_set_boundary(sml_dyn *dyn, const double *phis_dev, const double *tcorh_dev, const double *qcorh_dev, void *stream);
+/* For a Fortran host that keeps the prognostic variables in mod_dynvar's arrays (src/mod_dynvar.f90:14-27): the handle owns a
+ * device state; *_host copy complex vor/div/t(mx,nx,kx,2), ps(mx,nx,2) and the first tracer tr(mx,nx,kx,2) in and out, and
+ * phis/tcorh/qcorh(mx,nx).  Synchronous.  sml_dyn_state_dev returns the device state to pass to step/window. */
+int sml_dyn_state_dev(sml_dyn *dyn, double **state_dev);
+int sml_dyn_set_state_host(sml_dyn *dyn, const double *vor, const double *div, const double *t, const double *ps, const double *tr);
+int sml_dyn_get_state_host(sml_dyn *dyn, double *vor, double *div, double *t, double *ps, double *tr);
+int sml_dyn_set_boundary_host(sml_dyn *dyn, const double *phis, const double *tcorh, const double *qcorh);
 /* grtend(vordt,divdt,tdt,psdt,trdt,1,j2) without physics (src/dyn_grtend.f90): tend_dev receives the 33 tendencies */
 int sml_dyn_grtend(sml_dyn *dyn, const double *state_dev, int j2, double *tend_dev, void *stream);
 /* the rest of step() from given grid-point tendencies (src/dyn_step.f90:45-127): sptend [+ implic when alph != 0],

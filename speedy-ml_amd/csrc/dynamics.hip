@@ -552,6 +552,7 @@ struct sml_dyn {
     std::vector<ImpSlot *> slots;
     ImpSlot *cur = nullptr;
     double *bc = nullptr;              // phis | tcorh | qcorh  (3 x SP)
+    double *own_state = nullptr;       // [2][33][SP] for hosts that keep the state in Fortran arrays (sml_dyn_*_host)
     double *batch_spec = nullptr;      // [50][SP]
     double *batch_grid = nullptr;      // [50][GR]
     double *tend_grid = nullptr;       // [73][GR]
@@ -639,6 +640,7 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
     if (!rc) rc = fetch_table(d, 23, &d->d.vddyp, tmp, NX * MX);
     auto zeros = [&](double **p, size_t n) { int r = sml::dev_zeros(p, n); if (!r) d->allocs.push_back(*p); return r; };
     if (!rc) rc = zeros(&d->bc, (size_t)3 * SP);
+    if (!rc) rc = zeros(&d->own_state, (size_t)2 * NSTATE * SP);
     if (!rc) rc = zeros(&d->batch_spec, (size_t)NB_SPEC * SP);
     if (!rc) rc = zeros(&d->batch_grid, (size_t)NB_SPEC * GR);
     if (!rc) rc = zeros(&d->tend_grid, (size_t)NB_GRID * GR);
@@ -736,6 +738,54 @@ int sml_dyn_set_boundary(sml_dyn *d, const double *phis_dev, const double *tcorh
     SML_HIP(hipMemcpyAsync(d->bc, phis_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
     SML_HIP(hipMemcpyAsync(d->bc + SP, tcorh_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
     SML_HIP(hipMemcpyAsync(d->bc + 2 * SP, qcorh_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return SML_OK;
+}
+
+int sml_dyn_state_dev(sml_dyn *d, double **state_dev)
+{
+    SML_REQUIRE(d && state_dev, "sml_dyn_state_dev: bad arguments");
+    *state_dev = d->own_state;
+    return SML_OK;
+}
+
+// Host arrays in the reference's own shapes (src/mod_dynvar.f90:14-27): complex vor/div/t(mx,nx,kx,2), ps(mx,nx,2),
+// tr(mx,nx,kx,2,ntr) of which the first tracer is used.  One contiguous block of 8 levels per field and time level.
+static int copy_state(sml_dyn *d, double *vor, double *div, double *t, double *ps, double *tr, bool to_device)
+{
+    double *host3[4] = {vor, div, t, tr};
+    const int off3[4] = {F_VOR, F_DIV, F_T, F_TR};
+    for (int j = 0; j < 2; ++j) {
+        double *lev = d->own_state + (size_t)j * NSTATE * SP;
+        for (int f = 0; f < 4; ++f) {
+            double *h = host3[f] + (size_t)j * KX * SP, *g = lev + (size_t)off3[f] * SP;
+            SML_HIP(hipMemcpy(to_device ? g : h, to_device ? h : g, (size_t)KX * SP * sizeof(double), to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+        }
+        double *h = ps + (size_t)j * SP, *g = lev + (size_t)F_PS * SP;
+        SML_HIP(hipMemcpy(to_device ? g : h, to_device ? h : g, (size_t)SP * sizeof(double), to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    }
+    return SML_OK;
+}
+
+int sml_dyn_set_state_host(sml_dyn *d, const double *vor, const double *div, const double *t, const double *ps, const double *tr)
+{
+    SML_REQUIRE(d && vor && div && t && ps && tr, "sml_dyn_set_state_host: bad arguments");
+    return copy_state(d, const_cast<double *>(vor), const_cast<double *>(div), const_cast<double *>(t), const_cast<double *>(ps),
+                      const_cast<double *>(tr), true);
+}
+
+int sml_dyn_get_state_host(sml_dyn *d, double *vor, double *div, double *t, double *ps, double *tr)
+{
+    SML_REQUIRE(d && vor && div && t && ps && tr, "sml_dyn_get_state_host: bad arguments");
+    SML_HIP(hipDeviceSynchronize());
+    return copy_state(d, vor, div, t, ps, tr, false);
+}
+
+int sml_dyn_set_boundary_host(sml_dyn *d, const double *phis, const double *tcorh, const double *qcorh)
+{
+    SML_REQUIRE(d && phis && tcorh && qcorh, "sml_dyn_set_boundary_host: bad arguments");
+    SML_HIP(hipMemcpy(d->bc, phis, SP * sizeof(double), hipMemcpyHostToDevice));
+    SML_HIP(hipMemcpy(d->bc + SP, tcorh, SP * sizeof(double), hipMemcpyHostToDevice));
+    SML_HIP(hipMemcpy(d->bc + 2 * SP, qcorh, SP * sizeof(double), hipMemcpyHostToDevice));
     return SML_OK;
 }
 

@@ -93,6 +93,63 @@ module speedyml_hip
       type(c_ptr), value :: bank, stream
       integer(c_int) :: rc
     end function
+    ! ---- spectral handle + SPEEDY adiabatic time step (include/speedyml_hip.h sections 4 and 4a) ----
+    function sml_spectral_create(a, sp) bind(C, name="sml_spectral_create") result(rc)
+      import :: c_int, c_double, c_ptr
+      real(c_double), value :: a
+      type(c_ptr), intent(out) :: sp
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_create(sp, dyn) bind(C, name="sml_dyn_create") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: sp
+      type(c_ptr), intent(out) :: dyn
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_impint(dyn, dt, alph) bind(C, name="sml_dyn_impint") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: dyn
+      real(c_double), value :: dt, alph
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_state_dev(dyn, state_dev) bind(C, name="sml_dyn_state_dev") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: dyn
+      type(c_ptr), intent(out) :: state_dev
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_set_state_host(dyn, vor, div, t, ps, tr) bind(C, name="sml_dyn_set_state_host") result(rc)
+      import :: c_int, c_double_complex, c_ptr
+      type(c_ptr), value :: dyn
+      complex(c_double_complex), intent(in) :: vor(*), div(*), t(*), ps(*), tr(*)
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_get_state_host(dyn, vor, div, t, ps, tr) bind(C, name="sml_dyn_get_state_host") result(rc)
+      import :: c_int, c_double_complex, c_ptr
+      type(c_ptr), value :: dyn
+      complex(c_double_complex), intent(out) :: vor(*), div(*), t(*), ps(*), tr(*)
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_set_boundary_host(dyn, phis, tcorh, qcorh) bind(C, name="sml_dyn_set_boundary_host") result(rc)
+      import :: c_int, c_double_complex, c_ptr
+      type(c_ptr), value :: dyn
+      complex(c_double_complex), intent(in) :: phis(*), tcorh(*), qcorh(*)
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_step(dyn, state_dev, j1, j2, dt, alph, rob, wil, stream) bind(C, name="sml_dyn_step") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: dyn, state_dev, stream
+      integer(c_int), value :: j1, j2
+      real(c_double), value :: dt, alph, rob, wil
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_window(dyn, state_dev, start, nsteps, delt, alph, rob, wil, stream) bind(C, name="sml_dyn_window") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: dyn, state_dev, stream
+      integer(c_int), value :: start, nsteps
+      real(c_double), value :: delt, alph, rob, wil
+      integer(c_int) :: rc
+    end function
   end interface
 
 contains

@@ -6,6 +6,7 @@ program test_driver
   use iso_c_binding
   use speedyml_hip
   use mod_reservoir_hip
+  use speedy_dyn_hip
   implicit none
 
   type(reservoir_type) :: res
@@ -17,7 +18,11 @@ program test_driver
   real(kind=dp) :: seed, errx, erro
   real(kind=dp) :: vorm(62,32,2), vorg(96,48), back(62,32), a
   integer :: kcos
-  external :: parmtr, inifft, grid, spec
+  external :: parmtr, inifft, grid, spec, stepone
+  complex(c_double_complex) :: vor0(mx,nx,kx,2), div0(mx,nx,kx,2), t0(mx,nx,kx,2), ps0(mx,nx,2), tr0(mx,nx,kx,2,ntr)
+  complex(c_double_complex) :: vorA(mx,nx,kx,2), tA(mx,nx,kx,2), psA(mx,nx,2)
+  real(kind=dp) :: fsg(kx), rgam
+  integer :: kk, m2, n2
 
   if (sml_device_count() < 1) then
     print *, 'test_driver: no HIP device visible'
@@ -119,6 +124,54 @@ program test_driver
   errx = maxval(abs(back - vorm(:,:,1)))/maxval(abs(vorm(:,:,1)))
   print '(a,es10.3)', 'spec(grid(v)) rel err = ', errx
   if (errx > 1.0e-12_dp) nfail = nfail + 1
+
+  ! ---- SPEEDY adiabatic time stepping: the external subroutines impint/step/stepone (host arrays in the reference's
+  ! shapes, one round trip per call) against the device-resident window; same kernels -> identical bits ----
+  call dyn_hip_init(a)
+  fsg = (/0.025_dp, 0.095_dp, 0.20_dp, 0.34_dp, 0.51_dp, 0.685_dp, 0.835_dp, 0.95_dp/)
+  rgam = (2.0_dp/7.0_dp*1004.0_dp)*6.0_dp/(1000.0_dp*9.81_dp)
+  vor = (0.0_dp,0.0_dp); div = (0.0_dp,0.0_dp); t = (0.0_dp,0.0_dp); ps = (0.0_dp,0.0_dp); tr = (0.0_dp,0.0_dp)
+  phis = (0.0_dp,0.0_dp); tcorh = (0.0_dp,0.0_dp); qcorh = (0.0_dp,0.0_dp)
+  do kk = 1, kx
+    t(1,1,kk,1) = cmplx(288.0_dp*max(0.2_dp, fsg(kk))**rgam*sqrt(2.0_dp), 0.0_dp, kind=dp)
+    do n2 = 1, 6
+      do m2 = 1, 6
+        if (m2 == 1 .and. n2 == 1) cycle
+        vor(m2,n2,kk,1) = 2.0e-6_dp*cmplx(rnd()-0.5_dp, merge(0.0_dp, rnd()-0.5_dp, m2 == 1), kind=dp)
+        div(m2,n2,kk,1) = 1.0e-7_dp*cmplx(rnd()-0.5_dp, merge(0.0_dp, rnd()-0.5_dp, m2 == 1), kind=dp)
+        t(m2,n2,kk,1) = 0.5_dp*cmplx(rnd()-0.5_dp, merge(0.0_dp, rnd()-0.5_dp, m2 == 1), kind=dp)
+        tr(m2,n2,kk,1,1) = 1.0e-4_dp*cmplx(rnd()-0.5_dp, merge(0.0_dp, rnd()-0.5_dp, m2 == 1), kind=dp)
+      end do
+    end do
+  end do
+  do n2 = 1, 6
+    do m2 = 1, 6
+      ps(m2,n2,1) = 2.0e-3_dp*cmplx(rnd()-0.5_dp, merge(0.0_dp, rnd()-0.5_dp, m2 == 1), kind=dp)
+      phis(m2,n2) = 300.0_dp*cmplx(rnd()-0.5_dp, merge(0.0_dp, rnd()-0.5_dp, m2 == 1), kind=dp)
+    end do
+  end do
+  tcorh = phis*(6.0_dp/(1000.0_dp*9.81_dp))
+  vor(:,:,:,2) = vor(:,:,:,1); div(:,:,:,2) = div(:,:,:,1); t(:,:,:,2) = t(:,:,:,1); ps(:,:,2) = ps(:,:,1); tr(:,:,:,2,:) = tr(:,:,:,1,:)
+  vor0 = vor; div0 = div; t0 = t; ps0 = ps; tr0 = tr
+  call dyn_hip_boundary()
+  call dyn_hip_window(0)                        ! stepone on the device-resident state
+  vorA = vor; tA = t; psA = ps
+  vor = vor0; div = div0; t = t0; ps = ps0; tr = tr0
+  call stepone                                  ! src/ini_stepone.f90 through the external impint/step
+  errx = maxval(abs(vor - vorA)) + maxval(abs(t - tA)) + maxval(abs(ps - psA))
+  print '(a,es10.3)', 'stepone: host-array externals vs device-resident window, sum of max|diff| = ', errx
+  if (errx /= 0.0_dp) nfail = nfail + 1
+  if (ps(1,1,1) /= ps0(1,1,1) .or. ps(1,1,2) /= ps0(1,1,1)) then
+    print *, 'global mean of log(ps) not conserved'
+    nfail = nfail + 1
+  end if
+  if (maxval(abs(vor(:,:,:,2) - vor0(:,:,:,1))) == 0.0_dp .or. .not. (maxval(abs(t)) < 1.0e3_dp)) then
+    print *, 'stepone left the state unchanged or produced non-finite values'
+    nfail = nfail + 1
+  end if
+  call dyn_hip_window(24)                       ! a whole 6-hour hybrid window
+  print '(a,es10.3,a,es10.3)', '6-hour window: max|vor| = ', maxval(abs(vor)), '   max|T| = ', maxval(abs(t))
+  if (.not. (maxval(abs(vor)) < 1.0e-3_dp .and. maxval(abs(t)) < 1.0e3_dp)) nfail = nfail + 1
 
   if (nfail == 0) then
     print *, 'FORTRAN HOST PARITY OK'
