@@ -173,12 +173,32 @@ typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 constexpr int DKT = 8, NBUF = 4, AHEAD = 3;
 
+// Work decomposition (mode): 0 = 2-D grid over all tiles of an M x N product; 1 = 1-D list of the tiles on or below the
+// diagonal (tile L = blockIdx.x, row-major in the triangle), so no workgroups are spent on the upper triangle.
+//
+// Where the time goes (m = 2920, 1035 + 45 tiles, MI355X, compile-time ablations of this kernel, executed-flop TF/s):
+//   full kernel 42.2 | MFMAs only (no DMA, no barrier, operands from registers) 57.8 | + LDS operand reads 57.0 |
+//   DMA + barrier but operands from registers 49.9.  So the MFMA stream of this tiling tops out at 58 TF/s under load
+//   (the 69-75 TF/s of profiles/micro/mfma_f64_peak.hip is an idle-chip figure; zeros instead of random data give +7 %,
+//   i.e. clocks), the operand reads are free on their own and cost 15 % once the DMA writes share the LDS, and DMA +
+//   barrier cost 14 %.  Measured and found irrelevant (all within 2 %): K-tile 8 vs 16, ring depth 3 vs 4, look-ahead 1-3
+//   tiles, an XCD-aware super-tile map (L2 hit rate is 52 % either way), splitting the ragged last round along K (the
+//   two resident workgroups per CU already keep the chip busy until the last tile).
+__device__ __forceinline__ void tri_tile(int L, int &ti, int &tj)
+{
+    ti = (int)((sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
+    while ((long)(ti + 1) * (ti + 2) / 2 <= L) ++ti;
+    while ((long)ti * (ti + 1) / 2 > L) --ti;
+    tj = L - (int)((long)ti * (ti + 1) / 2);
+}
+
 __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
-                                                        double *__restrict__ C, long ldc, int M, int N, int K, double alpha, int lower_only)
+                                                        double *__restrict__ C, long ldc, int M, int N, int K, double alpha, int mode)
 {
     __shared__ __attribute__((aligned(16))) double S[NBUF][2][DKT][LDS_LD];       // [ring slot][operand][k][row]  73.7 KB
-    const int ti = blockIdx.x, tj = blockIdx.y;
-    if (lower_only && tj > ti) return;
+    int ti, tj;
+    if (mode == 0) { ti = blockIdx.x; tj = blockIdx.y; }
+    else tri_tile((int)blockIdx.x, ti, tj);
     const int i0 = ti * BM, j0 = tj * BN;
     const WavePos w = wave_pos();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -411,8 +431,11 @@ int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, lon
     // beats main + tail passes.  Long K (m = 2920, the 40-year configuration) takes the LDS-DMA kernel.
     if (ok(A, lda) && ok(B, ldb) && M >= 2 && N >= 2 && K >= 512) {
         kmain = (K / DKT) * DKT;
-        dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-        hipLaunchKernelGGL(k_gemm_nt_dma, grid, dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, lower_only);
+        const int nbi = (M + BM - 1) / BM, nbj = (N + BN - 1) / BN;
+        if (!lower_only || nbi != nbj)
+            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi, nbj), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0);
+        else
+            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi * (nbi + 1) / 2), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 1);
         SML_HIP(hipGetLastError());
     }
     if (kmain < K)
