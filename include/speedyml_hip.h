@@ -231,6 +231,11 @@ int sml_spectral_spec(sml_spectral *sp, const double *vorg_dev, double *vorm_dev
  * :237-277): per-field int32 flags on the device.  kcos: 1|2.  scale: 0 none, 1 *cosgr(j) (vdspec kcos=2), 2 *cosgr2(j). */
 int sml_spectral_grid_mixed(sml_spectral *sp, const double *vorm_dev, double *vorg_dev, int nf, const int32_t *kcos_dev, void *stream);
 int sml_spectral_spec_mixed(sml_spectral *sp, const double *vorg_dev, double *vorm_dev, int nf, const int32_t *scale_dev, void *stream);
+/* Inverse transforms of DERIVED fields in one launch, without materialising uvspec / grad first (the transform set of
+ * grtend, src/dyn_grtend.f90:61-99, and of iogrid(31), src/ppo_iogrid.f90:582-593).  desc_dev: int32 [nf][4] on the device,
+ * (type, src0, src1, kcos) per output field, src = field index into spec_base_dev ([.][32][62]):
+ *   type 0: field src0;  1 | 2: ucos | vcos of uvspec(vor = src0, div = src1);  3 | 4: d/dx | d/dy of grad(src0). */
+int sml_spectral_grid_derived(sml_spectral *sp, const double *spec_base_dev, const int32_t *desc_dev, double *vorg_dev, int nf, void *stream);
 int sml_spectral_vdspec(sml_spectral *sp, const double *ug_dev, const double *vg_dev, double *vorm_dev,
                         double *divm_dev, int nf, int kcos, void *stream);                                    /* :416-452 */
 int sml_spectral_uvspec(sml_spectral *sp, const double *vorm_dev, const double *divm_dev, double *ucosm_dev,
@@ -291,7 +296,7 @@ int sml_dyn_grtend(sml_dyn *dyn, const double *state_dev, int j2, double *tend_d
  * hordif, and when dt > 0 timint on both time levels.  tend_dev is updated in place to the diffused tendencies. */
 int sml_dyn_spectral_step(sml_dyn *dyn, double *state_dev, double *tend_dev, int j1, int j2, double dt, double alph, double rob,
                           double wil, void *stream);
-/* step(j1,j2,dt,alph,rob,wil) (src/dyn_step.f90:1-128): five launches, state updated in place */
+/* step(j1,j2,dt,alph,rob,wil) (src/dyn_step.f90:1-128): four launches, state updated in place */
 int sml_dyn_step(sml_dyn *dyn, double *state_dev, int j1, int j2, double dt, double alph, double rob, double wil, void *stream);
 /* start != 0: stepone (src/ini_stepone.f90: impint(delt/2), step(1,1,delt/2), impint(delt), step(1,2,delt)); then
  * impint(2 delt) and nsteps leapfrog steps step(2,2,2 delt) (src/dyn_stloop.f90:28-43) */

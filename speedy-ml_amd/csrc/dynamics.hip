@@ -2,14 +2,14 @@
 //
 // Replaces, for the hybrid window between iogrid(30) and iogrid(31) (src/ppo_iogrid.f90:497-601):
 //   src/ini_indyns.f90, src/ini_impint.f90 (+ inv/ludcmp/lubksb of src/spe_matinv.f90)   -> host tables, uploaded once per (dt, alph)
-//   src/dyn_grtend.f90 (without the phypar call :222-225; column physics is out of scope)  -> k_pre, k_gridtend + 2 transform launches
+//   src/dyn_grtend.f90 (without the phypar call :222-225; column physics is out of scope)  -> k_gridtend + 2 transform launches
 //   src/dyn_sptend.f90, dyn_geop.f90, dyn_implic.f90, dyn_step.f90 (hordif, timint)        -> k_spectral
 //   src/ini_stepone.f90 + the step loop of src/dyn_stloop.f90:28-43                        -> sml_dyn_window
 //
-// The reference runs 164 single-field transforms and ~60 small array loops per step on one core.  Here one step is FIVE
+// The reference runs 164 single-field transforms and ~60 small array loops per step on one core.  Here one step is FOUR
 // launches on the caller's stream and nothing returns to the host:
-//   k_pre       uvspec of the 8 levels + grad(ps) + the state copy, written as ONE 50-field spectral batch
-//   k_grid      (spectral.hip) all 50 inverse transforms, per-field kcos
+//   k_grid      (spectral.hip) all 50 inverse transforms of grtend in one launch; uvspec of the 8 levels and grad(ps) are
+//               evaluated while the spectral fields are staged into LDS (sml_spectral_grid_derived), nothing is materialised
 //   k_gridtend  one thread per grid point walks the 8-level column: means, sigma-dot, u/v/T/q tendencies, the flux
 //               products -> ONE 73-field grid batch
 //   k_spec      (spectral.hip) all 73 forward transforms, per-field 1/cos pre-scaling
@@ -267,37 +267,8 @@ __device__ __forceinline__ void stencil(const double *__restrict__ P, const doub
     }
 }
 
-// k_pre: build the inverse-transform batch from state level j2 (dyn_grtend.f90:61-99).  grid = (ceil(SP/256), 50).
-//   fields 0..31  vor, div, t, tr (copied)            -> grid(.,.,1)
-//   fields 32..39 ucos(k), 40..47 vcos(k) (uvspec)    -> grid(.,.,2)
-//   field 48 d(ps)/dx, 49 d(ps)/dy (grad)             -> grid(.,.,2)
-__global__ __launch_bounds__(256) void k_pre(DevHoriz H, const double *__restrict__ st, double *__restrict__ batch)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (e >= SP) return;
-    const int c = e % MX2, n = e / MX2, m = c >> 1;
-    double out;
-    if (f < 32) {
-        out = st[(size_t)f * SP + e];
-    } else if (f < 48) {
-        const int k = (f - 32) & 7;
-        const double *vor = st + (size_t)(F_VOR + k) * SP, *div = st + (size_t)(F_DIV + k) * SP;
-        double a, b;
-        stencil(vor, div, n, c, H.uvdx[n * MX + m], H.uvdym[n * MX + m], H.uvdyp[n * MX + m], a, b);
-        out = f < 40 ? a : b;
-    } else {
-        const double *ps = st + (size_t)F_PS * SP;
-        const int row = n * MX2;
-        if (f == 48) out = irot(ps, row, c, H.gradx[m]);
-        else if (n == 0) out = H.gradyp[m] * ps[row + MX2 + c];
-        else if (n == NX - 1) out = -H.gradym[n * MX + m] * ps[row - MX2 + c];
-        else out = -H.gradym[n * MX + m] * ps[row - MX2 + c] + H.gradyp[n * MX + m] * ps[row + MX2 + c];
-    }
-    batch[(size_t)f * SP + e] = out;
-}
-
 // k_gridtend: grid-point tendencies (dyn_grtend.f90:80-216 and the flux products of :237-276), one thread per grid point.
-// Input batch G[50][48][96] as k_pre orders it.  Output batch O[73][48][96]:
+// Input batch G[50][48][96]: vor div t tr (8 levels each) | u(8) | v(8) | d(ps)/dx | d(ps)/dy.  Output batch O[73][48][96]:
 //   0..7 utend   8..15 vtend   16..23 -u*T'   24..31 -v*T'   32..39 -u*q   40..47 -v*q      (forward transform pre-scaled
 //   by 1/cos: the specx halves of vdspec(.,.,2))      48..55 (u^2+v^2)/2   56..63 ttend   64..71 qtend   72 ps tendency
 __global__ __launch_bounds__(64) void k_gridtend(DevHoriz H, LevelTables L, const double *__restrict__ G, double *__restrict__ O)
@@ -553,11 +524,10 @@ struct sml_dyn {
     ImpSlot *cur = nullptr;
     double *bc = nullptr;              // phis | tcorh | qcorh  (3 x SP)
     double *own_state = nullptr;       // [2][33][SP] for hosts that keep the state in Fortran arrays (sml_dyn_*_host)
-    double *batch_spec = nullptr;      // [50][SP]
     double *batch_grid = nullptr;      // [50][GR]
     double *tend_grid = nullptr;       // [73][GR]
     double *tend_spec = nullptr;       // [73][SP]
-    int32_t *kcos = nullptr, *scale = nullptr;
+    int32_t *desc = nullptr, *scale = nullptr;     // inverse-batch descriptors [50][4], forward-batch scaling flags [73]
 };
 
 namespace {
@@ -583,9 +553,8 @@ int fetch_table(sml_dyn *d, int which, const double **dst, std::vector<double> &
 int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend, double *tend_out, hipStream_t st)
 {
     const double *sj2 = state + (size_t)(a.j2 - 1) * NSTATE * SP;
-    hipLaunchKernelGGL(k_pre, dim3((SP + 255) / 256, NB_SPEC), dim3(256), 0, st, d->d, sj2, d->batch_spec);
-    SML_HIP(hipGetLastError());
-    int rc = sml_spectral_grid_mixed(d->sp, d->batch_spec, d->batch_grid, NB_SPEC, d->kcos, st);
+    // the 50 inverse transforms of grtend (:61-99) straight from the state: uvspec and grad are formed while the fields are staged
+    int rc = sml_spectral_grid_derived(d->sp, sj2, d->desc, d->batch_grid, NB_SPEC, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gridtend, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid);
     SML_HIP(hipGetLastError());
@@ -641,16 +610,20 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
     auto zeros = [&](double **p, size_t n) { int r = sml::dev_zeros(p, n); if (!r) d->allocs.push_back(*p); return r; };
     if (!rc) rc = zeros(&d->bc, (size_t)3 * SP);
     if (!rc) rc = zeros(&d->own_state, (size_t)2 * NSTATE * SP);
-    if (!rc) rc = zeros(&d->batch_spec, (size_t)NB_SPEC * SP);
     if (!rc) rc = zeros(&d->batch_grid, (size_t)NB_SPEC * GR);
     if (!rc) rc = zeros(&d->tend_grid, (size_t)NB_GRID * GR);
     if (!rc) rc = zeros(&d->tend_spec, (size_t)NB_GRID * SP);
     if (!rc) {
-        int32_t kc[NB_SPEC], sc[NB_GRID];
-        for (int f = 0; f < NB_SPEC; ++f) kc[f] = f < 32 ? 1 : 2;
+        int32_t kc[NB_SPEC][4], sc[NB_GRID];
+        for (int f = 0; f < NB_SPEC; ++f) {        // (type, src0, src1, kcos), see sml_spectral_grid_derived
+            const int k = f & 7;
+            if (f < 32) { kc[f][0] = 0; kc[f][1] = kc[f][2] = f; kc[f][3] = 1; }                              // vor div t tr: grid(.,.,1)
+            else if (f < 48) { kc[f][0] = f < 40 ? 1 : 2; kc[f][1] = F_VOR + k; kc[f][2] = F_DIV + k; kc[f][3] = 2; }   // u, v
+            else { kc[f][0] = f == 48 ? 3 : 4; kc[f][1] = kc[f][2] = F_PS; kc[f][3] = 2; }                     // grad(ps)
+        }
         for (int f = 0; f < NB_GRID; ++f) sc[f] = f < 48 ? 1 : 0;      // vdspec(.,.,2) scales by cosgr (src/spe_spectral.f90:429-443)
-        rc = sml::dev_upload(&d->kcos, kc, NB_SPEC);
-        if (!rc) { d->allocs.push_back(d->kcos); rc = sml::dev_upload(&d->scale, sc, NB_GRID); }
+        rc = sml::dev_upload(&d->desc, &kc[0][0], NB_SPEC * 4);
+        if (!rc) { d->allocs.push_back(d->desc); rc = sml::dev_upload(&d->scale, sc, NB_GRID); }
         if (!rc) d->allocs.push_back(d->scale);
     }
     if (rc) { sml_dyn_destroy(d); return rc; }

@@ -158,10 +158,42 @@ constexpr int MG = 4;                   // zonal wavenumbers per workgroup (forw
 constexpr int NMG = (MX + MG - 1) / MG; // 8 workgroups per field
 
 // inverse transform: vorm[32][62] -> vorg[48][96]; workgroup = (field, group of LATG latitude pairs)
+// (i g z): (re,im) -> (-g im, g re)
+__device__ __forceinline__ double irot(const double *a, int base, int c, double g)
+{
+    return (c & 1) ? g * a[base + c - 1] : -g * a[base + c + 1];
+}
+
+// One spectral coefficient of a DERIVED field, so that uvspec / grad need not be materialised before their inverse
+// transform (sml_spectral_grid_derived).  type 1 | 2: ucos | vcos of (vor = P, div = Q), uvspec :351-387;
+// type 3 | 4: d/dx | d/dy of P, grad :271-305.  Same expressions, in the same order, as k_uvvds / k_grad below.
+__device__ __forceinline__ double derived_coeff(const DevTables &T, int type, const double *__restrict__ P, const double *__restrict__ Q, int n, int c)
+{
+    const int m = c >> 1, row = n * MX2;
+    if (type <= 2) {
+        const double gx = T.uvdx[n * MX + m];
+        const double *ym = T.uvdym, *yp = T.uvdyp;
+        if (type == 1) {
+            if (n == 0) return irot(Q, row, c, gx) - yp[m] * P[row + MX2 + c];
+            if (n == NX - 1) return ym[n * MX + m] * P[row - MX2 + c];
+            return ym[n * MX + m] * P[row - MX2 + c] - yp[n * MX + m] * P[row + MX2 + c] + irot(Q, row, c, gx);
+        }
+        if (n == 0) return irot(P, row, c, gx) + yp[m] * Q[row + MX2 + c];
+        if (n == NX - 1) return -ym[n * MX + m] * Q[row - MX2 + c];
+        return -ym[n * MX + m] * Q[row - MX2 + c] + yp[n * MX + m] * Q[row + MX2 + c] + irot(P, row, c, gx);
+    }
+    if (type == 3) return irot(P, row, c, T.gradx[m]);
+    if (n == 0) return T.gradyp[m] * P[row + MX2 + c];
+    if (n == NX - 1) return -T.gradym[n * MX + m] * P[row - MX2 + c];
+    return -T.gradym[n * MX + m] * P[row - MX2 + c] + T.gradyp[n * MX + m] * P[row + MX2 + c];
+}
+
 constexpr int TG = 512;     // phase ablation: staging+launch floor 6.7 us, Legendre 2.6 us, Fourier 6.5 us at 256 threads (two
                             // rounds of the 392 Fourier items); 512 threads do them in one round
+// desc (optional): int32 [nf][4] = (type, src0, src1, kcos) per output field; type 0 = field src0 of vorm as it is,
+// 1..4 = derived_coeff of fields src0 (P) and src1 (Q)
 __global__ __launch_bounds__(TG) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos_all,
-                                              const int *__restrict__ kcos_of_field)
+                                              const int *__restrict__ kcos_of_field, const int *__restrict__ desc)
 {
     __shared__ double sv[SPEC_N];              // spectral coefficients
     __shared__ double sp[LATG][NX][MX];        // this workgroup's slab of the Legendre table (31 KB), staged with sv
@@ -169,11 +201,17 @@ __global__ __launch_bounds__(TG) void k_grid(DevTables T, const double *__restri
     __shared__ double stc[IX], sts[IX];
     __shared__ int snsh[NX];
     const int f = blockIdx.x / NLG, lg = blockIdx.x % NLG;
-    const int kcos = kcos_of_field ? kcos_of_field[f] : kcos_all;
-    const double *v = vorm + (size_t)f * SPEC_N;
+    int kcos = kcos_of_field ? kcos_of_field[f] : kcos_all, type = 0, src0 = f, src1 = f;
+    if (desc) { type = desc[4 * f]; src0 = desc[4 * f + 1]; src1 = desc[4 * f + 2]; kcos = desc[4 * f + 3]; }
+    const double *v = vorm + (size_t)src0 * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
     // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
-    for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = v[i];
+    if (type == 0) {
+        for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = v[i];
+    } else {
+        const double *q = vorm + (size_t)src1 * SPEC_N;
+        for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, type, v, q, i / MX2, i % MX2);
+    }
     {
         const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
         double *pl = &sp[0][0][0];
@@ -310,12 +348,6 @@ __global__ void k_scale(DevTables T, const double *__restrict__ in, double *__re
     if (op == OP_LAP) out[t] = -x * T.el2[n * MX + m];
     else if (op == OP_INVLAP) out[t] = -x * T.elm2[n * MX + m];
     else out[t] = x * T.trfilt[n * MX + m];
-}
-
-// (i g z): (re,im) -> (-g im, g re)
-__device__ __forceinline__ double irot(const double *a, int base, int c, double g)
-{
-    return (c & 1) ? g * a[base + c - 1] : -g * a[base + c + 1];
 }
 
 // uvspec (:351-387) and vds (:307-349) share one stencil:  A = ym*P(n-1) - yp*P(n+1) + i x Q ; B = -ym*Q(n-1) + yp*Q(n+1) + i x P
@@ -483,7 +515,7 @@ int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf
 {
     SML_REQUIRE(sp && nf >= 0 && (kcos == 1 || kcos == 2) && (nf == 0 || (vorm && vorg)), "sml_spectral_grid: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr, (const int *)nullptr);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
@@ -499,7 +531,17 @@ int sml_spectral_grid_mixed(sml_spectral *sp, const double *vorm, double *vorg, 
 {
     SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg && kcos_dev)), "sml_spectral_grid_mixed: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev, (const int *)nullptr);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_grid_derived(sml_spectral *sp, const double *spec_base, const int32_t *desc_dev, double *vorg, int nf, void *stream)
+{
+    SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (spec_base && desc_dev && vorg)), "sml_spectral_grid_derived: bad arguments");
+    if (!nf) return SML_OK;
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, spec_base, vorg, 1, (const int *)nullptr,
+                       (const int *)desc_dev);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }

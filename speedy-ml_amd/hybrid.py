@@ -158,7 +158,11 @@ class HybridRank:
             self.fields_out = torch.zeros((33, IL, IX), dtype=f64, device=dev)
             # SPEEDY's prognostic state, both leapfrog levels: [2][vor(8) | div(8) | t(8) | q(8) | ps] (mod_dynvar.f90)
             self.state = torch.zeros((2, NSTATE, NX, MX2), dtype=f64, device=dev)
-            self.uv = torch.zeros((16, NX, MX2), dtype=f64, device=dev)
+            # iogrid(31)'s inverse transforms in one launch: [t | u v (uvspec of vor, div) | q | ps] (see Spectral.grid_derived)
+            rows = ([(0, F_T + k, F_T + k, 1) for k in range(8)] + [(1, F_VOR + k, F_DIV + k, 2) for k in range(8)]
+                    + [(2, F_VOR + k, F_DIV + k, 2) for k in range(8)] + [(0, F_TR + k, F_TR + k, 1) for k in range(8)]
+                    + [(0, F_PS, F_PS, 1)])
+            self.out_desc = torch.tensor(rows, dtype=torch.int32, device=dev)
             self.safe = torch.ones(1, dtype=torch.int32, device=dev)
             self.dyn = Dynamics(self.sp)
             # boundary fields: surface geopotential and the diffusion correction terms (ini_fordate.f90:72-113); the
@@ -209,11 +213,7 @@ class HybridRank:
 
     def to_grid(self, stream):
         """uvspec -> grid(.,2) for u,v ; grid(.,1) for t, q, ps  (src/ppo_iogrid.f90:549-561 and 582-593)"""
-        sp, S = self.sp, self.state[0]
-        sp.uvspec(S[F_VOR:F_VOR + 8], S[F_DIV:F_DIV + 8], out=(self.uv[0:8], self.uv[8:16]), stream=stream)
-        sp.grid(self.uv, 2, out=self.fields_out[8:24], stream=stream)
-        sp.grid(S[F_T:F_T + 8], 1, out=self.fields_out[0:8], stream=stream)
-        sp.grid(S[F_TR:F_PS + 1], 1, out=self.fields_out[24:33], stream=stream)
+        self.sp.grid_derived(self.state[0], self.out_desc, out=self.fields_out, stream=stream)
 
     def handoff_out(self, stream):
         """iogrid(31) (src/ppo_iogrid.f90:579-601): spectral time level 1 -> the SPEEDY forecast grids F"""

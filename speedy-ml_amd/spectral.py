@@ -73,6 +73,17 @@ class Spectral:
                                                  _lib.ip(kcos_flags.data_ptr()), vp(stream)))
         return out
 
+    def grid_derived(self, base, desc, out=None, stream=None):
+        """Inverse transforms of derived fields in one launch: desc is an int32 device tensor [nf, 4] of
+        (type, src0, src1, kcos) rows indexing the fields of `base` ([., 32, 62]); type 0 plain, 1|2 ucos|vcos of
+        uvspec(src0, src1), 3|4 d/dx|d/dy of grad(src0)."""
+        self._chk(base, (NX, MX2))
+        nf = desc.shape[0]
+        assert desc.is_cuda and desc.element_size() == 4 and desc.is_contiguous() and tuple(desc.shape) == (nf, 4)
+        out = self._new(base, nf, (IL, IX)) if out is None else out
+        check(_lib.lib().sml_spectral_grid_derived(self._h, dp(base.data_ptr()), _lib.ip(desc.data_ptr()), dp(out.data_ptr()), nf, vp(stream)))
+        return out
+
     def spec_mixed(self, vorg, scale_flags, out=None, stream=None):
         """One launch for fields with different forward pre-scaling (0 none, 1 *cosgr, 2 *cosgr2 per field)."""
         nf = self._chk(vorg, (IL, IX))

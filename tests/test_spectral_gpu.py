@@ -180,3 +180,24 @@ def test_mixed_flag_launches_match_separate_launches(sp):
     a = sp.spec_mixed(g, torch.ones(6, dtype=torch.int32, device="cuda"))
     vor2, div2 = sp.vds(a, sp.spec(zero))
     assert torch.equal(vor, vor2) and torch.equal(div, div2)
+
+
+def test_grid_derived_equals_separate_operators(sp):
+    """uvspec / grad folded into the inverse transform's staging give the same bits as uvspec / grad followed by grid."""
+    rng = np.random.default_rng(11)
+    base = torch.from_numpy(rng.standard_normal((6, NX, MX2))).cuda()
+    sp.trunct(base)
+    rows = [(0, 2, 2, 1), (1, 0, 1, 2), (2, 0, 1, 2), (3, 4, 4, 2), (4, 4, 4, 2), (0, 5, 5, 2), (2, 3, 2, 1), (1, 5, 0, 2)]
+    desc = torch.tensor(rows, dtype=torch.int32, device="cuda")
+    got = sp.grid_derived(base, desc)
+    for f, (typ, a, b, kcos) in enumerate(rows):
+        if typ == 0:
+            src = base[a:a + 1]
+        elif typ in (1, 2):
+            u, v = sp.uvspec(base[a:a + 1].contiguous(), base[b:b + 1].contiguous())
+            src = u if typ == 1 else v
+        else:
+            dx, dy = sp.grad(base[a:a + 1].contiguous())
+            src = dx if typ == 3 else dy
+        want = sp.grid(src.contiguous(), kcos)
+        assert torch.equal(got[f], want[0]), (f, typ)
