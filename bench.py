@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--mode", default="hybrid", choices=["hybrid", "sweep"],
                     help="sweep = reservoir predict sweep only (development aid; the driver uses the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab", action="store_true", help="BASELINE config 5: add the 1152-region slab-ocean reservoirs and their coupling")
     ap.add_argument("--regions", type=int, default=1152, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -73,7 +74,7 @@ def main():
     # "Software pipeline"): measured +6 % only, because the latency-bound SPEEDY kernels slow down 2x next to an
     # HBM-saturating stream; the default is the reference's sequential order.
     model = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode=args.mode,
-                              pipeline=os.environ.get("SML_PIPELINE", "0") == "1")
+                              pipeline=os.environ.get("SML_PIPELINE", "0") == "1", slab=args.slab)
     if rank == 0:
         print(f"[bench] rank0 loaded {len(regions)} reservoirs in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
 

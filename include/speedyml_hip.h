@@ -210,6 +210,33 @@ int sml_handoff_to_fields(const double *g_dev, double *fields_dev, void *stream)
 int sml_handoff_from_fields(const double *fields_dev, double *f_dev, void *stream);
 int sml_handoff_check(const double *fields_dev, int32_t *safe_dev, void *stream);
 
+/* ---- slab-ocean coupling (config 5): the `ocean_model` branches of sendrecievegrid, src/mpires.f90:286-330, 470-484,
+ * 756-790; sizes of initialize_slab_ocean_model, src/mod_slab_ocean_reservoir.f90:9-133.  The slab reservoirs live in a second
+ * sml_bank (n_model = 0, every output un-standardised with the SST statistics as predict_slab_ml does, :1318-1363) and are
+ * stepped with sml_bank_predict_all every timestep_slab/timestep-th atmosphere step (src/parallelmain.f90:237-249). */
+typedef struct sml_slab sml_slab;
+/* d, n, k, chunk sizes and the input segment offsets of a region's slab reservoir (m = 4000, deg = 6 as shipped) */
+int sml_slab_sizes(const sml_region *g, int m, int deg, int local_predictvars, sml_res_sizes *out);
+/* sea_of_slot: sst_bool_prediction per slot; atmo_sst_input_of_slot as given to sml_exchange_create; ring = timestep_slab/timestep - 1 */
+int sml_slab_create(sml_bank *atmo_bank, sml_bank *slab_bank, int number_of_regions, const int32_t *region_of_slot, int nslots,
+                    const int32_t *sea_of_slot, const int32_t *atmo_sst_input_of_slot, int ring, sml_slab **out);
+int sml_slab_destroy(sml_slab *slab);
+/* wholegrid_sst before the mask and floor: region r writes its res patch from all_slab_out[r][0:resx*resy] (REGION order,
+ * stride out_stride) if sea_of_region[r], 272 K otherwise (src/mpires.f90:309-330).  Call it BEFORE sml_exchange_scatter,
+ * whose SST kernel then restores base_sst where sea_mask > 0 and applies the 272 K floor (:470-484). */
+int sml_slab_scatter_sst(sml_slab *slab, const double *all_slab_out_dev, int out_stride, const int32_t *sea_of_region_dev, double *g_dev,
+                         void *stream);
+/* after sml_exchange_gather: ring column (timestep-1) mod ring <- atmo_training_data_idx entries of the atmosphere feedback;
+ * slab feedback <- mean of the ring columns (src/mpires.f90:776-781).  timestep is sendrecievegrid's 1-based step. */
+int sml_slab_update_inputs(sml_slab *slab, int timestep, void *stream);
+
+/* The hybrid's calendar (src/mod_calendar.f90:24-175) and the TISR slice it selects (get_tisr_by_date,
+ * src/mpires.f90:1676-1708): integer bookkeeping, quirks included.  sml_tisr_index returns the 1-based slice (1..8760) of
+ * the hour-of-365-day-year table for `hours_elapsed` since 1 January `startyear` 00h (the reference starts at 1981). */
+int sml_calendar_date(int startyear, int hours_elapsed, int32_t *date_out /* year, month, day, hour */);
+int sml_hours_into_year(int year, int month, int day, int hour);
+int sml_tisr_index(int startyear, int hours_elapsed);
+
 /* ===================================================================================================
  * 4. spectral transforms -- replaces src/spe_spectral.f90 + src/spe_subfft_fftpack.f90 (FFTPACK)
  * =================================================================================================== */

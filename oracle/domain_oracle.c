@@ -377,3 +377,81 @@ double rd_get_radius_by_lat(double startlat, double endlat)
     if (smallest_lat >= highest_lat) return max_radius;
     return (max_radius - min_radius) / highest_lat + min_radius;
 }
+
+/* ---- the hybrid's calendar (src/mod_calendar.f90) ---- */
+static int rd_leap(int y) { return ((y % 4 == 0) && (y % 100 != 0)) || (y % 400 == 0); }      /* leap_year_check :93-105 */
+
+/* get_current_time_delta_hour :24-91 -> date[4] = year, month, day, hour */
+void rd_calendar_date(int startyear, int hours_elapsed, int *date)
+{
+    int ncal365[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    int years_elasped = hours_elapsed / 8760;
+    int currentyear = years_elasped + startyear;
+    int leap_days = 0;
+    for (int i = 0; i <= years_elasped - 1; ++i) if (rd_leap(startyear + i)) leap_days = leap_days + 1;
+    int day_of_year = ((hours_elapsed % 8760) / 24) - leap_days;
+    if (rd_leap(currentyear)) ncal365[1] = 29;
+    int day_while_counter = day_of_year, month = 1;
+    while (day_while_counter > 0) {
+        day_while_counter = day_while_counter - ncal365[month - 1];
+        month = month + 1;
+    }
+    month = month - 1;
+    if (month <= 0) { month = 12; currentyear = currentyear - 1; }
+    date[0] = currentyear; date[1] = month; date[2] = ncal365[month - 1] + day_while_counter; date[3] = hours_elapsed % 24;
+}
+
+/* numof_hours_into_year :133-175 */
+int rd_hours_into_year(int year, int month, int day, int hour)
+{
+    static const int ncal365[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    static const int ncal_leap[12] = {31, 29, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    int numofhours = 0;
+    if (month > 1) for (int i = 1; i <= month - 1; ++i) numofhours += 24 * (rd_leap(year) ? ncal_leap[i - 1] : ncal365[i - 1]);
+    if (day > 1) for (int i = 1; i <= day - 1; ++i) numofhours += 24;
+    numofhours = numofhours + hour;
+    if (numofhours == 0) numofhours = 1;
+    return numofhours;
+}
+
+/* get_tisr_by_date, src/mpires.f90:1695-1704 */
+int rd_tisr_index(int startyear, int hours_elapsed)
+{
+    int d[4];
+    rd_calendar_date(startyear, hours_elapsed, d);
+    int idx = rd_hours_into_year(d[0], d[1], d[2], d[3]);
+    if (idx > 24 * 365) idx = idx - 24 * 365;
+    return idx;
+}
+
+/* ---- slab-ocean coupling (src/mpires.f90:286-330, 470-484, 776-781) ---- */
+/* wholegrid_sst (96 x 48, [y][x] as G stores it): base, then every region's res patch (slab outvec or 272), then the mask
+ * rule and the 272 K floor.  res_cell[r*4+j] = y*96+x of output j of region r (tile_full_2d_grid_with_local_res). */
+void rd_slab_sst(int nreg, const double *base_sst, const int *sea_mask_gt0, const int *sea_of_region, const int *res_cell,
+                 const double *all_slab_out, int out_stride, double *sst)
+{
+    for (int c = 0; c < RD_GRIDNUM; ++c) sst[c] = base_sst[c];
+    for (int r = 0; r < nreg; ++r)
+        for (int j = 0; j < 4; ++j) {
+            int cell = res_cell[r * 4 + j];
+            if (cell < 0) continue;
+            sst[cell] = sea_of_region[r] ? all_slab_out[(size_t)r * out_stride + j] : 272.0;
+        }
+    for (int c = 0; c < RD_GRIDNUM; ++c) {
+        if (sea_mask_gt0[c]) sst[c] = base_sst[c];
+        if (sst[c] < 272.0) sst[c] = 272.0;
+    }
+}
+
+/* averaged_atmo_input_vec(:, mod(timestep-1, R)+1) = feedback_atmo(atmo_training_data_idx); feedback_slab = sum(ring, dim=2)/R.
+ * idx: nidx 0-based positions; ring: [R][nidx]; slab feedback entries [0, nidx) are overwritten, the rest is left alone. */
+void rd_slab_ring_update(int timestep, int R, int nidx, const int *idx, const double *feedback_atmo, double *ring, double *feedback_slab)
+{
+    int col = (timestep - 1) % R;
+    for (int j = 0; j < nidx; ++j) ring[(size_t)col * nidx + j] = feedback_atmo[idx[j]];
+    for (int j = 0; j < nidx; ++j) {
+        double s = 0.0;
+        for (int c = 0; c < R; ++c) s = s + ring[(size_t)c * nidx + j];
+        feedback_slab[j] = s / (double)R;
+    }
+}

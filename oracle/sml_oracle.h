@@ -113,6 +113,16 @@ void rd_unstandardize_res(const rd_grid *g, int local_predictvars, int heightlev
                           int logp_idx, int precip_idx, const double *mean, const double *std, double *state_vec); /* :1424-1475 */
 double rd_get_radius_by_lat(double startlat, double endlat);       /* :1630-1660 */
 
+/* slab-ocean coupling of sendrecievegrid (src/mpires.f90:286-330, 470-484, 776-781) */
+void rd_slab_sst(int nreg, const double *base_sst, const int *sea_mask_gt0, const int *sea_of_region, const int *res_cell,
+                 const double *all_slab_out, int out_stride, double *sst);
+void rd_slab_ring_update(int timestep, int R, int nidx, const int *idx, const double *feedback_atmo, double *ring, double *feedback_slab);
+
+/* the hybrid's calendar (src/mod_calendar.f90:24-175) and get_tisr_by_date's slice index (src/mpires.f90:1695-1704) */
+void rd_calendar_date(int startyear, int hours_elapsed, int *date /* year, month, day, hour */);
+int  rd_hours_into_year(int year, int month, int day, int hour);
+int  rd_tisr_index(int startyear, int hours_elapsed);
+
 /* ---------------- reservoir (src/mod_reservoir.f90, src/mod_linalg.f90) ---------------- */
 /* y = beta*y + alpha*A*x with A in 1-based COO, entries applied in storage order (MKL_SPARSE_D_MV semantics as
  * used at mod_reservoir.f90:1444 with alpha=1,beta=0; duplicates accumulate). */

@@ -277,4 +277,52 @@ int sml_find_closest_divisor(int target, int number)
             if (i > 0 && number % i == 0) return i;
 }
 
+// The hybrid's own calendar (src/mod_calendar.f90), integer bookkeeping reproduced statement by statement, quirks included
+// (8760-hour years when counting years elapsed, leap days subtracted from the day of the year, day-of-year 0 mapping to
+// 31 December of the previous year).  date_out = (year, month, day, hour).
+static bool leap(int y) { return (y % 4 == 0 && y % 100 != 0) || y % 400 == 0; }          // leap_year_check :93-105
+
+int sml_calendar_date(int startyear, int hours_elapsed, int32_t *date_out)
+{   // get_current_time_delta_hour (src/mod_calendar.f90:24-91)
+    SML_REQUIRE(date_out && hours_elapsed >= 0, "sml_calendar_date: bad arguments");
+    int ncal[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    const int years = hours_elapsed / 8760;
+    int year = years + startyear, leap_days = 0;
+    for (int i = 0; i < years; ++i) leap_days += leap(startyear + i);
+    const int day_of_year = (hours_elapsed % 8760) / 24 - leap_days;
+    if (leap(year)) ncal[1] = 29;
+    int counter = day_of_year, month = 1;
+    while (counter > 0) {
+        SML_REQUIRE(month <= 12, "sml_calendar_date: the reference's month loop runs off its table for hours_elapsed=%d", hours_elapsed);
+        counter -= ncal[month - 1];
+        ++month;
+    }
+    --month;
+    if (month <= 0) { month = 12; --year; }
+    date_out[0] = year; date_out[1] = month; date_out[2] = ncal[month - 1] + counter; date_out[3] = hours_elapsed % 24;
+    return SML_OK;
+}
+
+int sml_hours_into_year(int year, int month, int day, int hour)
+{   // numof_hours_into_year (src/mod_calendar.f90:133-175)
+    static const int c365[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31}, cleap[12] = {31, 29, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    SML_REQUIRE(month >= 1 && month <= 12, "sml_hours_into_year: month %d", month);
+    int h = 0;
+    for (int i = 0; i < month - 1; ++i) h += 24 * (leap(year) ? cleap[i] : c365[i]);
+    if (day > 1) h += 24 * (day - 1);
+    h += hour;
+    return h == 0 ? 1 : h;
+}
+
+int sml_tisr_index(int startyear, int hours_elapsed)
+{   // get_tisr_by_date (src/mpires.f90:1676-1708): 1-based slice of full_tisr(:,:,8760)
+    int32_t d[4];
+    int rc = sml_calendar_date(startyear, hours_elapsed, d);
+    if (rc) return rc;
+    int idx = sml_hours_into_year(d[0], d[1], d[2], d[3]);
+    if (idx < 0) return idx;
+    if (idx > 24 * 365) idx -= 24 * 365;
+    return idx;
+}
+
 }  // extern "C"

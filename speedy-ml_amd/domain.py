@@ -53,3 +53,15 @@ def in_map(num_regions, region_num, overlap=1, num_vert_levels=1, vert_level=1, 
     n = check(_lib.lib().sml_domain_in_map(int(num_regions), int(region_num), overlap, num_vert_levels, vert_level, vert_overlap,
                                            int(precip_bool), int(sst_bool_input), int(tisr_input_bool), ip(gi), ip(si), cap))
     return gi[:n].copy(), si[:n].copy()
+
+
+def calendar_date(hours_elapsed, startyear=1981):
+    """get_current_time_delta_hour (src/mod_calendar.f90:24-91): (year, month, day, hour)."""
+    out = np.zeros(4, dtype=np.int32)
+    check(_lib.lib().sml_calendar_date(int(startyear), int(hours_elapsed), ip(out)))
+    return tuple(int(v) for v in out)
+
+
+def tisr_index(hours_elapsed, startyear=1981):
+    """get_tisr_by_date (src/mpires.f90:1676-1708): 1-based slice of the 8760-hour TISR table."""
+    return check(_lib.lib().sml_tisr_index(int(startyear), int(hours_elapsed)))

@@ -119,7 +119,8 @@ class HybridRank:
     """All state of one rank for the device-resident step loop."""
 
     def __init__(self, regions, classes, world=1, rank=0, sea_mask=None, mode="hybrid", seed=20240000, n_override=None,
-                 leapfrog_steps=LEAPFROG_PER_WINDOW, physical=True, pipeline=False, persistent_readout=True, drain_readout=True):
+                 leapfrog_steps=LEAPFROG_PER_WINDOW, physical=True, pipeline=False, persistent_readout=True, drain_readout=True,
+                 start_hours=12000 + 24 * 14, slab=False):
         import torch
         self.torch = torch
         self.regions, self.classes, self.world, self.rank, self.mode = list(regions), classes, world, rank, mode
@@ -141,13 +142,18 @@ class HybridRank:
         self.G[domain.G2_OFF:domain.GP_OFF] = torch.from_numpy(logp.ravel()).to(dev)
         self.G[domain.GP_OFF:domain.GS_OFF] = torch.from_numpy(precip.ravel()).to(dev)
         self.G[domain.GS_OFF:domain.GT_OFF] = self.base_sst
-        # TISR table: one (96,48) slice per 6-h step of a 365-day year (full_tisr, src/mod_reservoir.f90:890-909)
+        # TISR table: one (96,48) slice per hour of a 365-day year (full_tisr, src/mod_reservoir.f90:890-909); the slice of a
+        # step is chosen by the hybrid's calendar exactly as get_tisr_by_date does (src/mpires.f90:1676-1708)
         lat = np.deg2rad(np.linspace(-87.159, 87.159, 48))[None, :, None]
         lon = np.deg2rad(np.arange(96) * 3.75)[None, None, :]
-        hours = (np.arange(1460) * 6.0)[:, None, None]
+        hours = np.arange(8760, dtype=np.float64)[:, None, None]
         decl = np.deg2rad(23.44) * np.sin(2 * np.pi * (hours / 24.0 - 80.0) / 365.0)
         cosz = np.sin(lat) * np.sin(decl) + np.cos(lat) * np.cos(decl) * np.cos(2 * np.pi * hours / 24.0 + lon - np.pi)
-        self.tisr = torch.from_numpy(np.maximum(0.0, cosz) * 1361.0 * 3600.0).to(dev).contiguous()   # [1460][48][96]
+        self.tisr = torch.from_numpy(np.maximum(0.0, cosz) * 1361.0 * 3600.0).to(dev).contiguous()   # [8760][48][96]
+        # hours since 1 Jan 1981 00h at the first prediction step: traininglength + prediction marker + synclength of the
+        # shipped configuration (src/mod_reservoir.f90:40-78: 12000-h training window given in hours, 14-day sync)
+        self.start_hours = start_hours
+        self.timestep_hours = 6
         self.t = 0
         if mode == "hybrid":
             sst_flags = [int(classes[r][1]) for r in self.regions]
@@ -173,8 +179,11 @@ class HybridRank:
             self.phis, self.tcorh, self.qcorh = bc[0].contiguous(), bc[1].contiguous(), torch.zeros((NX, MX2), dtype=f64, device=dev)
             self.dyn.set_boundary(self.phis, self.tcorh, self.qcorh)
             self.even_split = (NREG % world == 0)
+            self.slab = None
+            if slab:
+                self.init_slab(classes, sea_mask, seed, n_override, physical)
             # first inputs: gather from the synthetic state (forecast = the same state) so feedback is realistic
-            self.G[domain.GT_OFF:] = self.tisr[0].reshape(-1)
+            self.G[domain.GT_OFF:] = self.tisr_slice(0).reshape(-1)
             self.ex.gather(self.G, self.G)
             if self.pipeline:
                 # Software pipeline (see step()): the reservoir advance and the state block of the readout of step t+1 run on a
@@ -189,6 +198,79 @@ class HybridRank:
             self.feedback.copy_(torch.from_numpy(rng.standard_normal((cap, self.bank.max_d))))
             self.local_model.copy_(torch.from_numpy(rng.standard_normal((cap, self.bank.max_n_model))))
         torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ slab ocean (BASELINE config 5)
+    def init_slab(self, classes, sea_mask, seed, n_override, physical):
+        """One slab-ocean reservoir per region that predicts SST (src/mod_slab_ocean_reservoir.f90:9-133: inputs = 27-step mean of
+        the lowest-level atmosphere inputs + logp + SST + TISR, plus an OHTC patch; outputs SST and OHTC of the 2x2 res patch)."""
+        import torch
+        from .slab import SLAB_RADIUS, SLAB_SIGMA, SlabCoupler, slab_sizes
+        dev = "cuda"
+        sea_slot = [int(classes[r][1]) for r in self.regions]
+        self.sea_of_region = torch.tensor([int(c[1]) for c in classes], dtype=torch.int32, device=dev)
+        # the SST kernel restores base_sst where sea_mask > 0 (src/mpires.f90:470-478): the reference's mask marks land
+        land = (1 - np.asarray(sea_mask, dtype=np.int32)) if sea_mask is not None else np.zeros((48, 96), dtype=np.int32)
+        self.sst_mask = torch.from_numpy(np.ascontiguousarray(land.reshape(-1))).to(dev)
+        sizes = [slab_sizes(domain.initializedomain(NREG, r)) for r in self.regions]
+        max_d = max(s.reservoir_numinputs for s in sizes)
+        max_out = max(s.chunk_size_prediction for s in sizes)
+        self.slab_bank = ReservoirBank(len(self.regions), max_d=max_d, max_n_model=1, max_n_out=max_out)
+        base = {}
+        for slot, r in enumerate(self.regions):
+            if not sea_slot[slot]:
+                continue
+            s = sizes[slot]
+            d = s.reservoir_numinputs
+            n = s.n if n_override is None else n_override * d
+            if (n, d) not in base:
+                b = make_reservoir(n=n, d=d, n_model=0, n_out=s.chunk_size_prediction, seed=seed + 500 + len(base), deg=6, m=4000,
+                                   radius=SLAB_RADIUS, sigma=SLAB_SIGMA, dense_win=False)
+                if physical:
+                    b.wout *= 1e-2          # small anomalies around the region's mean SST
+                b.win_rows = np.arange(1, n + 1, dtype=np.int32)
+                b.win_cols = (np.arange(n, dtype=np.int32) // b.win_q + 1).astype(np.int32)
+                base[(n, d)] = b
+            b = base[(n, d)]
+            _, mean, std, _ = self.bank.host_copies[slot]
+            stat = np.full(b.n_out, 35, dtype=np.int32)          # predict_slab_ml un-standardises every output with the SST statistics
+            self.slab_bank.load_sparse_win(slot, b.n, b.d, 0, b.n_out, b.rows, b.cols, b.vals, b.win_rows, b.win_cols, b.win_vals,
+                                           b.wout, mean, std, stat)
+        self.slab_feedback = device_view(self.slab_bank.feedback_ptr, (self.slab_bank.capacity, max_d))
+        self.slab_outvec = device_view(self.slab_bank.outvec_ptr, (self.slab_bank.capacity, max_out))
+        self.slab = SlabCoupler(self.bank, self.slab_bank, NREG, self.regions, sea_slot, [int(classes[r][1]) for r in self.regions])
+        # OHTC input patch: the exchange tiles an all-zero wholegrid_ohtc and standardises it with statistics slot 1
+        # (src/mpires.f90:294-295,730-733; src/mod_slab_ocean_reservoir.f90:349)
+        for slot in range(len(self.regions)):
+            if sea_slot[slot]:
+                _, mean, std, _ = self.bank.host_copies[slot]
+                s = sizes[slot]
+                self.slab_feedback[slot, s.tisr_end:s.reservoir_numinputs] = (0.0 - mean[0]) / std[0]
+        # SST outputs before the first slab prediction: the base SST at the region's res cells (start_prediction_slab takes them
+        # from the synchronisation data)
+        self.all_slab_out = torch.zeros((NREG, max_out), dtype=torch.float64, device=dev)
+        base_sst = self.base_sst.cpu().numpy()
+        rows = np.zeros((NREG, max_out))
+        for r in range(NREG):
+            gmap, _ = domain.out_map(NREG, r)
+            cells = np.asarray(gmap[128:132]) - domain.G2_OFF
+            rows[r, :4] = base_sst[cells]
+        self.all_slab_out.copy_(torch.from_numpy(rows))
+        self.slab_outvec.copy_(self.all_slab_out[torch.as_tensor(self.regions, dtype=torch.long, device=dev)])
+
+    def slab_predict_and_share(self, stream):
+        """predict_slab_ml for every SST-predicting region of the rank, then every rank gets all regions' outputs"""
+        self.slab_bank.predict(stream=stream)
+        if self.world == 1:
+            self.all_slab_out.copy_(self.slab_outvec)
+        else:
+            gather_outvec_slab(self.slab_outvec, self.regions, self.all_slab_out, self.even_split)
+
+    def scatter_all(self, allv, stream):
+        if self.slab is not None:
+            self.slab.scatter_sst(self.all_slab_out, self.sea_of_region, self.G, stream=stream)
+            self.ex.scatter(allv, self.G, base_sst=self.base_sst, sea_mask=self.sst_mask, stream=stream)
+        else:
+            self.ex.scatter(allv, self.G, base_sst=self.base_sst, stream=stream)
 
     # ------------------------------------------------------------------ the step
     def exchange_outvec(self, stream):
@@ -227,9 +309,14 @@ class HybridRank:
             self.dyn.window(self.state, self.leapfrog_steps, start=True, delt=DELT, stream=stream)
         self.handoff_out(stream)
 
+    def tisr_slice(self, timestep):
+        """get_tisr_by_date(timestep): the table slice for `timestep` steps after the start of the prediction"""
+        return self.tisr[domain.tisr_index(self.start_hours + timestep * self.timestep_hours) - 1]
+
     def next_tisr(self):
+        # sendrecievegrid(res, t, ...) fills the next inputs with get_tisr_by_date(timestep - 1) (src/mpires.f90:750)
         self.t += 1
-        self.G[domain.GT_OFF:].copy_(self.tisr[self.t % self.tisr.shape[0]].reshape(-1))
+        self.G[domain.GT_OFF:].copy_(self.tisr_slice(self.t - 1).reshape(-1))
 
     def step(self, stream):
         """One hybrid step.  `stream` must be the current torch stream (the TISR copy and the RCCL exchange are torch ops).
@@ -247,12 +334,17 @@ class HybridRank:
             return
         if not self.pipeline:
             self.bank.predict(stream=stream)
+            if self.slab is not None and self.slab.due(self.t + 1):      # mod(t*timestep, timestep_slab) == 0, parallelmain.f90:238
+                self.slab_predict_and_share(stream)
             allv = self.exchange_outvec(stream)
-            self.ex.scatter(allv, self.G, base_sst=self.base_sst, stream=stream)
+            self.scatter_all(allv, stream)
             self.speedy_leg(stream)
             self.next_tisr()
             self.ex.gather(self.G, self.F, stream=stream)
+            if self.slab is not None:
+                self.slab.update_inputs(self.t, stream=stream)
             return
+        assert self.slab is None, "the pipelined schedule does not carry the slab-ocean coupling"
         stream.wait_event(self.ev_partial)                      # state block of this step's readout (side stream)
         self.bank.readout_part(2, stream=stream)                # + physics-model block -> outvec(t)
         allv = self.exchange_outvec(stream)
@@ -291,6 +383,9 @@ class HybridRank:
                   "+ SPEEDY hand-off iogrid(30)/(31) + one 6-hour SPEEDY window of %d adiabatic time steps (stepone + leapfrog: "
                   "50 inverse + 73 forward transforms, grid-point tendencies, semi-implicit spectral step each) on the device; "
                   "column physics excluded (SURVEY section 8: out of scope)" % nst)
+        if self.mode == "hybrid" and self.slab is not None:
+            wl += ("; + slab-ocean coupling (config 5): SST assembly from the slab reservoirs, 27-step input averaging ring, "
+                   "predict_slab_ml of the SST-predicting regions every 28th step")
         return {"workload": wl, "regions_total": NREG, "regions_this_rank": len(self.regions),
                 "transforms_per_step": (99 + 123 * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
                 "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s); "

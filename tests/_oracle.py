@@ -265,6 +265,29 @@ class Oracle:
                                         model.shape[0], targets.shape[0], _p(np.asfortranarray(model)),
                                         _p(np.asfortranarray(targets)), _p(c), _p(b))
 
+    def slab_sst(self, base_sst, mask_gt0, sea_of_region, res_cell, all_slab_out):
+        nreg = len(sea_of_region)
+        out = np.zeros(4608)
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (mask_gt0, sea_of_region, res_cell)]
+        so = np.ascontiguousarray(all_slab_out, dtype=np.float64)
+        self.lib.rd_slab_sst(nreg, _p(np.ascontiguousarray(base_sst, dtype=np.float64)), _pi(a[0]), _pi(a[1]), _pi(a[2]), _p(so),
+                             so.shape[1], _p(out))
+        return out
+
+    def slab_ring_update(self, timestep, idx, feedback_atmo, ring, feedback_slab):
+        """ring: (R, nidx) C-contiguous float64, updated in place; feedback_slab[:nidx] overwritten in place"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        fa = np.ascontiguousarray(feedback_atmo, dtype=np.float64)
+        self.lib.rd_slab_ring_update(int(timestep), ring.shape[0], len(idx), _pi(idx), _p(fa), _p(ring), _p(feedback_slab))
+
+    def calendar_date(self, hours_elapsed, startyear=1981):
+        d = (C.c_int * 4)()
+        self.lib.rd_calendar_date(int(startyear), int(hours_elapsed), d)
+        return tuple(d)
+
+    def tisr_index(self, hours_elapsed, startyear=1981):
+        return self.lib.rd_tisr_index(int(startyear), int(hours_elapsed))
+
     def find_closest_divisor(self, approx, number):
         return self.lib.ro_find_closest_divisor(approx, number)
 

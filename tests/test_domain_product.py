@@ -114,3 +114,36 @@ def test_message_sizes_and_batch_divisor(oracle):
     for target, number in ((98, 1960), (7, 64), (2920, 58400), (13, 100), (97, 1960)):
         assert _lib.lib().sml_find_closest_divisor(target, number) == oracle.find_closest_divisor(target, number)
     assert _lib.lib().sml_find_closest_divisor(98, 1960) == 98
+
+
+def test_calendar_and_tisr_index_match_oracle(oracle):
+    """get_current_time_delta_hour / numof_hours_into_year / get_tisr_by_date (src/mod_calendar.f90, src/mpires.f90:1676-1708):
+    integer bookkeeping, bit-exact, quirks included."""
+    from speedy_ml_amd import domain
+    rng = np.random.default_rng(5)
+    hours = list(range(0, 24 * 800)) + list(range(0, 45 * 8760, 6))[::7] + [int(h) for h in rng.integers(0, 60 * 8760, 2000)]
+    for h in hours:
+        assert domain.calendar_date(h) == oracle.calendar_date(h), h
+        assert domain.tisr_index(h) == oracle.tisr_index(h), h
+        assert 1 <= domain.tisr_index(h) <= 8760
+    # hand-evaluated from the Fortran: hour 0 is "day 0 of the year" -> 31 December of the previous year, slice 8760;
+    # one year (8760 h) after 1 Jan 1981 the calendar reads 31 Dec 1981; the shipped configuration starts predictions
+    # 12000 + 359*? hours in -- only the arithmetic is checked here
+    assert domain.calendar_date(0) == (1980, 12, 31, 0) and domain.tisr_index(0) == 8760
+    assert domain.calendar_date(24) == (1981, 1, 1, 0) and domain.tisr_index(24) == 1
+    assert domain.calendar_date(25) == (1981, 1, 1, 1) and domain.tisr_index(25) == 1
+    assert domain.calendar_date(24 * 32 + 5) == (1981, 2, 1, 5) and domain.tisr_index(24 * 32 + 5) == 31 * 24 + 5
+    assert domain.calendar_date(8760) == (1981, 12, 31, 0)
+    # 1984 is a leap year: three years in, leap_days is still 0; four years in it is 1
+    assert domain.calendar_date(4 * 8760 + 24 * 60)[0] == 1985
+
+
+def test_slab_sizes_match_survey():
+    """initialize_slab_ocean_model (src/mod_slab_ocean_reservoir.f90:57-124); SURVEY 8a row 11: d=128, n=3968, k=23617, out=8."""
+    from speedy_ml_amd import domain
+    from speedy_ml_amd.slab import slab_sizes
+    s = slab_sizes(domain.initializedomain(1152, 954))
+    assert (s.reservoir_numinputs, s.n, s.k, s.chunk_size_prediction, s.chunk_size, s.chunk_size_speedy, s.nodes_per_input) == (128, 3968, 23617, 8, 8, 0, 31)
+    assert (s.atmo3d_start, s.atmo3d_end, s.logp_start, s.logp_end, s.sst_start, s.sst_end, s.tisr_start, s.tisr_end) == (1, 64, 65, 80, 81, 96, 97, 112)
+    p = slab_sizes(domain.initializedomain(1152, 0))          # polar region: 4 x 3 input patch
+    assert (p.reservoir_numinputs, p.nodes_per_input, p.n, p.chunk_size_prediction) == (96, 42, 4032, 8)

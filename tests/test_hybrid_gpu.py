@@ -91,7 +91,8 @@ def test_hybrid_step_stage_parity(model, oracle):
     Ggp = np.ascontiguousarray(G[domain.GP_OFF:domain.GS_OFF])
     Ggs = np.ascontiguousarray(G[domain.GS_OFF:domain.GT_OFF])
     Ggt = np.ascontiguousarray(G[domain.GT_OFF:])
-    assert np.array_equal(Ggt, m.tisr[1].cpu().numpy().ravel())
+    assert np.array_equal(Ggt, m.tisr_slice(m.t - 1).cpu().numpy().ravel())
+    assert m.t == 1 and domain.tisr_index(m.start_hours) == oracle.tisr_index(m.start_hours)
     Ff4 = np.ascontiguousarray(F[:domain.G2_OFF])
     Ff2 = np.ascontiguousarray(F[domain.G2_OFF:domain.GP_OFF])
     for s in range(NREG):
