@@ -358,10 +358,12 @@ int sml_train_accumulate(const double *states_dev, const double *model_dev, cons
  *   model_dev[slot]  : (n_model, T) column-major "imperfect model" forecasts;  targets_dev[slot] : (n_out, T)
  *   c_dev[slot]      : (n_aug, n_aug), b_dev[slot] : (n_out, n_aug), accumulated (lower-triangle tiles of C)
  * The four pointer tables are HOST arrays of device pointers, one entry per slot (NULL entries are skipped).
+ * ml_variant != 0: reservoir_layer_chunking_ml (:963-1065), whose step after a batch flush multiplies A by the column with
+ * the squared even entries while the leak term keeps the state (quirk Q6); the hybrid loop restarts from saved_state.
  * Returns the number of batches flushed (or <0). */
 int sml_bank_train_pass(sml_bank *bank, const double *noisy_inputs_dev, int T, int discard, int batch,
                         const double *const *model_dev, const double *const *targets_dev,
-                        double *const *c_dev, double *const *b_dev, void *stream);
+                        double *const *c_dev, double *const *b_dev, int ml_variant, void *stream);
 
 /* sml_train_accumulate updates only the tiles of C on or below the diagonal (half the flops and half the C traffic of
  * the reference's full DGEMM); this mirrors them into the upper triangle (sml_train_fit calls it itself). */

@@ -185,7 +185,7 @@ int ro_fit_chunk_hybrid(int n, int n_model, int n_out, double beta_res, double b
  * discard = discardlength/timestep, batch = reservoir%batch_size.  Returns number of batches flushed. */
 int ro_train_states(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals, const double *win,
                     double leakage, const double *noisy_inputs, int T, int discard, int batch,
-                    int n_model, int n_out, const double *model, const double *targets, double *c, double *b)
+                    int n_model, int n_out, const double *model, const double *targets, double *c, double *b, int ml_variant)
 {
     double *x = (double *)calloc(n, sizeof(double));
     double *states = (double *)calloc((size_t)n * batch, sizeof(double));
@@ -216,7 +216,9 @@ int ro_train_states(int n, int d, int k, const int32_t *rows, const int32_t *col
             int c0 = discard + (batch_number - 1) * batch;   /* 0-based first column of the batch */
             ro_chunking_matmul(n, n_model, n_out, batch, states, model + (size_t)c0 * n_model, targets + (size_t)c0 * n_out, c, b);
         } else {
-            const double *s = (i % batch == 0) ? saved : COL(i % batch);
+            /* after a flush the hybrid loop restarts from saved_state (:1133-1142); reservoir_layer_chunking_ml multiplies A by
+             * states(:,batch_size), whose even entries were squared in place (:1031-1034) -- quirk Q6 */
+            const double *s = (i % batch == 0) ? (ml_variant ? COL(batch) : saved) : COL(i % batch);
             double *tmpx = (double *)malloc(sizeof(double) * n);
             memcpy(tmpx, s, sizeof(double) * n);
             ro_advance(n, d, k, rows, cols, vals, win, 1.0, u, tmpx);

@@ -151,7 +151,8 @@ int  ro_fit_chunk_hybrid(int n, int n_model, int n_out, double beta_res, double 
 int  ro_train_states(int n, int d, int k, const int32_t *rows, const int32_t *cols, const double *vals, const double *win,
                      double leakage, const double *noisy_inputs /* (d,T) already noised */, int T, int discard, int batch,
                      int n_model, int n_out, const double *model /* (n_model,T) */, const double *targets /* (n_out,T) */,
-                     double *c /* (n_aug,n_aug) += */, double *b /* (n_out,n_aug) += */);   /* :1067-1175, Appendix D */
+                     double *c /* (n_aug,n_aug) += */, double *b /* (n_out,n_aug) += */,
+                     int ml_variant /* reservoir_layer_chunking_ml :963-1065 (quirk Q6) instead of _hybrid :1067-1175 */);
 int  ro_find_closest_divisor(int approx, int number);   /* mod_utilities.f90:1598-1636 */
 
 /* ---------------- SPEEDY adiabatic dynamical core (dynamics_oracle.c; src/dyn_*.f90, ini_indyns/impint.f90) ----------------

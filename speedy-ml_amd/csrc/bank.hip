@@ -46,8 +46,10 @@ __device__ __forceinline__ void decode_block(int id, int parts, int res_begin, i
 // x_new = (1-leak) x + leak tanh([A|Win] [x;u])        (src/mod_reservoir.f90:1444-1448)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
-                                                     int parts, const double *__restrict__ u_all, int u_stride, int cur)
+                                                     int parts, const double *__restrict__ u_all, int u_stride, int cur, int square_input)
 {
+    // square_input: the operand of A x is the state with its even (1-based) entries squared while the leak term keeps the
+    // state itself -- the step after a batch flush in the ML-only training loop (quirk Q6, src/mod_reservoir.f90:1031-1044)
     extern __shared__ __attribute__((aligned(16))) double xu[];
     int res, part;
     decode_block(blockIdx.x, parts, res_begin, res, part);
@@ -59,7 +61,15 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
     const double *__restrict__ u = u_all + (size_t)res * u_stride;
     // stage [x ; u] with 16-byte loads (x is 256-byte aligned)
     const int n2 = D.n >> 1;
-    for (int i = threadIdx.x; i < n2; i += THREADS) reinterpret_cast<f64x2 *>(xu)[i] = reinterpret_cast<const f64x2 *>(x)[i];
+    if (!square_input) {
+        for (int i = threadIdx.x; i < n2; i += THREADS) reinterpret_cast<f64x2 *>(xu)[i] = reinterpret_cast<const f64x2 *>(x)[i];
+    } else {
+        for (int i = threadIdx.x; i < n2; i += THREADS) {
+            f64x2 v = reinterpret_cast<const f64x2 *>(x)[i];
+            v[1] = v[1] * v[1];                      // device position parity == reference row parity (see load_common)
+            reinterpret_cast<f64x2 *>(xu)[i] = v;
+        }
+    }
     if ((D.n & 1) && threadIdx.x == 0) xu[D.n - 1] = x[D.n - 1];
     for (int i = threadIdx.x; i < D.d; i += THREADS) xu[D.n + i] = u[i];
     __syncthreads();
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
         }
         if (r < D.n) {
             const double xt = tanh(acc);
-            xn[r] = (1.0 - D.leak) * xu[r] + D.leak * xt;
+            xn[r] = (1.0 - D.leak) * (square_input ? x[r] : xu[r]) + D.leak * xt;
         }
     }
 }
@@ -488,7 +498,7 @@ int download_state(const HostRes &R, const double *src, double *x_host)
     return SML_OK;
 }
 
-int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st)
+int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st, int square_input = 0)
 {
     // (threads, parts): 512 x 2 -> three workgroups (3 x 53.8 KB LDS, 24 waves) per CU and 2304 workgroups = exactly three
     // rounds over 768 slots; 1024 x 1 halves the x re-reads but leaves a quarter-full last round.
@@ -508,11 +518,11 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
     if (threads == 1024)
-        hipLaunchKernelGGL(k_update<1024>, dim3(nres8 * parts), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur);
+        hipLaunchKernelGGL(k_update<1024>, dim3(nres8 * parts), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input);
     else if (threads == 256)
-        hipLaunchKernelGGL(k_update<256>, dim3(nres8 * parts), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur);
+        hipLaunchKernelGGL(k_update<256>, dim3(nres8 * parts), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input);
     else
-        hipLaunchKernelGGL(k_update<512>, dim3(nres8 * parts), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur);
+        hipLaunchKernelGGL(k_update<512>, dim3(nres8 * parts), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input);
     SML_HIP(hipGetLastError());
     if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_update.emplace_back(e0, e1); }
     b->cur ^= 1;
@@ -811,7 +821,7 @@ int sml_bank_timing_collect(sml_bank *b, double *update_ms, int *update_launches
 
 int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int discard, int batch,
                         const double *const *model_dev, const double *const *targets_dev,
-                        double *const *c_dev, double *const *b_dev, void *stream)
+                        double *const *c_dev, double *const *b_dev, int ml_variant, void *stream)
 {
     SML_REQUIRE(b && noisy_inputs_dev && model_dev && targets_dev && c_dev && b_dev, "sml_bank_train_pass: null argument");
     SML_REQUIRE(T > discard && discard >= 0 && batch > 0, "sml_bank_train_pass: need T > discard >= 0 and batch > 0 (T=%d discard=%d batch=%d)", T, discard, batch);
@@ -845,8 +855,9 @@ int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int 
     int flushed = 0;
     const int training_length = T - discard;
     for (int i = 1; i <= training_length - 1 && rc == SML_OK; ++i) {
-        // the running (unsquared) state lives in the bank, so "restart from saved_state after a flush" (quirk Q6) is implicit
-        rc = launch_update(b, 0, b->capacity, noisy_inputs_dev + step * (discard + i - 1), st);
+        // the running (unsquared) state lives in the bank, so "restart from saved_state after a flush" (quirk Q6) is implicit;
+        // the ML-only loop instead feeds the squared column into A x on the step after a flush (:1031-1044)
+        rc = launch_update(b, 0, b->capacity, noisy_inputs_dev + step * (discard + i - 1), st, ml_variant && i % batch == 0);
         if (rc) break;
         hipLaunchKernelGGL(k_store_state, sgrid, dim3(256), 0, st, b->d_descs, d_ts, b->capacity, i % batch, b->cur);
         if ((i + 1) % batch == 0) {

@@ -135,8 +135,9 @@ class ReservoirBank:
         check(_lib.lib().sml_bank_readout_part_bytes(self._h, int(part), C.byref(r)))
         return r.value
 
-    def train_pass(self, noisy_inputs, discard, batch, models, targets, cs, bs, stream=None):
-        """reservoir_layer_chunking_hybrid (src/mod_reservoir.f90:1067-1175) for every loaded slot.
+    def train_pass(self, noisy_inputs, discard, batch, models, targets, cs, bs, stream=None, ml_variant=False):
+        """reservoir_layer_chunking_hybrid (src/mod_reservoir.f90:1067-1175; ml_variant: reservoir_layer_chunking_ml :963-1065,
+        whose step after a batch flush feeds the squared column into A x, quirk Q6) for every loaded slot.
         noisy_inputs: device tensor [T, capacity, max_d]; models/targets/cs/bs: per-slot lists of device tensors
         (column-major buffers, see speedy_ml_amd.train) or None for slots to skip.  Returns #batches flushed."""
         T = noisy_inputs.shape[0]
@@ -150,7 +151,7 @@ class ReservoirBank:
             return arr
         tm, tt, tc, tb = table(models), table(targets), table(cs), table(bs)
         return check(_lib.lib().sml_bank_train_pass(self._h, dp(noisy_inputs.data_ptr()), T, discard, batch,
-                                                    tm, tt, tc, tb, vp(stream)))
+                                                    tm, tt, tc, tb, 1 if ml_variant else 0, vp(stream)))
 
 
 def gen_res(n, k, radius, seed):

@@ -258,12 +258,12 @@ class Oracle:
                                             C.c_double(prior_val), int(using_prior), _p(c), _p(b), _p(wout))
         return info, wout
 
-    def train_states(self, n, d, rows, cols, vals, win, leakage, noisy_inputs, discard, batch, model, targets, c, b):
+    def train_states(self, n, d, rows, cols, vals, win, leakage, noisy_inputs, discard, batch, model, targets, c, b, ml_variant=False):
         T = noisy_inputs.shape[1]
         return self.lib.ro_train_states(n, d, len(vals), _pi(rows), _pi(cols), _p(vals), _p(np.asfortranarray(win)),
                                         C.c_double(leakage), _p(np.asfortranarray(noisy_inputs)), T, discard, batch,
                                         model.shape[0], targets.shape[0], _p(np.asfortranarray(model)),
-                                        _p(np.asfortranarray(targets)), _p(c), _p(b))
+                                        _p(np.asfortranarray(targets)), _p(c), _p(b), 1 if ml_variant else 0)
 
     def slab_sst(self, base_sst, mask_gt0, sea_of_region, res_cell, all_slab_out):
         nreg = len(sea_of_region)

@@ -161,6 +161,38 @@ def test_device_training_pass_matches_oracle(oracle):
     bank.set_wout(0, to_host(wout))
 
 
+def test_device_training_pass_ml_variant(oracle):
+    """reservoir_layer_chunking_ml (src/mod_reservoir.f90:963-1065): no physics-model rows, and the step after a batch flush
+    multiplies A by the column whose even entries were squared in place while the leak term keeps the state (quirk Q6).
+    A leak rate below one exercises both halves of that step; the hybrid variant on the same data must differ."""
+    from speedy_ml_amd.reservoir import ReservoirBank
+    from speedy_ml_amd.synth import make_reservoir
+    r = make_reservoir(n=192, d=12, n_model=0, n_out=5, seed=18)
+    leak = 0.6
+    rng = np.random.default_rng(14)
+    T, discard, batch = 3 + 4 * 6, 3, 6
+    noisy = rng.standard_normal((T, 2, 12))
+    dev_in = torch.from_numpy(noisy).cuda()
+    targ = rng.standard_normal((r.n_out, T))
+    model = np.zeros((0, T))
+    results = {}
+    for ml in (True, False):
+        bank = ReservoirBank(2, max_d=12, max_n_model=1, max_n_out=5)
+        bank.load(1, r.n, r.d, 0, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None, leakage=leak)
+        cs, bs = [None, train.fortran_zeros(r.n, r.n)], [None, train.fortran_zeros(r.n_out, r.n)]
+        nb = bank.train_pass(dev_in, discard, batch, [None, None], [None, to_dev(targ)], cs, bs, ml_variant=ml)
+        co, bo = np.zeros((r.n, r.n), order="F"), np.zeros((r.n_out, r.n), order="F")
+        nbo = oracle.train_states(r.n, r.d, r.rows, r.cols, r.vals, r.win, leak, np.asfortranarray(noisy[:, 1, :r.d].T), discard, batch,
+                                  model, targ, co, bo, ml_variant=ml)
+        assert nb == nbo == 4
+        cg, bg = to_host(cs[1]), to_host(bs[1])
+        low = np.tril_indices(r.n)
+        assert np.max(np.abs(cg[low] - co[low])) <= 1e-12 * np.max(np.abs(co)), ml
+        assert np.max(np.abs(bg - bo)) <= 1e-12 * np.max(np.abs(bo)), ml
+        results[ml] = bg
+    assert np.max(np.abs(results[True] - results[False])) > 1e-6 * np.max(np.abs(results[False]))
+
+
 def test_batched_fit_equals_single(oracle):
     rng = np.random.default_rng(31)
     n, n_model, n_out, m = 200, 8, 6, 150
