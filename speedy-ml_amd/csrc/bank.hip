@@ -46,13 +46,18 @@ __device__ __forceinline__ void decode_block(int id, int parts, int res_begin, i
 // x_new = (1-leak) x + leak tanh([A|Win] [x;u])        (src/mod_reservoir.f90:1444-1448)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
-                                                     int parts, const double *__restrict__ u_all, int u_stride, int cur, int square_input)
+                                                     int parts, const double *__restrict__ u_all, int u_stride, int cur, int square_input,
+                                                     int whole_blocks)
 {
+    // Work split: the first whole_blocks workgroups take one reservoir each (x staged once per reservoir); the remaining
+    // reservoirs -- the ragged last round of the chip's resident workgroups -- are cut into `parts` slice ranges so that the
+    // tail is a round of short workgroups instead of a half-empty round of long ones.
     // square_input: the operand of A x is the state with its even (1-based) entries squared while the leak term keeps the
     // state itself -- the step after a batch flush in the ML-only training loop (quirk Q6, src/mod_reservoir.f90:1031-1044)
     extern __shared__ __attribute__((aligned(16))) double xu[];
     int res, part;
-    decode_block(blockIdx.x, parts, res_begin, res, part);
+    if ((int)blockIdx.x < whole_blocks) { decode_block(blockIdx.x, 1, res_begin, res, part); parts = 1; }
+    else decode_block((int)blockIdx.x - whole_blocks, parts, res_begin + whole_blocks, res, part);
     if (res >= res_end) return;
     const ResDesc D = descs[res];
     if (!D.loaded) return;
@@ -500,12 +505,33 @@ int download_state(const HostRes &R, const double *src, double *x_host)
 
 int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st, int square_input = 0)
 {
-    // (threads, parts): 512 x 2 -> three workgroups (3 x 53.8 KB LDS, 24 waves) per CU and 2304 workgroups = exactly three
-    // rounds over 768 slots; 1024 x 1 halves the x re-reads but leaves a quarter-full last round.
-    static const int cfg = getenv("SML_UPD_CFG") ? atoi(getenv("SML_UPD_CFG")) : 0;
-    const int threads = cfg == 1 ? 1024 : (cfg == 2 ? 256 : 512);
-    const int parts = cfg == 1 ? 1 : (cfg == 2 ? 4 : 2);
+    // 512-thread workgroups: three per CU (3 x 50.7 KB LDS, 24 waves).  A workgroup's life is latency-bound (29 us for a whole
+    // reservoir on an idle chip: staging + ~11 dependent slice batches per wave) and staging [x ; u] costs 18 us per copy
+    // over the whole bank, so: one workgroup per reservoir for every full round of the chip's resident slots, and the
+    // ragged remainder cut into slice ranges.  Measured (1152 reservoirs, ms): 512 x 2 parts everywhere 0.142, 512 x 1
+    // everywhere 0.132 (its second round is half empty), 3..8 parts 0.164..0.265, 1024 x 1 0.164, 256 x 4 0.18.
+    static const int cfg = getenv("SML_UPD_CFG") ? atoi(getenv("SML_UPD_CFG")) : -1;
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
+    static int slots = 0;
+    if (!slots) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        SML_HIP(hipGetDevice(&dev));
+        SML_HIP(hipGetDeviceProperties(&prop, dev));
+        slots = 3 * prop.multiProcessorCount;
+    }
+    int threads = 512, parts = 2, whole = 0;
+    if (cfg == 1) { threads = 1024; parts = 1; }
+    else if (cfg == 2) { threads = 256; parts = 4; }
+    else if (cfg == 9) { parts = 1; whole = nres8; }
+    else if (cfg >= 3) parts = cfg;
+    else if (cfg < 0) {
+        whole = (nres8 / slots) * slots;                     // multiples of 8 as long as the CU count is
+        whole -= whole % 8;
+        const int rem = nres8 - whole;
+        parts = rem ? std::max(1, std::min(4, slots / rem)) : 1;
+    }
+    const int nblocks = whole + (nres8 - whole) * parts;
     const size_t lds = (size_t)b->max_nd * sizeof(double);
     SML_REQUIRE(lds <= 160 * 1024, "reservoir too large for the LDS-staged update (n+d=%d)", b->max_nd);
     static bool attr_set = false;
@@ -518,11 +544,11 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
     if (threads == 1024)
-        hipLaunchKernelGGL(k_update<1024>, dim3(nres8 * parts), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input);
+        hipLaunchKernelGGL(k_update<1024>, dim3(nblocks), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole);
     else if (threads == 256)
-        hipLaunchKernelGGL(k_update<256>, dim3(nres8 * parts), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input);
+        hipLaunchKernelGGL(k_update<256>, dim3(nblocks), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole);
     else
-        hipLaunchKernelGGL(k_update<512>, dim3(nres8 * parts), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input);
+        hipLaunchKernelGGL(k_update<512>, dim3(nblocks), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole);
     SML_HIP(hipGetLastError());
     if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_update.emplace_back(e0, e1); }
     b->cur ^= 1;
