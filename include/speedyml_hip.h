@@ -329,6 +329,10 @@ int sml_dyn_step(sml_dyn *dyn, double *state_dev, int j1, int j2, double dt, dou
  * impint(2 delt) and nsteps leapfrog steps step(2,2,2 delt) (src/dyn_stloop.f90:28-43) */
 int sml_dyn_window(sml_dyn *dyn, double *state_dev, int start, int nsteps, double delt, double alph, double rob, double wil,
                    void *stream);
+/* how sml_dyn_window runs a time step: 0 = four launches over whole fields (default), 1 = two kernels (zonal-wavenumber
+ * space <-> latitude space; bit-identical results, measured slower on MI355X, see csrc/dynamics.hip), -1 = default /
+ * environment SML_DYN_TWO_KERNEL */
+int sml_dyn_select_window_form(int form);
 
 /* ===================================================================================================
  * 4b. reservoir construction (host, set-up time) -- replaces gen_res / makesparse / shuffle / sparse_eigen

@@ -62,7 +62,7 @@ EXPORTS = [
     "parmtr_", "inifft_", "grid_", "spec_", "vdspec_", "uvspec_", "vds_", "grad_", "lap_", "invlap_", "trunct_",
     "sml_dyn_create", "sml_dyn_destroy", "sml_dyn_impint", "sml_dyn_get_table", "sml_dyn_set_boundary", "sml_dyn_state_dev",
     "sml_dyn_set_state_host", "sml_dyn_get_state_host", "sml_dyn_set_boundary_host", "sml_dyn_grtend",
-    "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window",
+    "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_select_window_form",
     "sml_makesparse", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",
     "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit", "sml_train_fit_batched",
 ]

@@ -63,7 +63,7 @@ struct ImpSlot {                   // impint(dt, alph)
     double tref[KX], tref1[KX], tref2[KX], tref3[KX], dhsx[KX];
     double xc[KX][KX], xd[KX][KX], xj[LMAX][KX][KX];       // Fortran x(k,k1) -> x[k1][k]
     double *d_h = nullptr;         // device: dmp1 | dmp1d | dmp1s | elz   (4 x 992)
-    double *d_x = nullptr;         // device: xd(64) | xc(64) | xj(61*64) | level tables (12 x 8, rows LV_*)
+    double *d_x = nullptr;         // device: xd(64) | xc(64) | xj(61*64) | level tables (13 x 8, rows LV_*)
     LevelTables lv;
 };
 
@@ -360,7 +360,7 @@ struct StepArgs {
 //   FROM_FLUX = false: tendencies are read from tend_in[33] (testing entry point sml_dyn_spectral_step)
 //   tend_out (optional): the tendencies after sptend/implic/hordif, [vordt(8) | divdt(8) | tdt(8) | trdt(8) | psdt]
 constexpr int LV_DHS = 0, LV_DHSR = 1, LV_XG1 = 2, LV_XG2 = 3, LV_TCORV = 4, LV_QCORV = 5, LV_TREF = 6, LV_TREF1 = 7, LV_TREF2 = 8,
-              LV_TREF3 = 9, LV_DHSX = 10, LV_CORF = 11, LV_ROWS = 12;
+              LV_TREF3 = 9, LV_DHSX = 10, LV_CORF = 11, LV_FSGR = 12, LV_ROWS = 13;
 
 template <bool FROM_FLUX>
 __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, StepArgs a, const double *__restrict__ S,
@@ -513,6 +513,480 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
     if (k == 0) timint(F_PS, psdt);
 }
 
+
+// =====================================================================================================================
+// The 6-hour window as TWO kernels per time step (sml_dyn_window): zonal-wavenumber space <-> latitude space.
+//
+// A spectral transform is a Legendre transform (couples the total wavenumbers n of ONE zonal wavenumber m across latitudes)
+// times a Fourier transform (couples the longitudes / zonal wavenumbers of ONE latitude).  Everything SPEEDY does between two
+// transforms is local to one of the two spaces: the spectral step couples n (3-point stencils) and the 8 levels of one m;
+// the grid-point tendencies couple the 8 levels of one grid point.  So a time step needs only ONE exchange in each direction:
+//
+//   k_latspace (one workgroup per latitude row, 48):  Fourier coefficients of the 50 inverse fields of this row ->
+//       Fourier synthesis (96 longitudes) -> grid-point tendencies of the row's 96 columns -> forward Fourier transform of the
+//       73 tendency fields -> their Fourier coefficients FB[m][field][lat].
+//   k_mspace  (one workgroup per zonal wavenumber, 31):  FB[m] -> Gaussian quadrature / Legendre analysis of the 73 fields
+//       -> vds, Laplacian, sptend, geop, implic, hordif, truncation, leapfrog of the 32 x 8 coefficients of this m -> uvspec and
+//       grad of the NEW state -> Legendre synthesis of the 50 inverse fields of the next step -> FA[lat][field][m].
+//
+// Against the four-launch form (k_grid, k_gridtend, k_spec, k_spectral) this halves the launches, removes the 8-fold / 6-fold
+// re-staging of every field by the batched transform kernels, and never writes a grid or a spectral batch to HBM: the only
+// traffic between the two kernels is 1.2 MB + 1.7 MB of Fourier coefficients.  Every sum keeps the order of the kernels it
+// replaces (Legendre sums as gridy/specy, DFT as k_grid / k_spec, vertical and semi-implicit algebra as k_gridtend /
+// k_spectral), so the results are BIT-IDENTICAL to theirs (tests/test_dynamics_gpu.py).
+//
+// MEASURED, and why it is not the default (SML_DYN_TWO_KERNEL=1 selects it): 32.7 + 27.7 = 60 us per time step against 43 us
+// for the four launches.  A zonal wavenumber or a latitude row is served by ONE compute unit -- 31 and 48 workgroups on a
+// 256-CU chip -- and the 23 M multiply-adds of a step then run at the fp64 rate and LDS bandwidth of 79 CUs with 5-12
+// wavefronts each: phase stamps (profiles/micro/window_phase_stamps.py) give k_mspace = load 8.5 (strided state gather) +
+// analysis 5.3 + spectral step 5.2 + synthesis 9 us and k_latspace = load 1.9 + synthesis 5.8 + tendencies 2.8 + fold 1.5 +
+// forward DFT 6.5 us.  Register tiling of the four transform loops (4 x 4 / 2 x 4 outputs per thread) took k_mspace from
+// 51 to 33 us; LDS stride padding and deeper unrolling changed nothing -- the loops are bound by the latency of a nearly
+// empty CU, not by bank conflicts.  The four-launch form pays 19 us of launch floor per step but spreads the same arithmetic
+// over 300-580 workgroups.
+constexpr int MS_THREADS = 512, LS_THREADS = 768, NFA = 50, NFB = 73;
+// LDS strides are padded off the 256-byte bank period: lanes of a wavefront differ in field / latitude-pair index, and the
+// natural strides (64, 96 doubles per field, 32 per Legendre row) put them all on the same banks (measured: the Legendre
+// synthesis loop took 5.8 us instead of 1.5)
+constexpr int FS = 66;       // doubles per field of one zonal wavenumber: [32][2] + 2
+constexpr int FBS = 98;      // doubles per forward field: [48][2] + 2
+constexpr int PLS = 33;      // doubles per Legendre row: [32] + 1
+constexpr int TS = 98;       // doubles per tendency-field row in k_latspace: [96] + 2
+constexpr int MS_FB = NFB * FBS, MS_SP = NFB * FS, MS_PL = 24 * PLS, MS_ST = 2 * NSTATE * FS, MS_VC = 5 * 512;
+constexpr size_t MS_LDS = (size_t)(MS_FB + MS_SP + MS_PL + MS_ST + MS_VC + LV_ROWS * KX + 128 + 24) * sizeof(double) + 32 * sizeof(int);
+constexpr size_t LS_LDS = (size_t)(NFA * MX2 + NFA * IX + NFB * TS + 2 * IX + LV_ROWS * KX) * sizeof(double);
+
+// phase time stamps of workgroup 5 (profiles/micro/window_phase_stamps.py); compiled in with -DSML_DYN_STAMPS only
+__device__ unsigned long long g_dbg[64];
+#ifdef SML_DYN_STAMPS
+#define STAMP(slot) do { if (blockIdx.x == 5 && threadIdx.x == 0 && g_dbg[slot] == 0) g_dbg[slot] = wall_clock64(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+struct WinTables {
+    const double *polT;      // [31][24][32]: P_m^n at latitude j, one contiguous slab per zonal wavenumber
+    const double *wt;        // [24] Gaussian weights
+    const double *cosgr;     // [48]
+    const double *twc, *tws; // [96] cos / sin(2 pi t / 96), the table of spectral.hip
+    const int *nsh2;         // [32]
+};
+
+__device__ __forceinline__ double irot_l(const double *a, int n, int ri, double g) { return ri ? g * a[n * 2] : -g * a[n * 2 + 1]; }
+
+// the 3-point-in-n stencil of uvspec / vds on one zonal wavenumber held as [n][re,im] (same expressions as stencil())
+__device__ __forceinline__ void stencil_l(const double *P, const double *Q, int n, int ri, double gx, double ym, double yp, double &a, double &b)
+{
+    if (n == 0) {
+        a = irot_l(Q, n, ri, gx) - yp * P[(n + 1) * 2 + ri];
+        b = irot_l(P, n, ri, gx) + yp * Q[(n + 1) * 2 + ri];
+    } else if (n == NX - 1) {
+        a = ym * P[(n - 1) * 2 + ri];
+        b = -ym * Q[(n - 1) * 2 + ri];
+    } else {
+        a = ym * P[(n - 1) * 2 + ri] - yp * P[(n + 1) * 2 + ri] + irot_l(Q, n, ri, gx);
+        b = -ym * Q[(n - 1) * 2 + ri] + yp * Q[(n + 1) * 2 + ri] + irot_l(P, n, ri, gx);
+    }
+}
+
+__global__ __launch_bounds__(MS_THREADS) void k_mspace(DevHoriz H, WinTables W, StepArgs a, double sdrag, int do_step, int next_j2,
+                                                        const double *__restrict__ FB, double *__restrict__ FA, double *__restrict__ state,
+                                                        const double *__restrict__ imp_h, const double *__restrict__ imp_x,
+                                                        const double *__restrict__ phis, const double *__restrict__ tcorh,
+                                                        const double *__restrict__ qcorh)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *fb = sm;                        // [73][48][2] Fourier coefficients of the forward fields, then sym / antisym parts
+    double *sp = fb + MS_FB;                // [73][32][2] their spectral coefficients; later [18][32][2] derived inverse fields
+    double *pl = sp + MS_SP;                // [24][32]    Legendre functions of this zonal wavenumber
+    double *st = pl + MS_PL;                // [2][33][32][2] both time levels of the state
+    double *vc = st + MS_ST;                // 5 x [8][64] vertical coupling
+    double *lv = vc + MS_VC;                // [13][8]
+    double *xdc = lv + LV_ROWS * KX;        // xd, xc
+    double *wts = xdc + 128;                // [24]
+    int *nsh = reinterpret_cast<int *>(wts + 24);
+    const int m = blockIdx.x, tid = threadIdx.x;
+    STAMP(0);
+    for (int i = tid; i < 24 * 32; i += MS_THREADS) pl[(i >> 5) * PLS + (i & 31)] = W.polT[(size_t)m * 768 + i];
+    for (int i = tid; i < LV_ROWS * KX; i += MS_THREADS) lv[i] = imp_x[128 + LMAX * 64 + i];
+    if (tid < 128) xdc[tid] = imp_x[tid];
+    if (tid < 24) wts[tid] = W.wt[tid];
+    if (tid < 32) nsh[tid] = W.nsh2[tid];
+    for (int i = tid; i < 2 * NSTATE * 64; i += MS_THREADS) {
+        const int f = i >> 6, q = i & 63;                 // f counts both levels: 0..65
+        st[f * FS + q] = state[(size_t)f * SP + (q >> 1) * MX2 + 2 * m + (q & 1)];
+    }
+    if (do_step)
+        for (int i = tid; i < NFB * 96; i += MS_THREADS) fb[(i / 96) * FBS + i % 96] = FB[(size_t)m * NFB * 96 + i];
+    __syncthreads();
+    STAMP(1);
+    if (do_step) {
+        // symmetric / antisymmetric parts times the Gaussian weight, in place (specy :511-517)
+        for (int it = tid; it < NFB * 48; it += MS_THREADS) {
+            const int f = it / 48, r = it % 48, j = r >> 1, ri = r & 1;
+            const double n_ = fb[f * FBS + (47 - j) * 2 + ri], s_ = fb[f * FBS + j * 2 + ri], wj = wts[j];
+            fb[f * FBS + j * 2 + ri] = (n_ + s_) * wj;
+            fb[f * FBS + (47 - j) * 2 + ri] = (n_ - s_) * wj;
+        }
+        __syncthreads();
+        STAMP(2);
+        // Legendre analysis (specy :519-537), latitude sums in the reference's order.  Register tile of 4 fields x 4 total
+        // wavenumbers of one parity per thread: 8 LDS operands feed 16 accumulators (the one-output-per-thread form spent
+        // 6 us per launch on LDS reads: this whole zonal wavenumber is served by ONE CU's LDS)
+        for (int it = tid; it < 19 * 16; it += MS_THREADS) {
+            const int nq = it & 3, par = (it >> 2) & 1, ri = (it >> 3) & 1, f0 = (it >> 4) * 4, c = 2 * m + ri;
+            double acc[4][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+            const int n0 = par + 8 * nq;                                  // n = n0 + 2 t, t = 0..3
+#pragma unroll 6
+            for (int j = 0; j < IY; ++j) {
+                const int lat = par ? 47 - j : j;
+                double pv[4], fv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pv[t] = pl[j * PLS + n0 + 2 * t];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) fv[x] = fb[min(f0 + x, NFB - 1) * FBS + lat * 2 + ri];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[x][t] = acc[x][t] + pv[t] * fv[x];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int n = n0 + 2 * t;
+                    if (f0 + x < NFB) sp[(f0 + x) * FS + n * 2 + ri] = (n < NX - 1 && c < nsh[n]) ? acc[x][t] : 0.0;
+                }
+        }
+        __syncthreads();
+        STAMP(3);
+        // ---- the spectral step for the 32 x 2 coefficients of this m and the 8 levels: one thread each (cf. k_spectral)
+        const int ci = tid & 63, k = tid >> 6, n = ci >> 1, ri = ci & 1, hm = n * MX + m;
+        const size_t e = (size_t)n * MX2 + 2 * m + ri;
+        double *d4 = vc, *t4 = vc + 512, *tds = vc + 1024, *yfs = vc + 1536, *dvs = vc + 2048;
+        double *s1 = st, *s2 = st + NSTATE * FS;
+        double vordt, divdt, tdt, trdt, psdt;
+        {
+            const double gx = H.gradx[m], ym = H.vddym[hm], yp = H.vddyp[hm], el2 = H.el2[hm];
+            double dummy;
+            stencil_l(sp + k * FS, sp + (8 + k) * FS, n, ri, gx, ym, yp, vordt, divdt);
+            const double lapke = -sp[(48 + k) * FS + ci] * el2;
+            divdt = divdt - lapke;
+            stencil_l(sp + (16 + k) * FS, sp + (24 + k) * FS, n, ri, gx, ym, yp, dummy, tdt);
+            tdt = tdt + sp[(56 + k) * FS + ci];
+            stencil_l(sp + (32 + k) * FS, sp + (40 + k) * FS, n, ri, gx, ym, yp, dummy, trdt);
+            trdt = trdt + sp[(64 + k) * FS + ci];
+            psdt = sp[72 * FS + ci];
+            if (m == 0 && n == 0) psdt = 0.;
+        }
+        {
+            const double *s4 = a.j4 == 1 ? s1 : s2;
+            d4[k * 64 + ci] = s4[(F_DIV + k) * FS + ci];
+            t4[k * 64 + ci] = s4[(F_T + k) * FS + ci];
+            const double ps4 = s4[F_PS * FS + ci];
+            const double el2 = H.el2[hm];
+            __syncthreads();
+            double dmeanc = 0.0;
+#pragma unroll
+            for (int j = 0; j < KX; ++j) dmeanc = dmeanc + d4[j * 64 + ci] * lv[LV_DHS * KX + j];
+            psdt = psdt - dmeanc;
+            if (m == 0 && n == 0) psdt = 0.;
+            double sg = 0.0, sig_k = 0.0, sig_k1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < KX - 1; ++j) {
+                sg = sg - lv[LV_DHS * KX + j] * (d4[j * 64 + ci] - dmeanc);
+                if (j + 1 == k) sig_k = sg;
+                if (j == k) sig_k1 = sg;
+            }
+            const double dumk_k = k > 0 ? sig_k * (lv[LV_TREF * KX + k] - lv[LV_TREF * KX + (k > 0 ? k - 1 : 0)]) : 0.0;
+            const double dumk_k1 = k < KX - 1 ? sig_k1 * (lv[LV_TREF * KX + (k < KX - 1 ? k + 1 : k)] - lv[LV_TREF * KX + k]) : 0.0;
+            tdt = tdt - (dumk_k1 + dumk_k) * lv[LV_DHSR * KX + k] + lv[LV_TREF3 * KX + k] * (sig_k1 + sig_k) - lv[LV_TREF2 * KX + k] * dmeanc;
+            double phi = phis[e] + lv[LV_XG1 * KX + KX - 1] * t4[(KX - 1) * 64 + ci];
+#pragma unroll
+            for (int j = KX - 2; j >= 0; --j)
+                if (j >= k) phi = phi + lv[LV_XG2 * KX + j + 1] * t4[(j + 1) * 64 + ci] + lv[LV_XG1 * KX + j] * t4[j * 64 + ci];
+            if (m == 0 && k >= 1 && k <= KX - 2) phi = phi + lv[LV_CORF * KX + k] * (t4[(k + 1) * 64 + ci] - t4[(k - 1) * 64 + ci]);
+            {
+                const double g1 = phi + lv[LV_TREF1 * KX + k] * ps4;
+                const double g2 = -g1 * el2;
+                divdt = divdt - g2;
+            }
+            if (a.implicit) {
+                const double elz = imp_h[3 * NX * MX + hm];
+                const int ll = m + n;
+                double xl[KX];
+#pragma unroll
+                for (int k1 = 0; k1 < KX; ++k1) xl[k1] = ll != 0 ? imp_x[128 + (size_t)(ll - 1) * 64 + k1 * KX + k] : 0.0;
+                tds[k * 64 + ci] = tdt;
+                __syncthreads();
+                double ye = 0.;
+#pragma unroll
+                for (int k1 = 0; k1 < KX; ++k1) ye = ye + xdc[k1 * KX + k] * tds[k1 * 64 + ci];
+                ye = ye + lv[LV_TREF1 * KX + k] * psdt;
+                yfs[k * 64 + ci] = divdt + elz * ye;
+                __syncthreads();
+                divdt = 0.;
+                if (ll != 0) {
+#pragma unroll
+                    for (int k1 = 0; k1 < KX; ++k1) divdt = divdt + xl[k1] * yfs[k1 * 64 + ci];
+                }
+                dvs[k * 64 + ci] = divdt;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < KX; ++j) psdt = psdt - dvs[j * 64 + ci] * lv[LV_DHSX * KX + j];
+#pragma unroll
+                for (int k1 = 0; k1 < KX; ++k1) tdt = tdt + xdc[64 + k1 * KX + k] * dvs[k1 * 64 + ci];
+            }
+            const double dmp = H.dmp[hm], dmpd = H.dmpd[hm], dmps = H.dmps[hm];
+            const double dmp1 = imp_h[hm], dmp1d = imp_h[NX * MX + hm], dmp1s = imp_h[2 * NX * MX + hm];
+            const double v1 = s1[(F_VOR + k) * FS + ci], d1 = s1[(F_DIV + k) * FS + ci];
+            const double ct = s1[(F_T + k) * FS + ci] + tcorh[e] * lv[LV_TCORV * KX + k];
+            const double cq = s1[(F_TR + k) * FS + ci] + qcorh[e] * lv[LV_QCORV * KX + k];
+            vordt = (vordt - dmp * v1) * dmp1;
+            divdt = (divdt - dmpd * d1) * dmp1d;
+            tdt = (tdt - dmp * ct) * dmp1;
+            trdt = (trdt - dmpd * cq) * dmp1d;
+            if (k == 0) {
+                if (m == 0) { vordt = vordt - sdrag * v1; divdt = divdt - sdrag * d1; }
+                vordt = (vordt - dmps * v1) * dmp1s;
+                divdt = (divdt - dmps * d1) * dmp1s;
+                tdt = (tdt - dmps * ct) * dmp1s;
+            }
+        }
+        if (a.integrate) {
+            const double tf = H.trfilt[hm];
+            double *g1 = state, *g2 = state + (size_t)NSTATE * SP;
+            auto timint = [&](int f, double fdt) {
+                fdt = fdt * tf;
+                const int o = f * FS + ci;
+                const double f1 = s1[o];
+                const double fj = a.j1 == 1 ? f1 : s2[o];
+                const double fnew = f1 + a.dt * fdt;
+                const double n1 = fj + a.wil * a.eps * (f1 - 2 * fj + fnew);
+                const double fj_after = a.j1 == 1 ? n1 : fj;
+                const double n2 = fnew - (1 - a.wil) * a.eps * (n1 - 2 * fj_after + fnew);
+                s1[o] = n1; s2[o] = n2;
+                g1[(size_t)f * SP + e] = n1; g2[(size_t)f * SP + e] = n2;
+            };
+            timint(F_VOR + k, vordt);
+            timint(F_DIV + k, divdt);
+            timint(F_T + k, tdt);
+            timint(F_TR + k, trdt);
+            if (k == 0) timint(F_PS, psdt);
+        }
+        __syncthreads();
+    }
+    STAMP(4);
+    if (!next_j2) return;
+    // ---- inverse side for the next grtend: uvspec of the 8 levels and grad(ps) of time level next_j2, then Legendre synthesis
+    const double *sl = st + (next_j2 - 1) * NSTATE * FS;
+    double *syn = sp;
+    for (int it = tid; it < 18 * 64; it += MS_THREADS) {
+        const int fd = it >> 6, q = it & 63, n = q >> 1, ri = q & 1, hm = n * MX + m;
+        double out;
+        if (fd < 16) {
+            const int k = fd & 7;
+            double ua, vb;
+            stencil_l(sl + (F_VOR + k) * FS, sl + (F_DIV + k) * FS, n, ri, H.uvdx[hm], H.uvdym[hm], H.uvdyp[hm], ua, vb);
+            out = fd < 8 ? ua : vb;
+        } else {
+            const double *ps = sl + F_PS * FS;
+            if (fd == 16) out = irot_l(ps, n, ri, H.gradx[m]);
+            else if (n == 0) out = H.gradyp[m] * ps[(n + 1) * 2 + ri];
+            else if (n == NX - 1) out = -H.gradym[hm] * ps[(n - 1) * 2 + ri];
+            else out = -H.gradym[hm] * ps[(n - 1) * 2 + ri] + H.gradyp[hm] * ps[(n + 1) * 2 + ri];
+        }
+        syn[fd * FS + q] = out;
+    }
+    __syncthreads();
+    STAMP(5);
+    // Legendre synthesis (gridy :454-495): register tile of 2 fields x 4 latitude pairs per thread
+    for (int it = tid; it < 25 * 12; it += MS_THREADS) {
+        const int jq = it % 6, ri = (it / 6) & 1, f0 = (it / 12) * 2, c = 2 * m + ri;
+        const double *v0 = (f0 < 32 ? sl + f0 * FS : syn + (f0 - 32) * FS) + ri, *v1 = v0 + FS;
+        double ev[2][4], od[2][4];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ev[x][t] = 0.0; od[x][t] = 0.0; }
+#pragma unroll 4
+        for (int n = 0; n < NX; n += 2) {
+            const bool me = c < nsh[n], mo = c < nsh[n + 1];
+            const double a0 = v0[n * 2], a1 = v1[n * 2], b0 = v0[(n + 1) * 2], b1 = v1[(n + 1) * 2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double pe = pl[(jq * 4 + t) * PLS + n], po = pl[(jq * 4 + t) * PLS + n + 1];
+                if (me) { ev[0][t] = ev[0][t] + a0 * pe; ev[1][t] = ev[1][t] + a1 * pe; }
+                if (mo) { od[0][t] = od[0][t] + b0 * po; od[1][t] = od[1][t] + b1 * po; }
+            }
+        }
+        STAMP(7);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int jj = jq * 4 + t, f = f0 + x;
+                FA[((size_t)(IL - 1 - jj) * NFA + f) * MX2 + c] = ev[x][t] + od[x][t];       // northern row il+1-j
+                FA[((size_t)jj * NFA + f) * MX2 + c] = ev[x][t] - od[x][t];                   // southern row j
+            }
+    }
+    STAMP(6);
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_latspace(DevHoriz H, WinTables W, double akap, const double *__restrict__ lvg,
+                                                          const double *__restrict__ FA, double *__restrict__ FB)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *fa = sm;                  // [50][62] Fourier coefficients of this latitude row
+    double *g = fa + NFA * MX2;       // [50][96] grid row: vor div t tr (8 levels each) | u(8) | v(8) | dps/dx | dps/dy
+    double *T = g + NFA * IX;         // [73][96] tendency fields (layout of k_gridtend), then folded about longitude 48
+    double *tc = T + NFB * TS, *ts = tc + IX;
+    double *lv = ts + IX;             // [13][8]
+    const int row = blockIdx.x, tid = threadIdx.x;
+    STAMP(10);
+    for (int i = tid; i < NFA * MX2; i += LS_THREADS) fa[i] = FA[(size_t)row * NFA * MX2 + i];
+    for (int i = tid; i < IX; i += LS_THREADS) { tc[i] = W.twc[i]; ts[i] = W.tws[i]; }
+    for (int i = tid; i < LV_ROWS * KX; i += LS_THREADS) lv[i] = lvg[i];
+    __syncthreads();
+    const double cg = W.cosgr[row];
+    STAMP(11);
+    // Fourier synthesis (gridx) of the 31 retained modes, two longitudes per work item (cf. k_grid); 4 fields per thread share
+    // the twiddle reads
+    for (int w = tid; w < 13 * (IX / 2 + 1); w += LS_THREADS) {
+        const int i = w % (IX / 2 + 1), f0 = (w / (IX / 2 + 1)) * 4;
+        const double *fc[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fc[x] = fa + min(f0 + x, NFA - 1) * MX2;
+        double A[4] = {0.0, 0.0, 0.0, 0.0}, B[4] = {0.0, 0.0, 0.0, 0.0};
+        int ph = 0;
+#pragma unroll 5
+        for (int kk = 1; kk <= MX - 1; ++kk) {
+            ph += i;
+            if (ph >= IX) ph -= IX;
+            const double cs = tc[ph], sn = ts[ph];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { A[x] += fc[x][2 * kk] * cs; B[x] += fc[x][2 * kk + 1] * sn; }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int f = f0 + x;
+            if (f >= NFA) break;
+            double x0 = fc[x][0] + 2.0 * (A[x] - B[x]), x1 = fc[x][0] + 2.0 * (A[x] + B[x]);
+            if (f >= 32) { x0 = x0 * cg; x1 = x1 * cg; }              // grid(.,.,2) for u, v and grad(ps)
+            g[f * IX + i] = x0;
+            if (i != 0 && i != IX / 2) g[f * IX + IX - i] = x1;
+        }
+    }
+    __syncthreads();
+    STAMP(12);
+    // grid-point tendencies (dyn_grtend.f90:80-216): one thread per (longitude, level); the column sums are re-derived by every
+    // thread from the LDS row in the reference's order, so no exchange between the level-threads is needed
+    {
+        const int i = tid % IX, k = tid / IX;
+        const double cor = H.coriol[row];
+        auto G = [&](int f) { return g[f * IX + i]; };
+        double px = G(48), py = G(49);
+        double umean = 0.0, vmean = 0.0, dmean = 0.0;
+#pragma unroll
+        for (int j = 0; j < KX; ++j) {
+            umean = umean + G(32 + j) * lv[LV_DHS * KX + j];
+            vmean = vmean + G(40 + j) * lv[LV_DHS * KX + j];
+            dmean = dmean + G(F_DIV + j) * lv[LV_DHS * KX + j];
+        }
+        if (k == 0) T[72 * TS + i] = -umean * px - vmean * py;
+        // sigma-dot and its mass-flux part at interfaces k and k+1 of this level (running sums from the top)
+        double sd = 0.0, sm_ = 0.0, sd_k = 0.0, sd_k1 = 0.0, sm_k = 0.0, sm_k1 = 0.0, puv_k = 0.0;
+#pragma unroll
+        for (int j = 0; j < KX; ++j) {
+            const double puv = (G(32 + j) - umean) * px + (G(40 + j) - vmean) * py;
+            if (j == k) { sd_k = sd; sm_k = sm_; puv_k = puv; }
+            sd = sd - lv[LV_DHS * KX + j] * (puv + G(F_DIV + j) - dmean);
+            sm_ = sm_ - lv[LV_DHS * KX + j] * puv;
+            if (j == k) { sd_k1 = sd; sm_k1 = sm_; }
+        }
+        const double ug = G(32 + k), vg = G(40 + k), tg = G(F_T + k), trg = G(F_TR + k), divg = G(F_DIV + k);
+        const double vorg = G(F_VOR + k) + cor;
+        const double trefk = lv[LV_TREF * KX + k];
+        const double tgg = tg - trefk;
+        const int km = k > 0 ? k - 1 : 0, kp = k < KX - 1 ? k + 1 : KX - 1;
+        const double ug_m = G(32 + km), ug_p = G(32 + kp), vg_m = G(40 + km), vg_p = G(40 + kp);
+        const double tgg_m = G(F_T + km) - lv[LV_TREF * KX + km], tgg_p = G(F_T + kp) - lv[LV_TREF * KX + kp];
+        const double trg_m = G(F_TR + km), trg_p = G(F_TR + kp);
+        px = RGAS * px;
+        py = RGAS * py;
+        const double dhsr = lv[LV_DHSR * KX + k];
+        const bool top = k == 0, bot = k == KX - 1;
+        // temp(k) = sigdt(k) * (f(k) - f(k-1)) at the upper interface, temp(k+1) at the lower one; zero at the two ends
+        double t0 = top ? 0.0 : sd_k * (ug - ug_m), t1 = bot ? 0.0 : sd_k1 * (ug_p - ug);
+        T[k * TS + i] = vg * vorg - tgg * px - (t1 + t0) * dhsr;
+        t0 = top ? 0.0 : sd_k * (vg - vg_m); t1 = bot ? 0.0 : sd_k1 * (vg_p - vg);
+        T[(8 + k) * TS + i] = -ug * vorg - tgg * py - (t1 + t0) * dhsr;
+        t0 = top ? 0.0 : sd_k * (tgg - tgg_m) + sm_k * (trefk - lv[LV_TREF * KX + km]);
+        t1 = bot ? 0.0 : sd_k1 * (tgg_p - tgg) + sm_k1 * (lv[LV_TREF * KX + kp] - trefk);
+        T[(56 + k) * TS + i] = tgg * divg - (t1 + t0) * dhsr + lv[LV_FSGR * KX + k] * tgg * (sd_k1 + sd_k)
+                               + lv[LV_TREF3 * KX + k] * (sm_k1 + sm_k) + akap * (tg * puv_k - tgg * dmean);
+        // tracer: no vertical advection across the two uppermost interior interfaces (:196-203)
+        t0 = (top || k == 1 || k == 2) ? 0.0 : sd_k * (trg - trg_m);
+        t1 = (bot || k == 0 || k == 1) ? 0.0 : sd_k1 * (trg_p - trg);
+        T[(64 + k) * TS + i] = trg * divg - (t1 + t0) * dhsr;
+        T[(48 + k) * TS + i] = 0.5 * (ug * ug + vg * vg);
+        T[(16 + k) * TS + i] = -ug * tgg;
+        T[(24 + k) * TS + i] = -vg * tgg;
+        T[(32 + k) * TS + i] = -ug * trg;
+        T[(40 + k) * TS + i] = -vg * trg;
+    }
+    __syncthreads();
+    STAMP(13);
+    // fold about longitude 48 in place, after the vdspec pre-scaling (fields 0..47 by 1/cos): T[f][i] <- x_i + x_{96-i},
+    // T[f][96-i] <- x_i - x_{96-i} (i = 1..47); x_0 and x_48 stay
+    for (int w = tid; w < NFB * (IX / 2 + 1); w += LS_THREADS) {
+        const int i = w % (IX / 2 + 1), f = w / (IX / 2 + 1);
+        double x = T[f * TS + i];
+        if (i == 0 || i == IX / 2) {
+            if (f < 48) T[f * TS + i] = x * cg;
+        } else {
+            double y = T[f * TS + IX - i];
+            if (f < 48) { x = x * cg; y = y * cg; }
+            T[f * TS + i] = x + y;
+            T[f * TS + IX - i] = x - y;
+        }
+    }
+    __syncthreads();
+    STAMP(14);
+    // forward DFT (specx) of the 31 retained modes: Re_k = sum ss cos / 96, Im_k = - sum sd sin / 96, Im of k = 0 is 0
+    for (int w = tid; w < 19 * MX; w += LS_THREADS) {
+        const int kk = w % MX, f0 = (w / MX) * 4;
+        const double *x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = T + min(f0 + q, NFB - 1) * TS;
+        double re[4], im[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { re[q] = 0.0; im[q] = 0.0; re[q] += x[q][0] * tc[0]; im[q] -= x[q][0] * ts[0]; }
+        int ph = 0;
+#pragma unroll 4
+        for (int i = 1; i <= IX / 2; ++i) {
+            ph += kk;
+            if (ph >= IX) ph -= IX;
+            const double cs = tc[ph], sn = ts[ph];
+            const int io = i == IX / 2 ? i : IX - i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { re[q] += x[q][i] * cs; im[q] -= x[q][io] * sn; }
+        }
+        const double sc = 1. / (double)IX;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (f0 + q >= NFB) break;
+            double *o = FB + ((size_t)kk * NFB + f0 + q) * 96 + row * 2;
+            o[0] = re[q] * sc;
+            o[1] = kk == 0 ? 0.0 : im[q] * sc;
+        }
+    }
+    STAMP(15);
+}
+
 }  // namespace
 
 struct sml_dyn {
@@ -528,6 +1002,8 @@ struct sml_dyn {
     double *tend_grid = nullptr;       // [73][GR]
     double *tend_spec = nullptr;       // [73][SP]
     int32_t *desc = nullptr, *scale = nullptr;     // inverse-batch descriptors [50][4], forward-batch scaling flags [73]
+    WinTables win{};                   // tables of the two-kernel window
+    double *fa = nullptr, *fb = nullptr;   // Fourier coefficients exchanged by k_mspace / k_latspace: [48][50][62], [31][73][48][2]
 };
 
 namespace {
@@ -565,6 +1041,8 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
+
+int g_window_form = -1;      // sml_dyn_select_window_form
 
 StepArgs make_args(int j1, int j2, double dt, double alph, double rob, double wil)
 {
@@ -607,7 +1085,43 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
     if (!rc) rc = fetch_table(d, 21, &d->d.uvdyp, tmp, NX * MX);
     if (!rc) rc = fetch_table(d, 22, &d->d.vddym, tmp, NX * MX);
     if (!rc) rc = fetch_table(d, 23, &d->d.vddyp, tmp, NX * MX);
+    if (!rc) {
+        // tables of the two-kernel window: Legendre functions regrouped by zonal wavenumber, weights, 1/cos, twiddles
+        std::vector<double> cpol, polT((size_t)MX * IY * NX), w24, cg48, n32;
+        rc = fetch_table(d, 24, nullptr, cpol, MX2 * NX * IY);
+        for (int m = 0; m < MX && !rc; ++m)
+            for (int j = 0; j < IY; ++j)
+                for (int n = 0; n < NX; ++n) polT[((size_t)m * IY + j) * NX + n] = cpol[((size_t)j * NX + n) * MX2 + 2 * m];
+        if (!rc) rc = upload(d, &d->win.polT, polT.data(), polT.size());
+        if (!rc) rc = fetch_table(d, 3, &d->win.wt, w24, IY);
+        if (!rc) rc = fetch_table(d, 6, &d->win.cosgr, cg48, IL);
+        if (!rc) rc = fetch_table(d, 12, nullptr, n32, NX);
+        if (!rc) {
+            int32_t nsh[NX];
+            for (int n = 0; n < NX; ++n) nsh[n] = (int32_t)n32[n];
+            int32_t *dn = nullptr;
+            rc = sml::dev_upload(&dn, nsh, NX);
+            if (!rc) { d->allocs.push_back(dn); d->win.nsh2 = dn; }
+        }
+        if (!rc) {
+            double twc[IX], tws[IX];                      // the twiddle table of spectral.hip (build_tables), same expressions
+            for (int k = 0; k < IX; ++k) {
+                const long double ang = 2.0L * 3.14159265358979323846264338327950288L * k / (long double)IX;
+                twc[k] = (double)cosl(ang);
+                tws[k] = (double)sinl(ang);
+            }
+            twc[24] = twc[72] = 0.0; tws[0] = tws[48] = 0.0;
+            rc = upload(d, &d->win.twc, twc, IX);
+            if (!rc) rc = upload(d, &d->win.tws, tws, IX);
+        }
+    }
     auto zeros = [&](double **p, size_t n) { int r = sml::dev_zeros(p, n); if (!r) d->allocs.push_back(*p); return r; };
+    if (!rc) rc = zeros(&d->fa, (size_t)IL * NFA * MX2);
+    if (!rc) rc = zeros(&d->fb, (size_t)MX * NFB * 96);
+    if (!rc) {
+        SML_HIP(hipFuncSetAttribute((const void *)k_mspace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MS_LDS));
+        SML_HIP(hipFuncSetAttribute((const void *)k_latspace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LS_LDS));
+    }
     if (!rc) rc = zeros(&d->bc, (size_t)3 * SP);
     if (!rc) rc = zeros(&d->own_state, (size_t)2 * NSTATE * SP);
     if (!rc) rc = zeros(&d->batch_grid, (size_t)NB_SPEC * GR);
@@ -651,7 +1165,7 @@ int sml_dyn_impint(sml_dyn *d, double dt, double alph)
         if (s->dt == dt && s->alph == alph) { d->cur = s; return SML_OK; }
     ImpSlot *s = new ImpSlot;
     build_impint(*s, d->h, dt, alph);
-    std::vector<double> hh((size_t)4 * NX * MX), xx((size_t)128 + LMAX * 64 + 12 * KX);
+    std::vector<double> hh((size_t)4 * NX * MX), xx((size_t)128 + LMAX * 64 + LV_ROWS * KX);
     memcpy(&hh[0], s->dmp1, sizeof s->dmp1);
     memcpy(&hh[NX * MX], s->dmp1d, sizeof s->dmp1d);
     memcpy(&hh[2 * NX * MX], s->dmp1s, sizeof s->dmp1s);
@@ -661,8 +1175,9 @@ int sml_dyn_impint(sml_dyn *d, double dt, double alph)
     memcpy(&xx[128], s->xj, sizeof s->xj);
     {
         const LevelTables &lv = s->lv;
-        const double *rows[12] = {lv.dhs, lv.dhsr, lv.xgeop1, lv.xgeop2, lv.tcorv, lv.qcorv, lv.tref, lv.tref1, lv.tref2, lv.tref3, lv.dhsx, lv.corf};
-        for (int r = 0; r < 12; ++r) memcpy(&xx[128 + LMAX * 64 + r * KX], rows[r], KX * sizeof(double));   // order = LV_* in k_spectral
+        const double *rows[LV_ROWS] = {lv.dhs, lv.dhsr, lv.xgeop1, lv.xgeop2, lv.tcorv, lv.qcorv, lv.tref, lv.tref1, lv.tref2, lv.tref3, lv.dhsx, lv.corf,
+                                       lv.fsgr};
+        for (int r = 0; r < LV_ROWS; ++r) memcpy(&xx[128 + LMAX * 64 + r * KX], rows[r], KX * sizeof(double));   // order = LV_* in k_spectral
     }
     int rc = sml::dev_upload(&s->d_h, hh.data(), hh.size());
     if (!rc) rc = sml::dev_upload(&s->d_x, xx.data(), xx.size());
@@ -711,6 +1226,13 @@ int sml_dyn_set_boundary(sml_dyn *d, const double *phis_dev, const double *tcorh
     SML_HIP(hipMemcpyAsync(d->bc, phis_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
     SML_HIP(hipMemcpyAsync(d->bc + SP, tcorh_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
     SML_HIP(hipMemcpyAsync(d->bc + 2 * SP, qcorh_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return SML_OK;
+}
+
+int sml_dyn_debug_stamps(unsigned long long *out)        // not part of the C-ABI (no declaration in include/): phase profiling aid
+{
+    SML_HIP(hipDeviceSynchronize());
+    SML_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 64));
     return SML_OK;
 }
 
@@ -789,20 +1311,58 @@ int sml_dyn_step(sml_dyn *d, double *state_dev, int j1, int j2, double dt, doubl
     return run_step(d, state_dev, make_args(j1, j2, dt, alph, rob, wil), 0, nullptr, sml::as_stream(stream));
 }
 
+int sml_dyn_select_window_form(int form)
+{
+    SML_REQUIRE(form >= -1 && form <= 1, "sml_dyn_select_window_form: -1 default, 0 four launches per step, 1 two kernels per step");
+    g_window_form = form;
+    return SML_OK;
+}
+
 int sml_dyn_window(sml_dyn *d, double *state_dev, int start, int nsteps, double delt, double alph, double rob, double wil, void *stream)
 {
     SML_REQUIRE(d && state_dev && nsteps >= 0 && delt > 0, "sml_dyn_window: bad arguments");
     hipStream_t st = sml::as_stream(stream);
-    int rc = SML_OK;
-    if (start) {                                   // stepone, istart = 0 or 2 (src/ini_stepone.f90:16-31)
-        rc = sml_dyn_impint(d, 0.5 * delt, alph);
-        if (!rc) rc = run_step(d, state_dev, make_args(1, 1, 0.5 * delt, alph, rob, wil), 0, nullptr, st);
-        if (!rc) rc = sml_dyn_impint(d, delt, alph);
-        if (!rc) rc = run_step(d, state_dev, make_args(1, 2, delt, alph, rob, wil), 0, nullptr, st);
+    static const int env_two = getenv("SML_DYN_TWO_KERNEL") ? atoi(getenv("SML_DYN_TWO_KERNEL")) : 0;
+    const int four_launch = !(g_window_form < 0 ? env_two : g_window_form);
+    // the schedule: stepone for istart = 0 or 2 (src/ini_stepone.f90:16-31), then impint(2 delt) (:34) and the leapfrog loop
+    // (src/dyn_stloop.f90:28-43)
+    struct Item { double dt_imp; StepArgs a; };
+    std::vector<Item> sched;
+    if (start) {
+        sched.push_back({0.5 * delt, make_args(1, 1, 0.5 * delt, alph, rob, wil)});
+        sched.push_back({delt, make_args(1, 2, delt, alph, rob, wil)});
     }
-    if (!rc) rc = sml_dyn_impint(d, 2 * delt, alph);         // :34
-    for (int i = 0; i < nsteps && !rc; ++i)                    // src/dyn_stloop.f90:28-43
-        rc = run_step(d, state_dev, make_args(2, 2, 2 * delt, alph, rob, wil), 0, nullptr, st);
+    for (int i = 0; i < nsteps; ++i) sched.push_back({2 * delt, make_args(2, 2, 2 * delt, alph, rob, wil)});
+    int rc = SML_OK;
+    if (four_launch) {
+        for (size_t i = 0; i < sched.size() && !rc; ++i) {
+            rc = sml_dyn_impint(d, sched[i].dt_imp, alph);
+            if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st);
+        }
+        if (!rc) rc = sml_dyn_impint(d, 2 * delt, alph);
+        return rc;
+    }
+    // two kernels per time step (see k_mspace / k_latspace); one extra k_mspace launch starts the pipeline with the inverse
+    // side of the first step
+    const double *phis = d->bc, *tcorh = d->bc + SP, *qcorh = d->bc + 2 * SP;
+    for (size_t i = 0; i < sched.size() && !rc; ++i) {
+        rc = sml_dyn_impint(d, sched[i].dt_imp, alph);
+        if (rc) break;
+        const ImpSlot *imp = d->cur;
+        if (i == 0) {
+            hipLaunchKernelGGL(k_mspace, dim3(MX), dim3(MS_THREADS), MS_LDS, st, d->d, d->win, sched[0].a, imp->lv.sdrag, 0, sched[0].a.j2,
+                               (const double *)d->fb, d->fa, state_dev, (const double *)imp->d_h, (const double *)imp->d_x, phis, tcorh, qcorh);
+            SML_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_latspace, dim3(IL), dim3(LS_THREADS), LS_LDS, st, d->d, d->win, imp->lv.akap,
+                           (const double *)(imp->d_x + 128 + LMAX * 64), (const double *)d->fa, d->fb);
+        SML_HIP(hipGetLastError());
+        const int next_j2 = i + 1 < sched.size() ? sched[i + 1].a.j2 : 0;
+        hipLaunchKernelGGL(k_mspace, dim3(MX), dim3(MS_THREADS), MS_LDS, st, d->d, d->win, sched[i].a, imp->lv.sdrag, 1, next_j2,
+                           (const double *)d->fb, d->fa, state_dev, (const double *)imp->d_h, (const double *)imp->d_x, phis, tcorh, qcorh);
+        SML_HIP(hipGetLastError());
+    }
+    if (!rc) rc = sml_dyn_impint(d, 2 * delt, alph);
     return rc;
 }
 

@@ -206,3 +206,41 @@ def test_state_of_rest_stays_at_rest(dyn):
     assert np.max(np.abs(out[:, F_VOR:F_T])) < 1e-15          # no wind is generated
     assert rel(out[:, F_T:F_T + 8], s[:, F_T:F_T + 8]) < 1e-12
     assert np.max(np.abs(out[:, F_PS])) < 1e-12
+
+
+@pytest.mark.parametrize("two_kernel", [False, True])
+def test_window_equals_step_by_step(dyn, oracle, two_kernel, monkeypatch):
+    """sml_dyn_window enqueues the whole schedule; with two_kernel it runs every time step as two kernels (zonal-wavenumber
+    space <-> latitude space, k_mspace / k_latspace) instead of four launches over whole fields.  All forms keep the
+    reference's summation orders, so a window must give the same BITS as the same schedule issued step by step."""
+    from speedy_ml_amd import _lib
+    check = _lib.check
+    check(_lib.lib().sml_dyn_select_window_form(1 if two_kernel else 0))
+    from _oracle import oracle_iogrid30
+    from speedy_ml_amd import synth
+    g4, logp, _, _ = synth.synthetic_state(9)
+    lvl = oracle_iogrid30(oracle, g4, logp)
+    phis0 = synth.synthetic_orography()
+    phis = oracle.trunct(oracle.spec(phis0.T))
+    tcorh = oracle.trunct(oracle.spec((phis0 * 6.0 / (1000.0 * 9.81)).T))
+    qcorh = oracle.trunct(oracle.spec((phis0 * 1e-7).T))
+    dyn.set_boundary(spec2(phis), spec2(tcorh), spec2(qcorh))
+    st = {k: np.stack([lvl[k], lvl[k] * 0.5], axis=-1) for k in KEYS}
+    a, b = to_state(st), to_state(st)
+    nsteps = 5
+    dyn.window(a, nsteps, start=True)
+    dyn.impint(0.5 * DELT); dyn.step(b, 1, 1, 0.5 * DELT)
+    dyn.impint(DELT); dyn.step(b, 1, 2, DELT)
+    dyn.impint(2 * DELT)
+    for _ in range(nsteps):
+        dyn.step(b, 2, 2, 2 * DELT)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
+    diff = float((a - b).abs().max())
+    assert torch.equal(a, b), diff
+    # a window without the starter steps (start=False) continues a leapfrog run
+    dyn.window(a, 3, start=False)
+    for _ in range(3):
+        dyn.step(b, 2, 2, 2 * DELT)
+    assert torch.equal(a, b)
+    check(_lib.lib().sml_dyn_select_window_form(-1))
