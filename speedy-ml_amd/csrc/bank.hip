@@ -559,8 +559,15 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
 {
     // measured on MI355X (1152 reservoirs, event-timed): <17,64> 1.40 ms, <17,128> 1.46, <17,256> 1.58, <8,128> 1.57,
     // <17,512> 1.89, <34,256> 1.84, <34,128> 2.03 ms; non-temporal vs plain loads within 1 %.  One wavefront per workgroup wins.
-    static const int variant = getenv("SML_RO_VARIANT") ? atoi(getenv("SML_RO_VARIANT")) : 7;
+    // With few resident reservoirs (a rank of an 8-GPU run holds 144) one wavefront per 17 rows leaves the chip short of
+    // loads in flight (144 reservoirs: 0.44 ms = 2.1 TB/s); the columns of a row group are then split over 2 / 4 / 8 wavefronts.
+    static const int forced = getenv("SML_RO_VARIANT") ? atoi(getenv("SML_RO_VARIANT")) : -1;
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
+    int variant = forced;
+    if (variant < 0) {
+        const int groups = nres8 * ((b->max_n_out_loaded + 16) / 17);       // workgroups of the one-wavefront form
+        variant = groups >= 4608 ? 7 : (groups >= 2304 ? 4 : (groups >= 1152 ? 13 : 1));
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = b->timing && !(flags & 4);       // the small physics-model block (part 2) is not the roofline kernel
     if (flags & (8 | 16)) {
@@ -611,6 +618,7 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
     case 10: RO_LAUNCH(17, 128, false) break;
     case 11: RO_LAUNCH(8, 64, true) break;
     case 12: RO_LAUNCH(34, 64, true) break;
+    case 13: RO_LAUNCH(17, 256, true) break;
     case 0: RO_LAUNCH(RO_ROWS, 256, true) break;
     default: RO_LAUNCH(RO_ROWS, 64, true) break;
     }
