@@ -263,6 +263,11 @@ int sml_spectral_spec_mixed(sml_spectral *sp, const double *vorg_dev, double *vo
  * (type, src0, src1, kcos) per output field, src = field index into spec_base_dev ([.][32][62]):
  *   type 0: field src0;  1 | 2: ucos | vcos of uvspec(vor = src0, div = src1);  3 | 4: d/dx | d/dy of grad(src0). */
 int sml_spectral_grid_derived(sml_spectral *sp, const double *spec_base_dev, const int32_t *desc_dev, double *vorg_dev, int nf, void *stream);
+/* The forward counterpart: after a (mixed) forward transform, form the output fields in one launch.  desc_dev: int32
+ * [nf_out][4] = (type, src0, src1, truncate): type 0 = field src0; 5 | 6 = vor | div of vds(ucos = src0, vcos = src1)
+ * (:307-349); truncate != 0 applies trunct (:540-551).  iogrid(30)'s vdspec/spec/trunct (src/ppo_iogrid.f90:530-547) is
+ * sml_spectral_spec_mixed + this. */
+int sml_spectral_spec_post(sml_spectral *sp, const double *spec_in_dev, const int32_t *desc_dev, double *spec_out_dev, int nf_out, void *stream);
 int sml_spectral_vdspec(sml_spectral *sp, const double *ug_dev, const double *vg_dev, double *vorm_dev,
                         double *divm_dev, int nf, int kcos, void *stream);                                    /* :416-452 */
 int sml_spectral_uvspec(sml_spectral *sp, const double *vorm_dev, const double *divm_dev, double *ucosm_dev,

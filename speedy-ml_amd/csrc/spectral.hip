@@ -378,6 +378,35 @@ __global__ void k_uvvds(DevTables T, const double *__restrict__ P, const double 
     B[t] = b;
 }
 
+// Spectral post-processing by descriptor (sml_spectral_spec_post): out field f = trunct?( type 0: field src0 | type 5 / 6: vor /
+// div of vds(ucos = src0, vcos = src1) ).  Same expressions as k_uvvds followed by k_scale(OP_TRUNCT).
+__global__ void k_post(DevTables T, const double *__restrict__ in, const int *__restrict__ desc, double *__restrict__ out, int total)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int f = t / SPEC_N, e = t % SPEC_N, c = e % MX2, n = e / MX2, m = c >> 1;
+    const int type = desc[4 * f], src0 = desc[4 * f + 1], src1 = desc[4 * f + 2], trunc = desc[4 * f + 3];
+    double v;
+    if (type == 0) {
+        v = in[(size_t)src0 * SPEC_N + e];
+    } else {
+        const double *P = in + (size_t)src0 * SPEC_N, *Q = in + (size_t)src1 * SPEC_N;
+        const int row = n * MX2;
+        const double gx = T.gradx[m], ym = T.vddym[n * MX + m], yp = T.vddyp[n * MX + m];
+        if (type == 5) {
+            if (n == 0) v = irot(Q, row, c, gx) - T.vddyp[m] * P[row + MX2 + c];
+            else if (n == NX - 1) v = ym * P[row - MX2 + c];
+            else v = ym * P[row - MX2 + c] - yp * P[row + MX2 + c] + irot(Q, row, c, gx);
+        } else {
+            if (n == 0) v = irot(P, row, c, gx) + T.vddyp[m] * Q[row + MX2 + c];
+            else if (n == NX - 1) v = -ym * Q[row - MX2 + c];
+            else v = -ym * Q[row - MX2 + c] + yp * Q[row + MX2 + c] + irot(P, row, c, gx);
+        }
+    }
+    if (trunc) v = v * T.trfilt[n * MX + m];
+    out[t] = v;
+}
+
 // grad (:271-305)
 __global__ void k_grad(DevTables T, const double *__restrict__ psi, double *__restrict__ dx, double *__restrict__ dy, int total)
 {
@@ -551,6 +580,16 @@ int sml_spectral_spec_mixed(sml_spectral *sp, const double *vorg, double *vorm, 
     SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg && scale_dev)), "sml_spectral_spec_mixed: bad arguments");
     if (!nf) return SML_OK;
     hipLaunchKernelGGL(k_spec, dim3(nf * NMG), dim3(TT), 0, sml::as_stream(stream), sp->d, vorg, vorm, 0, (const int *)scale_dev);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_spec_post(sml_spectral *sp, const double *spec_in, const int32_t *desc_dev, double *spec_out, int nf_out, void *stream)
+{
+    SML_REQUIRE(sp && nf_out >= 0 && (nf_out == 0 || (spec_in && desc_dev && spec_out)), "sml_spectral_spec_post: bad arguments");
+    if (!nf_out) return SML_OK;
+    const int total = nf_out * SPEC_N;
+    hipLaunchKernelGGL(k_post, dim3((total + 255) / 256), dim3(256), 0, sml::as_stream(stream), sp->d, spec_in, (const int *)desc_dev, spec_out, total);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }

@@ -169,6 +169,13 @@ class HybridRank:
                     + [(2, F_VOR + k, F_DIV + k, 2) for k in range(8)] + [(0, F_TR + k, F_TR + k, 1) for k in range(8)]
                     + [(0, F_PS, F_PS, 1)])
             self.out_desc = torch.tensor(rows, dtype=torch.int32, device=dev)
+            # iogrid(30)'s forward side in two launches: all 33 fields [t u v q ps] transformed at once (u, v pre-scaled by 1/cos as
+            # vdspec(.,.,2) does), then vds + trunct straight into time level 1 of the state [vor div t q ps]
+            self.in_scale = torch.tensor([0] * 8 + [1] * 16 + [0] * 9, dtype=torch.int32, device=dev)
+            rows = ([(5, 8 + k, 16 + k, 1) for k in range(8)] + [(6, 8 + k, 16 + k, 1) for k in range(8)]
+                    + [(0, k, k, 1) for k in range(8)] + [(0, 24 + k, 24 + k, 1) for k in range(8)] + [(0, 32, 32, 1)])
+            self.in_desc = torch.tensor(rows, dtype=torch.int32, device=dev)
+            self.raw_spec = torch.zeros((33, NX, MX2), dtype=f64, device=dev)
             self.safe = torch.ones(1, dtype=torch.int32, device=dev)
             self.dyn = Dynamics(self.sp)
             # boundary fields: surface geopotential and the diffusion correction terms (ini_fordate.f90:72-113); the
@@ -285,11 +292,8 @@ class HybridRank:
         the grid for the physical-range guard.  33 fields per launch."""
         sp, S = self.sp, self.state[0]
         handoff_to_fields(self.G, self.fields, stream)
-        fT, fu, fv, fq_ps = self.fields[0:8], self.fields[8:16], self.fields[16:24], self.fields[24:33]
-        sp.vdspec(fu, fv, 2, out=(S[F_VOR:F_VOR + 8], S[F_DIV:F_DIV + 8]), stream=stream)
-        sp.spec(fT, out=S[F_T:F_T + 8], stream=stream)
-        sp.spec(fq_ps, out=S[F_TR:F_PS + 1], stream=stream)
-        sp.trunct(S, stream=stream)
+        sp.spec_mixed(self.fields, self.in_scale, out=self.raw_spec, stream=stream)
+        sp.spec_post(self.raw_spec, self.in_desc, S, stream=stream)
         self.to_grid(stream)
         handoff_check(self.fields_out, self.safe, stream)
 

@@ -84,6 +84,16 @@ class Spectral:
         check(_lib.lib().sml_spectral_grid_derived(self._h, dp(base.data_ptr()), _lib.ip(desc.data_ptr()), dp(out.data_ptr()), nf, vp(stream)))
         return out
 
+    def spec_post(self, spec_in, desc, out, stream=None):
+        """Output fields from transformed fields in one launch: desc int32 [nf_out, 4] = (type, src0, src1, truncate); type 0
+        field src0, 5|6 vor|div of vds(src0, src1)."""
+        self._chk(spec_in, (NX, MX2))
+        nf = desc.shape[0]
+        assert desc.is_cuda and desc.element_size() == 4 and desc.is_contiguous() and tuple(desc.shape) == (nf, 4)
+        assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (nf, NX, MX2)
+        check(_lib.lib().sml_spectral_spec_post(self._h, dp(spec_in.data_ptr()), _lib.ip(desc.data_ptr()), dp(out.data_ptr()), nf, vp(stream)))
+        return out
+
     def spec_mixed(self, vorg, scale_flags, out=None, stream=None):
         """One launch for fields with different forward pre-scaling (0 none, 1 *cosgr, 2 *cosgr2 per field)."""
         nf = self._chk(vorg, (IL, IX))

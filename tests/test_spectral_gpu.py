@@ -201,3 +201,22 @@ def test_grid_derived_equals_separate_operators(sp):
             src = dx if typ == 3 else dy
         want = sp.grid(src.contiguous(), kcos)
         assert torch.equal(got[f], want[0]), (f, typ)
+
+
+def test_spec_post_equals_separate_operators(sp):
+    """vds + trunct by descriptor give the same bits as vds followed by trunct."""
+    rng = np.random.default_rng(12)
+    raw = torch.from_numpy(rng.standard_normal((5, NX, MX2))).cuda()
+    rows = [(5, 0, 1, 1), (6, 0, 1, 1), (0, 2, 2, 1), (6, 3, 4, 0), (0, 4, 4, 0), (5, 3, 4, 0)]
+    desc = torch.tensor(rows, dtype=torch.int32, device="cuda")
+    out = torch.zeros((len(rows), NX, MX2), dtype=torch.float64, device="cuda")
+    sp.spec_post(raw, desc, out)
+    for f, (typ, a, b, tr) in enumerate(rows):
+        if typ == 0:
+            want = raw[a:a + 1].clone()
+        else:
+            vor, div = sp.vds(raw[a:a + 1].contiguous(), raw[b:b + 1].contiguous())
+            want = (vor if typ == 5 else div).clone()
+        if tr:
+            sp.trunct(want)
+        assert torch.equal(out[f], want[0]), (f, typ)
