@@ -37,6 +37,75 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_baseline(model, budget_s=12.0):
+    """Reference-faithful CPU path (the oracle, 1 core) on a bounded sample of the same workload.  The only place outside
+    tests/ and smoke() that touches oracle/: it is the reported baseline, never part of the measured or shipped path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import Oracle
+    from speedy_ml_amd.dynamics import DELT
+    from speedy_ml_amd.hybrid import NREG
+    from speedy_ml_amd.spectral import IL, IX, MX2, NX
+    from speedy_ml_amd.synth import make_reservoir
+    o = Oracle()
+    r = make_reservoir(seed=20240954)          # interior + SST class, dense W_in as the reference stores it
+    x = np.zeros(r.n)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s or n < 3:
+        x, out = o.predict_raw(r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, 1.0,
+                               r.feedback, r.local_model, x)
+        n += 1
+    per_predict = (time.perf_counter() - t0) / n
+    sample = (f"{n} reference-faithful predict calls (COO SpMV, dense 26.5 MB W_in matmul, W_out GEMV) of one interior "
+              f"reservoir: {per_predict * 1e3:.3f} ms each, x1152 per step")
+    total = per_predict * NREG
+    if model.mode == "hybrid":
+        from _oracle import DynOracle, RefSpectral
+        rng = np.random.default_rng(1)
+        v = rng.standard_normal((MX2, NX))
+        gfield = rng.standard_normal((IX, IL))
+        # transforms: the COMPILED REFERENCE (oracle/_ref: the reference's own FFTPACK + Legendre code) when its .so
+        # travelled with the snapshot, else the oracle's direct-DFT restatement (5x slower: flattering)
+        eng = RefSpectral() if RefSpectral.available() else o
+        which = "compiled reference spe_spectral.f90/FFTPACK (oracle/_ref)" if RefSpectral.available() else "oracle direct-DFT restatement"
+
+        def pair_time(e, budget):
+            t1 = time.perf_counter()
+            m = 0
+            while time.perf_counter() - t1 < budget:
+                e.grid(v, 1)
+                e.spec(gfield)
+                m += 1
+            return (time.perf_counter() - t1) / m, m
+        per_pair, m = pair_time(eng, 2.0)
+        per_pair_oracle, _ = pair_time(o, 1.0)
+        # one adiabatic time step with the oracle (dynamics_oracle.c); its own direct-DFT transforms are swapped for the
+        # reference's FFTPACK ones in the estimate: 50 inverse + 73 forward per step
+        dyn = DynOracle(o)
+        dyn.impint(2 * DELT, 0.5)
+        mask = np.repeat(o.table(11), 2, axis=0)
+        small = lambda shape, sc: rng.standard_normal(shape) * sc * mask.reshape((MX2, NX) + (1,) * (len(shape) - 2))
+        st = {"vor": small((MX2, NX, 8, 2), 1e-7), "div": small((MX2, NX, 8, 2), 1e-8), "t": small((MX2, NX, 8, 2), 0.1),
+              "tr": small((MX2, NX, 8, 2), 1e-4), "ps": small((MX2, NX, 2), 1e-4)}
+        st["t"][0, 0] += dyn.table(17)[:, None] * np.sqrt(2.0)
+        zero = np.zeros((MX2, NX))
+        t1 = time.perf_counter()
+        ns = 0
+        while time.perf_counter() - t1 < 3.0 or ns < 2:
+            st = dyn.step_dry(2, 2, 2 * DELT, 0.5, 0.05, 0.53, st, zero, zero, zero)
+            ns += 1
+        per_step_oracle = (time.perf_counter() - t1) / ns
+        per_tr, per_tr_oracle = per_pair / 2.0, per_pair_oracle / 2.0
+        per_step = max(per_step_oracle - 123 * per_tr_oracle, 0.0) + 123 * per_tr
+        nst = 0 if model.leapfrog_steps is None else model.leapfrog_steps + 2
+        total += per_tr * 99 + per_step * nst
+        sample += (f"; SPEEDY leg: {m} grid+spec pairs with the {which}: {per_pair * 1e6:.0f} us per pair (incl. ctypes overhead); "
+                   f"{ns} adiabatic time steps with the oracle: {per_step_oracle * 1e3:.2f} ms each, of which its 123 direct-DFT "
+                   f"transforms are re-priced at the reference's transform cost -> {per_step * 1e3:.2f} ms per step, x{nst} steps "
+                   f"+ 99 hand-off transforms per hybrid step; exchange tilers not timed (small)")
+    return {"value": 1.0 / total, "unit": "steps/s", "cores": 1, "kind": "port", "sample": sample}
+
+
 def main():
     args = parse()
     import torch
@@ -142,7 +211,7 @@ def main():
                                        "algorithmic_bytes_per_launch": upd_b, "avg_launch_ms": upd_ms}},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = model.cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
