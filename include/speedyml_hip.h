@@ -35,6 +35,13 @@ int sml_version(void);
 /* number of visible HIP devices (0 on a CPU-only box; never initialises a context) */
 int sml_device_count(void);
 int sml_set_device(int ordinal);
+/* device memory for hosts without a HIP binding of their own (the Fortran drop-ins of speedy-ml_amd/fortran/): hipMalloc,
+ * hipFree, hipMemset(0), synchronous hipMemcpy in either direction */
+int sml_dev_alloc(uint64_t bytes, void **out_dev);
+int sml_dev_free(void *dev);
+int sml_dev_zero(void *dev, uint64_t bytes);
+int sml_dev_upload(void *dst_dev, const void *src_host, uint64_t bytes);
+int sml_dev_download(void *dst_host, const void *src_dev, uint64_t bytes);
 
 /* ===================================================================================================
  * 1. resdomain: integer bookkeeping (host only, no GPU needed) -- replaces src/res_domain.f90

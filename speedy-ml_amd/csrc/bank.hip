@@ -648,6 +648,41 @@ int sml_set_device(int ordinal)
     return SML_OK;
 }
 
+// device memory for hosts that have no HIP binding of their own (the Fortran drop-ins): plain hipMalloc / hipMemcpy
+int sml_dev_alloc(uint64_t bytes, void **out_dev)
+{
+    SML_REQUIRE(out_dev, "sml_dev_alloc: null pointer");
+    SML_HIP(hipMalloc(out_dev, bytes ? bytes : 16));
+    return SML_OK;
+}
+
+int sml_dev_free(void *dev)
+{
+    if (dev) SML_HIP(hipFree(dev));
+    return SML_OK;
+}
+
+int sml_dev_zero(void *dev, uint64_t bytes)
+{
+    SML_REQUIRE(dev || !bytes, "sml_dev_zero: null pointer");
+    if (bytes) SML_HIP(hipMemset(dev, 0, bytes));
+    return SML_OK;
+}
+
+int sml_dev_upload(void *dst_dev, const void *src_host, uint64_t bytes)
+{
+    SML_REQUIRE((dst_dev && src_host) || !bytes, "sml_dev_upload: null pointer");
+    if (bytes) SML_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+int sml_dev_download(void *dst_host, const void *src_dev, uint64_t bytes)
+{
+    SML_REQUIRE((dst_host && src_dev) || !bytes, "sml_dev_download: null pointer");
+    if (bytes) SML_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return SML_OK;
+}
+
 int sml_bank_create(int capacity, int max_d, int max_n_model, int max_n_out, sml_bank **out)
 {
     SML_REQUIRE(out && capacity > 0 && max_d > 0 && max_n_model >= 0 && max_n_out > 0, "sml_bank_create: bad arguments");

@@ -3,6 +3,8 @@
 !     mklsparse(reservoir)                      src/mod_linalg.f90:10-25     (build the device-resident operator)
 !     synchronize(reservoir, input, x, length)  src/mod_reservoir.f90:1354-1381
 !     predict(reservoir, x, local_model_in)     src/mod_reservoir.f90:1418-1489
+!     chunking_matmul(reservoir, states, model, targets)   src/mod_reservoir.f90:1645-1701 (Gram accumulation on the device)
+!     fit_chunk_hybrid(reservoir)               src/mod_reservoir.f90:1235-1334 + mldivide src/mod_linalg.f90:109-151
 ! The reference's reservoir_type (src/mod_utilities.f90:168-330) carries MKL handles (cooA, descrA); the patch shown
 ! in INTEGRATION.md replaces them by the two fields hip_bank / hip_slot below.  This module defines a reduced
 ! reservoir_type with exactly the fields those three routines touch so that it builds stand-alone (the full type
@@ -26,6 +28,10 @@ module mod_reservoir_hip
     integer, allocatable       :: out_stat_idx(:)          ! from sml_domain_out_map
     type(c_ptr) :: hip_bank = c_null_ptr                   ! replaces cooA / descrA
     integer(c_int) :: hip_slot = 0
+    ! training (src/mod_utilities.f90:262-266): the Gram matrices stay on the device between batches
+    real(kind=dp) :: beta_res = 0.001_dp, beta_model = 1.0_dp, prior_val = 0.0_dp
+    logical :: using_prior = .true.
+    type(c_ptr) :: hip_c = c_null_ptr, hip_b = c_null_ptr  ! states_x_states_aug (n_aug,n_aug), states_x_trainingdata_aug (n_out,n_aug)
   end type
 
 contains
@@ -77,6 +83,50 @@ contains
     call sml_check(rc, 'sml_bank_set_feedback')
     rc = sml_bank_predict_one(reservoir%hip_bank, reservoir%hip_slot, x, reservoir%local_model, reservoir%outvec)
     call sml_check(rc, 'sml_bank_predict_one')
+  end subroutine
+
+  ! chunking_matmul (src/mod_reservoir.f90:1645-1701): one batch of (squared-even) reservoir states, imperfect-model
+  ! forecasts and targets is folded into the device-resident Gram matrices:  C += aug aug^T (tiles on/below the diagonal),
+  ! B += Y aug^T with aug = [model ; states].  The reference slices model/targets out of imperfect_model_states / trainingdata
+  ! by batch number; here the caller passes the three blocks.
+  subroutine chunking_matmul(reservoir, states, model_block, target_block)
+    type(reservoir_type), intent(inout) :: reservoir
+    real(kind=dp), intent(in) :: states(:,:), model_block(:,:), target_block(:,:)     ! (n,m), (n_model,m), (n_out,m)
+    integer(c_int) :: n, nm, no, m
+    integer(c_int64_t) :: naug
+    type(c_ptr) :: ds, dm, dy
+    n = size(states, 1); m = size(states, 2); nm = size(model_block, 1); no = size(target_block, 1)
+    naug = int(n + nm, c_int64_t)
+    if (.not. c_associated(reservoir%hip_c)) then               ! initialize_chunk_training (:1561-1592): zeroed accumulators
+      call sml_check(sml_dev_alloc(8_c_int64_t*naug*naug, reservoir%hip_c), 'sml_dev_alloc')
+      call sml_check(sml_dev_alloc(8_c_int64_t*naug*no, reservoir%hip_b), 'sml_dev_alloc')
+      call sml_check(sml_dev_zero(reservoir%hip_c, 8_c_int64_t*naug*naug), 'sml_dev_zero')
+      call sml_check(sml_dev_zero(reservoir%hip_b, 8_c_int64_t*naug*no), 'sml_dev_zero')
+    end if
+    call sml_check(sml_dev_alloc(8_c_int64_t*n*m, ds), 'sml_dev_alloc')
+    call sml_check(sml_dev_alloc(8_c_int64_t*max(nm, 1)*m, dm), 'sml_dev_alloc')
+    call sml_check(sml_dev_alloc(8_c_int64_t*no*m, dy), 'sml_dev_alloc')
+    call sml_check(sml_dev_upload(ds, states, 8_c_int64_t*n*m), 'sml_dev_upload')
+    if (nm > 0) call sml_check(sml_dev_upload(dm, model_block, 8_c_int64_t*nm*m), 'sml_dev_upload')
+    call sml_check(sml_dev_upload(dy, target_block, 8_c_int64_t*no*m), 'sml_dev_upload')
+    call sml_check(sml_train_accumulate(ds, dm, dy, n, nm, no, m, reservoir%hip_c, reservoir%hip_b, c_null_ptr), 'sml_train_accumulate')
+    call sml_check(sml_dev_free(ds), 'sml_dev_free')            ! hipFree waits for the accumulation
+    call sml_check(sml_dev_free(dm), 'sml_dev_free')
+    call sml_check(sml_dev_free(dy), 'sml_dev_free')
+  end subroutine
+
+  ! fit_chunk_hybrid (src/mod_reservoir.f90:1235-1334): ridge regularisation, dgesv on the transposed system, wout = Z^T.
+  ! reservoir%wout (n_out, n_aug) is overwritten; the accumulators stay on the device (sml_train_fit does not destroy them).
+  subroutine fit_chunk_hybrid(reservoir)
+    type(reservoir_type), intent(inout) :: reservoir
+    integer(c_int) :: n, nm, no
+    type(c_ptr) :: dw
+    n = reservoir%n; nm = reservoir%chunk_size_speedy; no = reservoir%chunk_size_prediction
+    call sml_check(sml_dev_alloc(8_c_int64_t*no*(n + nm), dw), 'sml_dev_alloc')
+    call sml_check(sml_train_fit(reservoir%hip_c, reservoir%hip_b, n, nm, no, reservoir%beta_res, reservoir%beta_model, &
+                                 reservoir%prior_val, merge(1_c_int, 0_c_int, reservoir%using_prior), dw, c_null_ptr), 'sml_train_fit')
+    call sml_check(sml_dev_download(reservoir%wout, dw, 8_c_int64_t*no*(n + nm)), 'sml_dev_download')
+    call sml_check(sml_dev_free(dw), 'sml_dev_free')
   end subroutine
 
 end module mod_reservoir_hip

@@ -93,6 +93,53 @@ module speedyml_hip
       type(c_ptr), value :: bank, stream
       integer(c_int) :: rc
     end function
+    ! ---- device memory helpers and the training kernels (include/speedyml_hip.h section 5) ----
+    function sml_dev_alloc(bytes, dev) bind(C, name="sml_dev_alloc") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      integer(c_int64_t), value :: bytes
+      type(c_ptr), intent(out) :: dev
+      integer(c_int) :: rc
+    end function
+    function sml_dev_free(dev) bind(C, name="sml_dev_free") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: dev
+      integer(c_int) :: rc
+    end function
+    function sml_dev_zero(dev, bytes) bind(C, name="sml_dev_zero") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: dev
+      integer(c_int64_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+    function sml_dev_upload(dst_dev, src_host, bytes) bind(C, name="sml_dev_upload") result(rc)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: dst_dev
+      real(c_double), intent(in) :: src_host(*)
+      integer(c_int64_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+    function sml_dev_download(dst_host, src_dev, bytes) bind(C, name="sml_dev_download") result(rc)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      real(c_double), intent(out) :: dst_host(*)
+      type(c_ptr), value :: src_dev
+      integer(c_int64_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+    function sml_train_accumulate(states_dev, model_dev, y_dev, n, n_model, n_out, m, c_dev, b_dev, stream) &
+             bind(C, name="sml_train_accumulate") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: states_dev, model_dev, y_dev, c_dev, b_dev, stream
+      integer(c_int), value :: n, n_model, n_out, m
+      integer(c_int) :: rc
+    end function
+    function sml_train_fit(c_dev, b_dev, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout_dev, stream) &
+             bind(C, name="sml_train_fit") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: c_dev, b_dev, wout_dev, stream
+      integer(c_int), value :: n, n_model, n_out, using_prior
+      real(c_double), value :: beta_res, beta_model, prior_val
+      integer(c_int) :: rc
+    end function
     ! ---- spectral handle + SPEEDY adiabatic time step (include/speedyml_hip.h sections 4 and 4a) ----
     function sml_spectral_create(a, sp) bind(C, name="sml_spectral_create") result(rc)
       import :: c_int, c_double, c_ptr

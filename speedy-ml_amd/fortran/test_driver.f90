@@ -23,6 +23,9 @@ program test_driver
   complex(c_double_complex) :: vorA(mx,nx,kx,2), tA(mx,nx,kx,2), psA(mx,nx,2)
   real(kind=dp) :: fsg(kx), rgam
   integer :: kk, m2, n2
+  integer, parameter :: mb = 48
+  real(kind=dp), allocatable :: tstates(:,:), tmodel(:,:), ty(:,:), aug(:,:), c_host(:,:), b_host(:,:), resid(:,:)
+  integer :: ib, naug
 
   if (sml_device_count() < 1) then
     print *, 'test_driver: no HIP device visible'
@@ -124,6 +127,46 @@ program test_driver
   errx = maxval(abs(back - vorm(:,:,1)))/maxval(abs(vorm(:,:,1)))
   print '(a,es10.3)', 'spec(grid(v)) rel err = ', errx
   if (errx > 1.0e-12_dp) nfail = nfail + 1
+
+  ! ---- training: chunking_matmul (two batches) + fit_chunk_hybrid on the device against the normal equations formed with
+  ! Fortran matmul on the host:  wout (C + reg) = B + prior  (src/mod_reservoir.f90:1261-1313) ----
+  naug = n + n_model
+  allocate(tstates(n,mb), tmodel(n_model,mb), ty(n_out,mb), aug(naug,mb), c_host(naug,naug), b_host(n_out,naug), resid(n_out,naug))
+  c_host = 0.0_dp; b_host = 0.0_dp
+  do ib = 1, 2
+    do j = 1, mb
+      do i = 1, n
+        tstates(i,j) = 2.0_dp*rnd()-1.0_dp
+      end do
+      do i = 1, n_model
+        tmodel(i,j) = 2.0_dp*rnd()-1.0_dp
+      end do
+      do i = 1, n_out
+        ty(i,j) = 2.0_dp*rnd()-1.0_dp
+      end do
+    end do
+    call chunking_matmul(res, tstates, tmodel, ty)
+    aug(1:n_model,:) = tmodel
+    aug(n_model+1:naug,:) = tstates
+    c_host = c_host + matmul(aug, transpose(aug))
+    b_host = b_host + matmul(ty, transpose(aug))
+  end do
+  res%beta_res = 0.001_dp; res%beta_model = 1.0_dp; res%prior_val = 0.5_dp; res%using_prior = .true.
+  call fit_chunk_hybrid(res)
+  do i = 1, naug                                             ! with a prior the betas enter squared (quirk Q8, :1271-1290)
+    if (i <= n_model) then
+      c_host(i,i) = c_host(i,i) + res%beta_model**2
+    else
+      c_host(i,i) = c_host(i,i) + res%beta_res**2
+    end if
+  end do
+  do i = 1, n_model
+    b_host(i,i) = b_host(i,i) + res%prior_val*res%beta_model**2
+  end do
+  resid = matmul(res%wout, c_host) - b_host
+  erro = maxval(abs(resid))/maxval(abs(b_host))
+  print '(a,es10.3)', 'training: max|wout (C+reg) - (B+prior)| / max|B| = ', erro
+  if (.not. (erro < 1.0e-9_dp)) nfail = nfail + 1
 
   ! ---- SPEEDY adiabatic time stepping: the external subroutines impint/step/stepone (host arrays in the reference's
   ! shapes, one round trip per call) against the device-resident window; same kernels -> identical bits ----
