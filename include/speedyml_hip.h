@@ -217,6 +217,17 @@ int sml_handoff_to_fields(const double *g_dev, double *fields_dev, void *stream)
 int sml_handoff_from_fields(const double *fields_dev, double *f_dev, void *stream);
 int sml_handoff_check(const double *fields_dev, int32_t *safe_dev, void *stream);
 
+/* ---- RCCL from the C-ABI, for a multi-rank host that is not Python (Fortran under MPI): the step's one data-path collective.
+ * One rank calls sml_comm_unique_id and distributes the 128 bytes (MPI_Bcast); every rank then calls sml_comm_create.
+ * sml_comm_allgather_outvec: ncclAllGather of the bank's outvec slab ([capacity][max_n_out] per rank, equal on all ranks) into
+ * all_outvec_dev [nranks*capacity][max_n_out] = the region-ordered slab of sml_exchange_scatter when the region count divides
+ * by the rank count (src/mpires.f90:347-454).  librccl.so is resolved at the first call (dlopen), not at link time. */
+typedef struct sml_comm sml_comm;
+int sml_comm_unique_id(char *id128);
+int sml_comm_create(int nranks, int rank, const char *id128, sml_comm **out);
+int sml_comm_destroy(sml_comm *comm);
+int sml_comm_allgather_outvec(sml_comm *comm, sml_bank *bank, double *all_outvec_dev, void *stream);
+
 /* ---- slab-ocean coupling (config 5): the `ocean_model` branches of sendrecievegrid, src/mpires.f90:286-330, 470-484,
  * 756-790; sizes of initialize_slab_ocean_model, src/mod_slab_ocean_reservoir.f90:9-133.  The slab reservoirs live in a second
  * sml_bank (n_model = 0, every output un-standardised with the SST statistics as predict_slab_ml does, :1318-1363) and are

@@ -55,6 +55,7 @@ EXPORTS = [
     "sml_bank_predict_all", "sml_bank_predict_one", "sml_bank_synchronize_all", "sml_bank_advance_all", "sml_bank_readout_part",
     "sml_bank_algorithmic_bytes", "sml_bank_readout_part_bytes", "sml_bank_timing", "sml_bank_timing_collect",
     "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
+    "sml_comm_unique_id", "sml_comm_create", "sml_comm_destroy", "sml_comm_allgather_outvec",
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",

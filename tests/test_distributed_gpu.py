@@ -61,3 +61,32 @@ def test_two_ranks_equal_one_rank(tmp_path):
         assert np.array_equal(d["G"], G) and np.array_equal(d["F"], F), r
         regs = d["regions"]
         assert np.array_equal(d["fb"], fb[regs]) and np.array_equal(d["lm"], lm[regs]), r
+
+
+def test_rccl_from_the_cabi_single_rank():
+    """sml_comm_*: the C-ABI's own RCCL communicator (for a non-Python multi-rank host).  One rank is all a 1-GPU box can
+    rehearse: the all-gather must reproduce the bank's outvec slab; the N > 1 path is the same call with a wider communicator."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from speedy_ml_amd import _lib
+    from speedy_ml_amd.reservoir import ReservoirBank
+    from speedy_ml_amd.synth import make_reservoir
+    L = _lib.lib()
+    ident = C.create_string_buffer(128)
+    _lib.check(L.sml_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(L.sml_comm_create(1, 0, ident, C.byref(comm)))
+    bank = ReservoirBank(3, max_d=12, max_n_model=4, max_n_out=6)
+    for i in range(3):
+        r = make_reservoir(n=96, d=12, n_model=4, n_out=6, seed=40 + i)
+        bank.load(i, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
+        bank.set_feedback(i, r.feedback)
+        bank.set_local_model(i, r.local_model)
+    bank.predict()
+    slab = torch.zeros((3, 6), dtype=torch.float64, device="cuda")
+    _lib.check(L.sml_comm_allgather_outvec(comm, bank._h, _lib.dp(slab.data_ptr()), None))
+    torch.cuda.synchronize()
+    want = np.stack([bank.get_outvec(i) for i in range(3)])
+    assert np.array_equal(slab.cpu().numpy(), want) and np.abs(want).max() > 0
+    _lib.check(L.sml_comm_destroy(comm))
