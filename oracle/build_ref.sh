@@ -36,3 +36,14 @@ OBJCOPY=/opt/rocm/lib/llvm/bin/llvm-objcopy
 "$FC" -shared -o "$OUT/libref_dyn.so" ref_dyn_driver.o dyn_geop.o dyn_sptend.o dyn_implic.o dyn_step.o ini_indyns.o ini_impint.o spe_matinv.o \
     spe_spectral.o spe_subfft_fftpack.o mod_atparam.o mod_spectral.o mod_fft.o mod_tsteps.o mod_dyncon0.o mod_dyncon1.o mod_dyncon2.o mod_hdifcon.o mod_dynvar.o
 echo "build_ref: wrote $OUT/libref_dyn.so"
+
+# ---- column physics: the reference's parametrisation routines depend only on mod_atparam, mod_physcon and their
+# own constant modules -- compiled in place, no stand-ins.  phypar itself (driver of the grid transforms, coupler fluxes, SPPT)
+# is NOT built: the harness exposes the individual routines it calls.
+for f in mod_physcon mod_cnvcon mod_lsccon mod_radcon mod_sflcon mod_vdicon phy_convmf phy_lscond phy_shtorh phy_radiat phy_suflux phy_vdifsc ini_inphys; do
+  "$FC" $FLAGS -I"$REF" -c "$REF/$f.f90" -o "$f.o" 2>/dev/null
+done
+"$FC" $FLAGS -c "$HERE/ref_phy_driver.f90" -o ref_phy_driver.o 2>/dev/null
+"$FC" -shared -o "$OUT/libref_phy.so" ref_phy_driver.o phy_convmf.o phy_lscond.o phy_shtorh.o phy_radiat.o phy_suflux.o phy_vdifsc.o ini_inphys.o \
+    mod_atparam.o mod_physcon.o mod_cnvcon.o mod_lsccon.o mod_radcon.o mod_sflcon.o mod_vdicon.o
+echo "build_ref: wrote $OUT/libref_phy.so"
