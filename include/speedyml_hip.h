@@ -358,6 +358,39 @@ int sml_dyn_window(sml_dyn *dyn, double *state_dev, int start, int nsteps, doubl
 int sml_dyn_select_window_form(int form);
 
 /* ===================================================================================================
+ * 4c. SPEEDY column physics on the device -- replaces the grid-point part of phypar (src/phy_phypar.f90:80-230) and the
+ *     parametrisations it calls: shtorh, convmf, lscond, cloud, radsw, radlw, suflux, vdifsc (src/phy_*.f90), with the
+ *     set-up routines inphys, radset, sflset, sol_oz.  One kernel, one thread per grid column.  The surface state (land-sea
+ *     mask, orography, land/sea temperatures, soil wetness, albedos, snow cover: the daily output of the reference's coupler
+ *     and of fordate) is an input.  Grids are [nf][48][96] as everywhere.
+ * =================================================================================================== */
+typedef struct sml_phys sml_phys;
+/* inphys(hsg, ., rlat) + radset: hsg9 = sigma half levels 0..8 (src/ini_indyns.f90:38-41), rlat48 = Gaussian latitudes in
+ * radians, south to north (src/ini_indyns.f90:72-80) */
+int sml_phys_create(const double *hsg9, const double *rlat48, sml_phys **out);
+int sml_phys_destroy(sml_phys *phys);
+/* host arrays [48][96]: fmask1, phis0 (mod_surfcon), stl_am, sst_am, soilw_am (mod_var_land / mod_var_sea), alb_l, alb_s,
+ * albsfc, snowc (mod_radcon, set by fordate); sflset(phis0) is applied here */
+int sml_phys_set_surface(sml_phys *phys, const double *fmask, const double *phis0, const double *tland, const double *tsea,
+                         const double *swav, const double *alb_l, const double *alb_s, const double *albsfc, const double *snowc);
+/* the hybrid model's SST grid (G's SST segment, device) becomes sst_am */
+int sml_phys_set_sst_dev(sml_phys *phys, const double *tsea_dev, void *stream);
+/* sol_oz(tyear) (src/phy_radiat.f90:1-83): zonal solar / ozone fields for the day, tyear = fraction of the year */
+int sml_phys_sol_oz(sml_phys *phys, double tyear);
+/* host copies for tests: zonal [6][48] = fsol ozone ozupp zenit stratz sqrt(clat); fband [301][4]; levels [9][9] = sig sigl
+ * dsig sigh grdsig grdscp wvi(:,2) wvi(:,1) entr with level index 1..8 (NULL to skip any) */
+int sml_phys_get_tables(sml_phys *phys, double *zonal_host, double *fband_host, double *levels_host);
+/* phypar's grid-point sequence for every column.  grids_dev [41][48][96]: ug1 vg1 tg1 qg1 phig1 (8 levels each) and pslg1 of
+ * time level 1 (src/phy_phypar.f90:54-66).  The tendencies utend vtend ttend qtend are 8 consecutive fields each of tend_dev,
+ * starting at fields off_u off_v off_t off_q; accumulate != 0 adds the physics to what is there (the dynamical tendencies),
+ * in the reference's order.  lradsw: this is a short-wave step (every nstrad = 3rd, src/dyn_stloop.f90:36). */
+int sml_phys_tendencies(sml_phys *phys, const double *grids_dev, int lradsw, double *tend_dev, int off_u, int off_v, int off_t, int off_q,
+                        int accumulate, void *stream);
+/* per-column diagnostics of the last call, host [48][96]: 0 precnv 1 precls 2 cbmf 3 ts 4 tskin 5 ssrd 6 slrd 7 olr 8 shf 9 evap
+ * 10 ustr 11 vstr 12 cloudc 13 clstr 14 tsr 15 ssr 16 slr 17 hfluxn(land) 18 hfluxn(sea) 19 t0 20 q0 21 iptop 22 icltop */
+int sml_phys_diag(sml_phys *phys, int which, double *out_host);
+
+/* ===================================================================================================
  * 4b. reservoir construction (host, set-up time) -- replaces gen_res / makesparse / shuffle / sparse_eigen
  *     (src/mod_reservoir.f90:182-212, src/mod_linalg.f90:180-514, src/mod_utilities.f90:1569-1596)
  * =================================================================================================== */

@@ -1,0 +1,61 @@
+"""Host-side mirror of SPEEDY's column physics (src/phy_phypar.f90 grid-point part and the phy_*.f90 parametrisations) over the
+C-ABI.  Grids are float64 CUDA tensors [nf, 48, 96]; surface fields are host numpy arrays (48, 96).  No CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, dp, vp
+
+HSG = np.array([0.000, 0.050, 0.140, 0.260, 0.420, 0.600, 0.770, 0.900, 1.000])      # src/ini_indyns.f90:38-41
+NSTRAD = 3                                                                               # src/mod_tsteps.f90:65
+DIAG = {n: i for i, n in enumerate(("precnv", "precls", "cbmf", "ts", "tskin", "ssrd", "slrd", "olr", "shf", "evap", "ustr", "vstr",
+                                    "cloudc", "clstr", "tsr", "ssr", "slr", "hfluxn_land", "hfluxn_sea", "t0", "q0", "iptop", "icltop"))}
+
+
+class Physics:
+    def __init__(self, rlat, hsg=HSG):
+        """rlat: the 48 Gaussian latitudes in radians, south to north (radang of src/ini_indyns.f90:72-80)"""
+        h = C.c_void_p()
+        check(_lib.lib().sml_phys_create(dp(np.ascontiguousarray(hsg, dtype=np.float64)), dp(np.ascontiguousarray(rlat, dtype=np.float64)), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            _lib.lib().sml_phys_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_surface(self, fmask, phis0, tland, tsea, swav, alb_l, alb_s, albsfc, snowc):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (fmask, phis0, tland, tsea, swav, alb_l, alb_s, albsfc, snowc)]
+        assert all(x.shape == (48, 96) for x in a)
+        check(_lib.lib().sml_phys_set_surface(self._h, *[dp(x) for x in a]))
+
+    def set_sst(self, tsea_dev, stream=None):
+        assert tsea_dev.is_cuda and tsea_dev.numel() == 4608 and tsea_dev.is_contiguous()
+        check(_lib.lib().sml_phys_set_sst_dev(self._h, dp(tsea_dev.data_ptr()), vp(stream)))
+
+    def sol_oz(self, tyear):
+        check(_lib.lib().sml_phys_sol_oz(self._h, C.c_double(tyear)))
+
+    def tables(self):
+        z, f, l = np.zeros((6, 48)), np.zeros((301, 4)), np.zeros((9, 9))
+        check(_lib.lib().sml_phys_get_tables(self._h, dp(z), dp(f), dp(l)))
+        return z, f, l
+
+    def tendencies(self, grids, lradsw, tend, off=(0, 8, 16, 24), accumulate=False, stream=None):
+        assert grids.is_cuda and grids.is_contiguous() and tuple(grids.shape) == (41, 48, 96)
+        assert tend.is_cuda and tend.is_contiguous() and tend.shape[0] >= max(off) + 8
+        check(_lib.lib().sml_phys_tendencies(self._h, dp(grids.data_ptr()), 1 if lradsw else 0, dp(tend.data_ptr()), *[int(o) for o in off],
+                                             1 if accumulate else 0, vp(stream)))
+        return tend
+
+    def diag(self, name):
+        out = np.zeros((48, 96))
+        check(_lib.lib().sml_phys_diag(self._h, DIAG[name], dp(out)))
+        return out

@@ -585,3 +585,119 @@ def oracle_window(dyn, lvl1, phis, tcorh, qcorh, nsteps, delt=900.0, alph=0.5, r
     for _ in range(nsteps):
         cur = dyn.step_dry(2, 2, 2 * delt, alph, rob, wil, cur, *bc)
     return cur
+
+
+# ---------------------------------------------------------------- SPEEDY column physics: the compiled reference (libref_phy.so)
+NGP = IX * IL
+
+
+class RefPhys:
+    """The reference's own parametrisation routines (oracle/_ref/libref_phy.so: phy_convmf, phy_lscond, phy_shtorh, phy_radiat,
+    phy_suflux, phy_vdifsc, ini_inphys compiled in place) and, in `phypar`, the call sequence of the grid-point part of
+    src/phy_phypar.f90:80-230 issued through them.  Arrays are (ngp, nlev) Fortran-ordered like the reference's."""
+
+    PATH = os.path.join(ORACLE_DIR, "_ref", "libref_phy.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    def __init__(self, hsg, rlat):
+        L = self.lib = C.CDLL(self.PATH)
+        L.refp_sol_oz.argtypes = [C.c_double]
+        L.refp_shtorh.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp]
+        L.refp_radlw.argtypes = [C.c_int] + [_dp] * 7
+        L.refp_init(_p(np.ascontiguousarray(hsg, dtype=np.float64)), _p(np.ascontiguousarray(rlat, dtype=np.float64)))
+        self.tt_rsw = np.zeros((NGP, KX), order="F")
+        self.ssrd = np.zeros(NGP)
+        self.fields()
+
+    def fields(self):
+        names = ("fsol", "ozone", "ozupp", "zenit", "stratz", "forog")
+        arrs = [np.zeros(NGP) for _ in names]
+        fband = np.zeros((301, 4), order="F")
+        sig, dsig, sigh, grdsig, grdscp = np.zeros(KX), np.zeros(KX), np.zeros(KX + 1), np.zeros(KX), np.zeros(KX)
+        wvi = np.zeros((KX, 2), order="F")
+        self.lib.refp_get_fields(*[_p(a) for a in arrs], _p(fband), _p(sig), _p(dsig), _p(sigh), _p(grdsig), _p(grdscp), _p(wvi))
+        self.sig, self.dsig, self.sigh, self.grdsig, self.grdscp, self.wvi, self.fband = sig, dsig, sigh, grdsig, grdscp, wvi, fband
+        return dict(zip(names, arrs))
+
+    def set_surface(self, phis0, alb_l, alb_s, albsfc, snowc):
+        self.lib.refp_set_surface(*[_p(np.ascontiguousarray(a, dtype=np.float64).ravel()) for a in (phis0, alb_l, alb_s, albsfc, snowc)])
+
+    def sol_oz(self, tyear):
+        self.lib.refp_sol_oz(tyear)
+
+    def radstate(self):
+        tau2, stratc, qcloud = np.zeros((NGP, KX, 4), order="F"), np.zeros((NGP, 2), order="F"), np.zeros(NGP)
+        self.lib.refp_get_radstate(_p(tau2), _p(stratc), _p(qcloud))
+        return tau2, stratc, qcloud
+
+    def phypar(self, ug, vg, tg, qg, phig, pslg, fmask, phis0, tland, tsea, swav, lradsw, utend, vtend, ttend, qtend):
+        """Returns (utend, vtend, ttend, qtend, diag) after phypar's sections 1.2-4.2; inputs (ngp, nlev) / (ngp,)"""
+        L = self.lib
+        F = lambda a: np.asfortranarray(a, dtype=np.float64).copy(order="F")
+        ug, vg, tg, qg, phig = F(ug), F(vg), F(tg), F(qg), F(phig)
+        fmask, phis0, tland, tsea, swav = (np.ascontiguousarray(a, dtype=np.float64).ravel().copy() for a in (fmask, phis0, tland, tsea, swav))
+        z2 = lambda: np.zeros((NGP, KX), order="F")
+        psg = np.exp(np.asarray(pslg, dtype=np.float64).ravel())
+        rps = 1.0 / psg
+        qg = np.maximum(qg, 0.0)
+        se = F(1004.0 * tg + phig)
+        rh, qsat = z2(), z2()
+        for k in range(KX):
+            q, r, s = qg[:, k].copy(), np.zeros(NGP), np.zeros(NGP)
+            L.refp_shtorh(1, _p(tg[:, k].copy()), _p(psg), float(self.sig[k]), _p(q), _p(r), _p(s))
+            rh[:, k], qsat[:, k] = r, s
+        iptop = np.zeros(NGP, dtype=np.int32)
+        cbmf, precnv, tt_cnv, qt_cnv = np.zeros(NGP), np.zeros(NGP), z2(), z2()
+        L.refp_convmf(_p(psg), _p(se), _p(qg), _p(qsat), _pi(iptop), _p(cbmf), _p(precnv), _p(tt_cnv), _p(qt_cnv))
+        for k in range(1, KX):
+            tt_cnv[:, k] = tt_cnv[:, k] * rps * self.grdscp[k]
+            qt_cnv[:, k] = qt_cnv[:, k] * rps * self.grdsig[k]
+        icnv = (KX - iptop).astype(np.int32)
+        precls, tt_lsc, qt_lsc = np.zeros(NGP), z2(), z2()
+        L.refp_lscond(_p(psg), _p(qg), _p(qsat), _pi(iptop), _p(precls), _p(tt_lsc), _p(qt_lsc))
+        ttend = F(ttend) + tt_cnv + tt_lsc
+        qtend = F(qtend) + qt_cnv + qt_lsc
+        diag = {}
+        if lradsw:
+            gse = (se[:, KX - 2] - se[:, KX - 1]) / (phig[:, KX - 2] - phig[:, KX - 1])
+            icltop = np.zeros(NGP, dtype=np.int32)
+            cloudc, clstr = np.zeros(NGP), np.zeros(NGP)
+            L.refp_cloud(_p(qg), _p(rh), _p(precnv), _p(precls), _pi(iptop), _p(gse), _p(fmask), _pi(icltop), _p(cloudc), _p(clstr))
+            ssrd, ssr, tsr, tt_rsw = np.zeros(NGP), np.zeros(NGP), np.zeros(NGP), z2()
+            L.refp_radsw(_p(psg), _p(qg), _pi(icltop), _p(cloudc), _p(clstr), _p(ssrd), _p(ssr), _p(tsr), _p(tt_rsw))
+            for k in range(KX):
+                tt_rsw[:, k] = tt_rsw[:, k] * rps * self.grdscp[k]
+            self.tt_rsw, self.ssrd = tt_rsw, ssrd
+            diag.update(cloudc=cloudc, clstr=clstr, tsr=tsr, ssr=ssr, icltop=icltop.astype(float))
+        ts = np.zeros(NGP)
+        slrd, slru3, slr, olr, tt_rlw = np.zeros(NGP), np.zeros(NGP), np.zeros(NGP), np.zeros(NGP), z2()
+        L.refp_radlw(-1, _p(tg), _p(ts), _p(slrd), _p(slru3), _p(slr), _p(olr), _p(tt_rlw))
+        z3 = lambda: np.zeros((NGP, 3), order="F")
+        ustr, vstr, shf, evap, slru = z3(), z3(), z3(), z3(), z3()
+        hfluxn = np.zeros((NGP, 2), order="F")
+        tskin, u0, v0, t0, q0 = (np.zeros(NGP) for _ in range(5))
+        psg_io = psg.copy()
+        L.refp_suflux(_p(psg_io), _p(ug), _p(vg), _p(tg), _p(qg), _p(rh), _p(phig), _p(phis0), _p(fmask), _p(tland), _p(tsea), _p(swav),
+                      _p(self.ssrd), _p(slrd), _p(ustr), _p(vstr), _p(shf), _p(evap), _p(slru), _p(hfluxn), _p(ts), _p(tskin), _p(u0), _p(v0),
+                      _p(t0), _p(q0), 1)
+        slru3 = slru[:, 2].copy()
+        L.refp_radlw(1, _p(tg), _p(ts), _p(slrd), _p(slru3), _p(slr), _p(olr), _p(tt_rlw))
+        for k in range(KX):
+            tt_rlw[:, k] = tt_rlw[:, k] * rps * self.grdscp[k]
+        ttend = ttend + self.tt_rsw + tt_rlw
+        ut, vt, tt, qt = z2(), z2(), z2(), z2()
+        L.refp_vdifsc(_p(ug), _p(vg), _p(se), _p(rh), _p(qg), _p(qsat), _p(phig), _pi(icnv), _p(ut), _p(vt), _p(tt), _p(qt))
+        n = KX - 1
+        ut[:, n] = ut[:, n] + ustr[:, 2] * rps * self.grdsig[n]
+        vt[:, n] = vt[:, n] + vstr[:, 2] * rps * self.grdsig[n]
+        tt[:, n] = tt[:, n] + shf[:, 2] * rps * self.grdscp[n]
+        qt[:, n] = qt[:, n] + evap[:, 2] * rps * self.grdsig[n]
+        utend, vtend = F(utend) + ut, F(vtend) + vt
+        ttend, qtend = ttend + tt, qtend + qt
+        diag.update(precnv=precnv, precls=precls, cbmf=cbmf, ts=ts, tskin=tskin, ssrd=self.ssrd.copy(), slrd=slrd, olr=olr, shf=shf[:, 2].copy(),
+                    evap=evap[:, 2].copy(), ustr=ustr[:, 2].copy(), vstr=vstr[:, 2].copy(), slr=slr, hfluxn_land=hfluxn[:, 0].copy(),
+                    hfluxn_sea=hfluxn[:, 1].copy(), t0=t0, q0=q0, iptop=iptop.astype(float))
+        return utend, vtend, ttend, qtend, diag
