@@ -33,6 +33,7 @@ def parse():
                     help="sweep = reservoir predict sweep only (development aid; the driver uses the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true", help="BASELINE config 5: add the 1152-region slab-ocean reservoirs and their coupling")
+    ap.add_argument("--no-physics", action="store_true", help="adiabatic SPEEDY window (development aid: isolates the cost of the column physics)")
     ap.add_argument("--regions", type=int, default=1152, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -98,11 +99,37 @@ def cpu_baseline(model, budget_s=12.0):
         per_tr, per_tr_oracle = per_pair / 2.0, per_pair_oracle / 2.0
         per_step = max(per_step_oracle - 123 * per_tr_oracle, 0.0) + 123 * per_tr
         nst = 0 if model.leapfrog_steps is None else model.leapfrog_steps + 2
+        phys_note = ""
+        if getattr(model, "phys", None) is not None:
+            # the column physics: the reference's own phy_*.f90 (oracle/_ref/libref_phy.so) through the phypar call sequence, a
+            # short-wave step and a step without; + 41 more inverse transforms per step
+            from _oracle import RefPhys
+            per_step += 41 * per_tr
+            if RefPhys.available():
+                sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+                from make_physics_golden import HSG, TYEAR, gaussian_latitudes, physics_inputs
+                inp = physics_inputs()
+                ref = RefPhys(HSG, gaussian_latitudes())
+                ref.set_surface(inp["phis0"], inp["alb_l"], inp["alb_s"], inp["albsfc"], inp["snowc"])
+                ref.sol_oz(TYEAR)
+                a = [inp[k] for k in ("ug", "vg", "tg", "qg", "phig", "pslg", "fmask", "phis0", "tland", "tsea", "swav")]
+                tt = {}
+                for sw in (True, False):
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        ref.phypar(*a, sw, inp["utend"], inp["vtend"], inp["ttend"], inp["qtend"])
+                    tt[sw] = (time.perf_counter() - t1) / 3
+                nsw = 2 + len([i for i in range(nst - 2) if (i + 1) % 3 == 1])
+                total += tt[True] * nsw + tt[False] * (nst - nsw)
+                phys_note = (f"; column physics with the compiled reference parametrisations (oracle/_ref, called through the phypar "
+                             f"sequence): {tt[True] * 1e3:.1f} ms per short-wave step (x{nsw}), {tt[False] * 1e3:.1f} ms otherwise (x{nst - nsw})")
+            else:
+                phys_note = "; column physics NOT priced (oracle/_ref/libref_phy.so absent): the baseline is flattered"
         total += per_tr * 99 + per_step * nst
         sample += (f"; SPEEDY leg: {m} grid+spec pairs with the {which}: {per_pair * 1e6:.0f} us per pair (incl. ctypes overhead); "
                    f"{ns} adiabatic time steps with the oracle: {per_step_oracle * 1e3:.2f} ms each, of which its 123 direct-DFT "
                    f"transforms are re-priced at the reference's transform cost -> {per_step * 1e3:.2f} ms per step, x{nst} steps "
-                   f"+ 99 hand-off transforms per hybrid step; exchange tilers not timed (small)")
+                   f"+ 99 hand-off transforms per hybrid step; exchange tilers not timed (small)" + phys_note)
     return {"value": 1.0 / total, "unit": "steps/s", "cores": 1, "kind": "port", "sample": sample}
 
 
@@ -143,7 +170,7 @@ def main():
     # "Software pipeline"): measured +6 % only, because the latency-bound SPEEDY kernels slow down 2x next to an
     # HBM-saturating stream; the default is the reference's sequential order.
     model = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode=args.mode,
-                              pipeline=os.environ.get("SML_PIPELINE", "0") == "1", slab=args.slab)
+                              pipeline=os.environ.get("SML_PIPELINE", "0") == "1", slab=args.slab, physics=not args.no_physics)
     if rank == 0:
         print(f"[bench] rank0 loaded {len(regions)} reservoirs in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
 

@@ -281,6 +281,11 @@ int sml_spectral_spec_mixed(sml_spectral *sp, const double *vorg_dev, double *vo
  * (type, src0, src1, kcos) per output field, src = field index into spec_base_dev ([.][32][62]):
  *   type 0: field src0;  1 | 2: ucos | vcos of uvspec(vor = src0, div = src1);  3 | 4: d/dx | d/dy of grad(src0). */
 int sml_spectral_grid_derived(sml_spectral *sp, const double *spec_base_dev, const int32_t *desc_dev, double *vorg_dev, int nf, void *stream);
+/* ... plus type 7: the geopotential of level src1 (0-based) from the 8 temperature levels that start at field src0,
+ * src/dyn_geop.f90:19-35, for phypar's grid(phi1) (src/phy_phypar.f90:61-65) without a separate geop pass.
+ * aux_dev: xgeop1(8) | xgeop2(8) | corf(8) | phis(62x32) on the device (needed only when a type-7 row is present). */
+int sml_spectral_grid_derived_aux(sml_spectral *sp, const double *spec_base_dev, const int32_t *desc_dev, const double *aux_dev,
+                                  double *vorg_dev, int nf, void *stream);
 /* The forward counterpart: after a (mixed) forward transform, form the output fields in one launch.  desc_dev: int32
  * [nf_out][4] = (type, src0, src1, truncate): type 0 = field src0; 5 | 6 = vor | div of vds(ucos = src0, vcos = src1)
  * (:307-349); truncate != 0 applies trunct (:540-551).  iogrid(30)'s vdspec/spec/trunct (src/ppo_iogrid.f90:530-547) is
@@ -322,6 +327,7 @@ void trunct_(double *vor);
  *     Tendencies: double tend[33][32][62] in the same field order.
  * =================================================================================================== */
 typedef struct sml_dyn sml_dyn;
+typedef struct sml_phys sml_phys;      /* column physics, declared further down */
 /* indyns (src/ini_indyns.f90): level and diffusion tables from the spectral handle's Gaussian latitudes */
 int sml_dyn_create(sml_spectral *sp, sml_dyn **out);
 int sml_dyn_destroy(sml_dyn *dyn);
@@ -352,6 +358,13 @@ int sml_dyn_step(sml_dyn *dyn, double *state_dev, int j1, int j2, double dt, dou
  * impint(2 delt) and nsteps leapfrog steps step(2,2,2 delt) (src/dyn_stloop.f90:28-43) */
 int sml_dyn_window(sml_dyn *dyn, double *state_dev, int start, int nsteps, double delt, double alph, double rob, double wil,
                    void *stream);
+/* Column physics inside grtend (src/dyn_grtend.f90:222-225: geop(j1); phypar(...)): once attached, every time step also
+ * transforms time level 1 to phypar's 41 grids (same launch as grtend's 50) and adds sml_phys_tendencies to the grid-point
+ * tendencies before the forward transforms.  phys == NULL detaches.  nstrad: short-wave radiation every nstrad-th leapfrog
+ * step of a window, lradsw = (mod(istep, nstrad) == 1) (src/dyn_stloop.f90:39); sml_dyn_set_lradsw sets the flag that single
+ * sml_dyn_step / sml_dyn_grtend calls and a window's stepone use (the module variable lradsw, src/mod_lflags.f90:22). */
+int sml_dyn_attach_physics(sml_dyn *dyn, sml_phys *phys, int nstrad);
+int sml_dyn_set_lradsw(sml_dyn *dyn, int lradsw);
 /* how sml_dyn_window runs a time step: 0 = four launches over whole fields (default), 1 = two kernels (zonal-wavenumber
  * space <-> latitude space; bit-identical results, measured slower on MI355X, see csrc/dynamics.hip), -1 = default /
  * environment SML_DYN_TWO_KERNEL */
@@ -364,7 +377,6 @@ int sml_dyn_select_window_form(int form);
  *     mask, orography, land/sea temperatures, soil wetness, albedos, snow cover: the daily output of the reference's coupler
  *     and of fordate) is an input.  Grids are [nf][48][96] as everywhere.
  * =================================================================================================== */
-typedef struct sml_phys sml_phys;
 /* inphys(hsg, ., rlat) + radset: hsg9 = sigma half levels 0..8 (src/ini_indyns.f90:38-41), rlat48 = Gaussian latitudes in
  * radians, south to north (src/ini_indyns.f90:72-80) */
 int sml_phys_create(const double *hsg9, const double *rlat48, sml_phys **out);

@@ -320,9 +320,14 @@ void do_timint(const so_tables *s, int j1, double dt, double eps, double wil, in
         }
 }
 
-/* grtend (src/dyn_grtend.f90) with the physics call (:222-225) omitted.  State level j2: vor,div,t,tr [8][SP], ps [SP]. */
-void do_grtend_dry(const do_tables *d, const so_tables *s, const double *vor, const double *div, const double *t, const double *tr,
-                   const double *ps, double *vordt, double *divdt, double *tdt, double *psdt, double *trdt)
+/* grtend (src/dyn_grtend.f90).  State level j2: vor,div,t,tr [8][SP], ps [SP].  The physics call (:222-225: geop(j1);
+ * phypar(vor(j1),div(j1),t(j1),tr(j1),phi,ps(j1),utend,vtend,ttend,trtend)) is a hook: when phys != NULL the oracle forms
+ * phypar's grid-point inputs from state level 1 exactly as phy_phypar.f90:54-66 does (uvspec + grid(.,2); grid(.,1) of t, q,
+ * phi; grid of ps) and hands them to phys, which adds its tendencies in place -- the tests plug the COMPILED reference
+ * parametrisations (oracle/_ref/libref_phy.so) in there.  phys == NULL is the adiabatic core. */
+void do_grtend(const do_tables *d, const so_tables *s, const double *vor, const double *div, const double *t, const double *tr,
+               const double *ps, const double *vor1, const double *div1, const double *t1, const double *tr1, const double *ps1,
+               const double *phis, do_phys_fn phys, void *ctx, double *vordt, double *divdt, double *tdt, double *psdt, double *trdt)
 {
     static double ug[KX][GR], vg[KX][GR], tg[KX][GR], vorg[KX][GR], divg[KX][GR], tgg[KX][GR], puv[KX][GR], trg[KX][GR];
     static double utend[KX][GR], vtend[KX][GR], ttend[KX][GR], trtend[KX][GR];
@@ -379,7 +384,22 @@ void do_grtend_dry(const do_tables *d, const so_tables *s, const double *vor, co
     for (int k = 1; k <= 2; ++k) for (int p = 0; p < GR; ++p) temp[k][p] = 0.;       /* do k=2,3 (1-based) */
     for (int k = 0; k < KX; ++k)
         for (int p = 0; p < GR; ++p) trtend[k][p] = trg[k][p] * divg[k][p] - (temp[k + 1][p] + temp[k][p]) * d->dhsr[k];
-    /* ---- physics would be added here (call geop(j1); call phypar(...)): omitted ---- */
+    if (phys) {          /* :222-225 */
+        static double phi1[KX * SP], ug1[KX][GR], vg1[KX][GR], tg1[KX][GR], qg1[KX][GR], phig1[KX][GR], pslg1[GR];
+        do_geop(d, t1, phis, phi1);
+        for (int k = 0; k < KX; ++k) {
+            so_uvspec(s, vor1 + k * SP, div1 + k * SP, dumc[0], dumc[1]);
+            so_grid(s, dumc[0], ug1[k], 2);
+            so_grid(s, dumc[1], vg1[k], 2);
+        }
+        for (int k = 0; k < KX; ++k) {
+            so_grid(s, t1 + k * SP, tg1[k], 1);
+            so_grid(s, tr1 + k * SP, qg1[k], 1);
+            so_grid(s, phi1 + k * SP, phig1[k], 1);
+        }
+        so_grid(s, ps1, pslg1, 1);
+        phys(ctx, &ug1[0][0], &vg1[0][0], &tg1[0][0], &qg1[0][0], &phig1[0][0], pslg1, &utend[0][0], &vtend[0][0], &ttend[0][0], &trtend[0][0]);
+    }
     for (int k = 0; k < KX; ++k) {
         so_vdspec(s, utend[k], vtend[k], vordt + k * SP, divdt + k * SP, 2);
         for (int p = 0; p < GR; ++p) {
@@ -400,15 +420,22 @@ void do_grtend_dry(const do_tables *d, const so_tables *s, const double *vor, co
     }
 }
 
-/* step (src/dyn_step.f90:1-128) with the adiabatic grtend.  State arrays hold both time levels: vor,div,t,tr [2][8][SP],
- * ps [2][SP]; phis, tcorh, qcorh [SP]. */
-void do_step_dry(const do_tables *d, const so_tables *s, int j1, int j2, double dt, double alph, double rob, double wil,
-                 double *vor, double *div, double *t, double *tr, double *ps, const double *phis, const double *tcorh, const double *qcorh)
+void do_grtend_dry(const do_tables *d, const so_tables *s, const double *vor, const double *div, const double *t, const double *tr,
+                   const double *ps, double *vordt, double *divdt, double *tdt, double *psdt, double *trdt)
+{
+    do_grtend(d, s, vor, div, t, tr, ps, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, vordt, divdt, tdt, psdt, trdt);
+}
+
+/* step (src/dyn_step.f90:1-128).  State arrays hold both time levels: vor,div,t,tr [2][8][SP], ps [2][SP]; phis, tcorh,
+ * qcorh [SP].  phys: see do_grtend (NULL = adiabatic). */
+void do_step(const do_tables *d, const so_tables *s, int j1, int j2, double dt, double alph, double rob, double wil,
+             double *vor, double *div, double *t, double *tr, double *ps, const double *phis, const double *tcorh, const double *qcorh,
+             do_phys_fn phys, void *ctx)
 {
     static double vordt[KX * SP], divdt[KX * SP], tdt[KX * SP], trdt[KX * SP], psdt[SP], ctmp[KX * SP], phi[KX * SP];
     const size_t L = (size_t)KX * SP;
     const double *vor2 = vor + (j2 - 1) * L, *div2 = div + (j2 - 1) * L, *t2 = t + (j2 - 1) * L, *tr2 = tr + (j2 - 1) * L, *ps2 = ps + (j2 - 1) * SP;
-    do_grtend_dry(d, s, vor2, div2, t2, tr2, ps2, vordt, divdt, tdt, psdt, trdt);
+    do_grtend(d, s, vor2, div2, t2, tr2, ps2, vor, div, t, tr, ps, phis, phys, ctx, vordt, divdt, tdt, psdt, trdt);
     if (alph == 0.) {
         do_sptend(d, s, div2, t2, ps2, phis, divdt, tdt, psdt, phi);
     } else {
@@ -438,4 +465,10 @@ void do_step_dry(const do_tables *d, const so_tables *s, int j1, int j2, double 
     do_timint(s, j1, dt, eps, wil, KX, div, divdt);
     do_timint(s, j1, dt, eps, wil, KX, t, tdt);
     do_timint(s, j1, dt, eps, wil, KX, tr, trdt);
+}
+
+void do_step_dry(const do_tables *d, const so_tables *s, int j1, int j2, double dt, double alph, double rob, double wil,
+                 double *vor, double *div, double *t, double *tr, double *ps, const double *phis, const double *tcorh, const double *qcorh)
+{
+    do_step(d, s, j1, j2, dt, alph, rob, wil, vor, div, t, tr, ps, phis, tcorh, qcorh, NULL, NULL);
 }

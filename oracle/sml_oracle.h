@@ -170,6 +170,15 @@ void do_sptend(const do_tables *d, const so_tables *s, const double *div, const 
 void do_implic(const do_tables *d, double *divdt, double *tdt, double *psdt);                    /* src/dyn_implic.f90 */
 void do_hordif(const do_tables *d, int nlev, const double *field, double *fdt, int which);       /* src/dyn_step.f90:130-150 */
 void do_timint(const so_tables *s, int j1, double dt, double eps, double wil, int nlev, double *field, double *fdt); /* :152-190 */
+/* physics hook of grtend (src/dyn_grtend.f90:222-225): level-1 grids [8][GR] (pslg1 [GR]) in, tendencies [8][GR] updated in place */
+typedef void (*do_phys_fn)(void *ctx, const double *ug1, const double *vg1, const double *tg1, const double *qg1, const double *phig1,
+                           const double *pslg1, double *utend, double *vtend, double *ttend, double *qtend);
+void do_grtend(const do_tables *d, const so_tables *s, const double *vor, const double *div, const double *t, const double *tr,
+               const double *ps, const double *vor1, const double *div1, const double *t1, const double *tr1, const double *ps1,
+               const double *phis, do_phys_fn phys, void *ctx, double *vordt, double *divdt, double *tdt, double *psdt, double *trdt);
+void do_step(const do_tables *d, const so_tables *s, int j1, int j2, double dt, double alph, double rob, double wil,
+             double *vor, double *div, double *t, double *tr, double *ps, const double *phis, const double *tcorh, const double *qcorh,
+             do_phys_fn phys, void *ctx);
 void do_grtend_dry(const do_tables *d, const so_tables *s, const double *vor, const double *div, const double *t, const double *tr,
                    const double *ps, double *vordt, double *divdt, double *tdt, double *psdt, double *trdt); /* src/dyn_grtend.f90 */
 void do_step_dry(const do_tables *d, const so_tables *s, int j1, int j2, double dt, double alph, double rob, double wil,

@@ -59,12 +59,12 @@ EXPORTS = [
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",
-    "sml_spectral_spec", "sml_spectral_grid_mixed", "sml_spectral_grid_derived", "sml_spectral_spec_post", "sml_spectral_spec_mixed", "sml_spectral_vdspec", "sml_spectral_uvspec", "sml_spectral_vds", "sml_spectral_grad",
+    "sml_spectral_spec", "sml_spectral_grid_mixed", "sml_spectral_grid_derived", "sml_spectral_grid_derived_aux", "sml_spectral_spec_post", "sml_spectral_spec_mixed", "sml_spectral_vdspec", "sml_spectral_uvspec", "sml_spectral_vds", "sml_spectral_grad",
     "sml_spectral_lap", "sml_spectral_invlap", "sml_spectral_trunct",
     "parmtr_", "inifft_", "grid_", "spec_", "vdspec_", "uvspec_", "vds_", "grad_", "lap_", "invlap_", "trunct_",
     "sml_dyn_create", "sml_dyn_destroy", "sml_dyn_impint", "sml_dyn_get_table", "sml_dyn_set_boundary", "sml_dyn_state_dev",
     "sml_dyn_set_state_host", "sml_dyn_get_state_host", "sml_dyn_set_boundary_host", "sml_dyn_grtend",
-    "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_select_window_form",
+    "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_attach_physics", "sml_dyn_set_lradsw", "sml_dyn_select_window_form",
     "sml_phys_create", "sml_phys_destroy", "sml_phys_set_surface", "sml_phys_set_sst_dev", "sml_phys_sol_oz", "sml_phys_get_tables",
     "sml_phys_tendencies", "sml_phys_diag",
     "sml_makesparse", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",

@@ -38,6 +38,8 @@ constexpr int NSTATE = 33;         // fields per time level
 constexpr int F_VOR = 0, F_DIV = 8, F_T = 16, F_TR = 24, F_PS = 32;
 constexpr int NB_SPEC = 50;        // inverse batch: the 32 3-D state fields, ucos(8), vcos(8), d(ps)/dx, d(ps)/dy
 constexpr int NB_GRID = 73;        // forward batch, see k_gridtend
+constexpr int NB_PHYS = 41;        // phypar's inverse set of time level 1: u(8) v(8) t(8) q(8) phi(8) ps (phy_phypar.f90:54-66)
+constexpr int NB_ALL = NB_SPEC + NB_PHYS;
 
 // src/mod_dyncon0.f90:9-45, src/mod_dyncon1.f90:12-27 (all reals are promoted to 8 bytes, src/makefile:6,12)
 constexpr double REARTH = 6.371e+6, OMEGA = 7.292e-05, GRAV = 9.81, GAMMA = 6.0, HSCALE = 7.5, HSHUM = 2.5;
@@ -998,7 +1000,11 @@ struct sml_dyn {
     ImpSlot *cur = nullptr;
     double *bc = nullptr;              // phis | tcorh | qcorh  (3 x SP)
     double *own_state = nullptr;       // [2][33][SP] for hosts that keep the state in Fortran arrays (sml_dyn_*_host)
-    double *batch_grid = nullptr;      // [50][GR]
+    double *batch_grid = nullptr;      // [50 + 41][GR]: grtend's inverse set | phypar's inverse set (time level 1)
+    sml_phys *phys = nullptr;          // column physics added to the grid-point tendencies (sml_dyn_attach_physics), not owned
+    int nstrad = 3, lradsw = 1;        // short-wave radiation every nstrad-th step; flag of the next sml_dyn_step (mod_lflags.f90:22)
+    int32_t *desc_phys = nullptr;      // inverse-batch descriptors with physics: [2 (j2)][91][4], fields relative to the whole state
+    double *aux = nullptr;             // xgeop1 | xgeop2 | corf | phis: geopotential operands of the type-7 rows
     double *tend_grid = nullptr;       // [73][GR]
     double *tend_spec = nullptr;       // [73][SP]
     int32_t *desc = nullptr, *scale = nullptr;     // inverse-batch descriptors [50][4], forward-batch scaling flags [73]
@@ -1026,14 +1032,20 @@ int fetch_table(sml_dyn *d, int which, const double **dst, std::vector<double> &
     return dst ? upload(d, dst, tmp.data(), n) : SML_OK;
 }
 
-int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend, double *tend_out, hipStream_t st)
+int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend, double *tend_out, hipStream_t st, int lradsw = 1)
 {
     const double *sj2 = state + (size_t)(a.j2 - 1) * NSTATE * SP;
-    // the 50 inverse transforms of grtend (:61-99) straight from the state: uvspec and grad are formed while the fields are staged
-    int rc = sml_spectral_grid_derived(d->sp, sj2, d->desc, d->batch_grid, NB_SPEC, st);
+    // the 50 inverse transforms of grtend (:61-99) straight from the state: uvspec and grad are formed while the fields are staged.
+    // With physics attached the same launch also produces phypar's 41 grids of time level 1 (phy_phypar.f90:54-66), geop(1) included.
+    int rc = d->phys ? sml_spectral_grid_derived_aux(d->sp, state, d->desc_phys + (size_t)(a.j2 - 1) * NB_ALL * 4, d->aux, d->batch_grid, NB_ALL, st)
+                     : sml_spectral_grid_derived(d->sp, sj2, d->desc, d->batch_grid, NB_SPEC, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gridtend, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid);
     SML_HIP(hipGetLastError());
+    if (d->phys) {      // dyn_grtend.f90:222-225: phypar adds its tendencies to utend, vtend, ttend, trtend before the forward transforms
+        rc = sml_phys_tendencies(d->phys, d->batch_grid + (size_t)NB_SPEC * GR, lradsw, d->tend_grid, 0, 8, 56, 64, 1, st);
+        if (rc) return rc;
+    }
     rc = sml_spectral_spec_mixed(d->sp, d->tend_grid, d->tend_spec, NB_GRID, d->scale, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_spectral<true>, dim3(SP / 8), dim3(64), 0, st, d->d, d->cur->lv, a, d->tend_spec, (const double *)nullptr,
@@ -1124,7 +1136,16 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
     }
     if (!rc) rc = zeros(&d->bc, (size_t)3 * SP);
     if (!rc) rc = zeros(&d->own_state, (size_t)2 * NSTATE * SP);
-    if (!rc) rc = zeros(&d->batch_grid, (size_t)NB_SPEC * GR);
+    if (!rc) rc = zeros(&d->batch_grid, (size_t)NB_ALL * GR);
+    if (!rc) rc = zeros(&d->aux, (size_t)24 + SP);
+    if (!rc) {
+        double lv[24];
+        for (int k = 0; k < KX; ++k) {
+            lv[k] = d->h.xgeop1[k]; lv[8 + k] = d->h.xgeop2[k];
+            lv[16 + k] = (k >= 1 && k <= KX - 2) ? d->h.xgeop1[k] * 0.5 * std::log(d->h.hsg[k + 1] / d->h.fsg[k]) / std::log(d->h.fsg[k + 1] / d->h.fsg[k - 1]) : 0.;
+        }
+        SML_HIP(hipMemcpy(d->aux, lv, sizeof lv, hipMemcpyHostToDevice));
+    }
     if (!rc) rc = zeros(&d->tend_grid, (size_t)NB_GRID * GR);
     if (!rc) rc = zeros(&d->tend_spec, (size_t)NB_GRID * SP);
     if (!rc) {
@@ -1139,6 +1160,25 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
         rc = sml::dev_upload(&d->desc, &kc[0][0], NB_SPEC * 4);
         if (!rc) { d->allocs.push_back(d->desc); rc = sml::dev_upload(&d->scale, sc, NB_GRID); }
         if (!rc) d->allocs.push_back(d->scale);
+        // the same set addressed from the start of the state for j2 = 1 | 2, followed by phypar's set of time level 1:
+        // u v (uvspec, kcos 2) | t q (kcos 1) | phi (type 7) | ps
+        static int32_t kp[2][NB_ALL][4];
+        for (int j2 = 0; j2 < 2; ++j2) {
+            for (int f = 0; f < NB_SPEC; ++f) {
+                kp[j2][f][0] = kc[f][0]; kp[j2][f][1] = kc[f][1] + j2 * NSTATE; kp[j2][f][2] = kc[f][2] + j2 * NSTATE; kp[j2][f][3] = kc[f][3];
+            }
+            for (int f = 0; f < NB_PHYS; ++f) {
+                int32_t *r = kp[j2][NB_SPEC + f];
+                const int k = f & 7;
+                if (f < 16) { r[0] = f < 8 ? 1 : 2; r[1] = F_VOR + k; r[2] = F_DIV + k; r[3] = 2; }
+                else if (f < 24) { r[0] = 0; r[1] = r[2] = F_T + k; r[3] = 1; }
+                else if (f < 32) { r[0] = 0; r[1] = r[2] = F_TR + k; r[3] = 1; }
+                else if (f < 40) { r[0] = 7; r[1] = F_T; r[2] = k; r[3] = 1; }
+                else { r[0] = 0; r[1] = r[2] = F_PS; r[3] = 1; }
+            }
+        }
+        if (!rc) rc = sml::dev_upload(&d->desc_phys, &kp[0][0][0], 2 * NB_ALL * 4);
+        if (!rc) d->allocs.push_back(d->desc_phys);
     }
     if (rc) { sml_dyn_destroy(d); return rc; }
     *out = d;
@@ -1224,6 +1264,7 @@ int sml_dyn_set_boundary(sml_dyn *d, const double *phis_dev, const double *tcorh
     SML_REQUIRE(d && phis_dev && tcorh_dev && qcorh_dev, "sml_dyn_set_boundary: bad arguments");
     hipStream_t st = sml::as_stream(stream);
     SML_HIP(hipMemcpyAsync(d->bc, phis_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
+    SML_HIP(hipMemcpyAsync(d->aux + 24, phis_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
     SML_HIP(hipMemcpyAsync(d->bc + SP, tcorh_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
     SML_HIP(hipMemcpyAsync(d->bc + 2 * SP, qcorh_dev, SP * sizeof(double), hipMemcpyDeviceToDevice, st));
     return SML_OK;
@@ -1279,6 +1320,7 @@ int sml_dyn_set_boundary_host(sml_dyn *d, const double *phis, const double *tcor
 {
     SML_REQUIRE(d && phis && tcorh && qcorh, "sml_dyn_set_boundary_host: bad arguments");
     SML_HIP(hipMemcpy(d->bc, phis, SP * sizeof(double), hipMemcpyHostToDevice));
+    SML_HIP(hipMemcpy(d->aux + 24, phis, SP * sizeof(double), hipMemcpyHostToDevice));
     SML_HIP(hipMemcpy(d->bc + SP, tcorh, SP * sizeof(double), hipMemcpyHostToDevice));
     SML_HIP(hipMemcpy(d->bc + 2 * SP, qcorh, SP * sizeof(double), hipMemcpyHostToDevice));
     return SML_OK;
@@ -1289,7 +1331,7 @@ int sml_dyn_grtend(sml_dyn *d, const double *state_dev, int j2, double *tend_dev
     SML_REQUIRE(d && state_dev && tend_dev && (j2 == 1 || j2 == 2), "sml_dyn_grtend: bad arguments");
     SML_REQUIRE(d->cur, "sml_dyn_grtend: call sml_dyn_impint first (tref enters the grid-point tendencies)");
     StepArgs a = make_args(1, j2, 0., 0., 0., 0.);
-    return run_step(d, const_cast<double *>(state_dev), a, 1, tend_dev, sml::as_stream(stream));
+    return run_step(d, const_cast<double *>(state_dev), a, 1, tend_dev, sml::as_stream(stream), d->lradsw);
 }
 
 int sml_dyn_spectral_step(sml_dyn *d, double *state_dev, double *tend_dev, int j1, int j2, double dt, double alph, double rob, double wil,
@@ -1308,7 +1350,23 @@ int sml_dyn_step(sml_dyn *d, double *state_dev, int j1, int j2, double dt, doubl
 {
     SML_REQUIRE(d && state_dev && (j1 == 1 || j1 == 2) && (j2 == 1 || j2 == 2), "sml_dyn_step: bad arguments");
     SML_REQUIRE(d->cur, "sml_dyn_step: call sml_dyn_impint first");
-    return run_step(d, state_dev, make_args(j1, j2, dt, alph, rob, wil), 0, nullptr, sml::as_stream(stream));
+    return run_step(d, state_dev, make_args(j1, j2, dt, alph, rob, wil), 0, nullptr, sml::as_stream(stream), d->lradsw);
+}
+
+int sml_dyn_attach_physics(sml_dyn *d, sml_phys *phys, int nstrad)
+{
+    SML_REQUIRE(d && nstrad >= 1, "sml_dyn_attach_physics: bad arguments");
+    d->phys = phys;
+    d->nstrad = nstrad;
+    d->lradsw = 1;
+    return SML_OK;
+}
+
+int sml_dyn_set_lradsw(sml_dyn *d, int lradsw)
+{
+    SML_REQUIRE(d, "sml_dyn_set_lradsw: null handle");
+    d->lradsw = lradsw ? 1 : 0;
+    return SML_OK;
 }
 
 int sml_dyn_select_window_form(int form)
@@ -1326,19 +1384,24 @@ int sml_dyn_window(sml_dyn *d, double *state_dev, int start, int nsteps, double 
     const int four_launch = !(g_window_form < 0 ? env_two : g_window_form);
     // the schedule: stepone for istart = 0 or 2 (src/ini_stepone.f90:16-31), then impint(2 delt) (:34) and the leapfrog loop
     // (src/dyn_stloop.f90:28-43)
-    struct Item { double dt_imp; StepArgs a; };
+    struct Item { double dt_imp; StepArgs a; int lradsw; };
     std::vector<Item> sched;
+    // short-wave flag: stepone runs with whatever the module variable holds -- .true. at start-up (mod_lflags.f90:22), the last
+    // leapfrog step's value when a later window restarts -- then mod(istep, nstrad) == 1 with istep = 1, 2, ...
+    // (dyn_stloop.f90:39, at_gcm.f90:81)
     if (start) {
-        sched.push_back({0.5 * delt, make_args(1, 1, 0.5 * delt, alph, rob, wil)});
-        sched.push_back({delt, make_args(1, 2, delt, alph, rob, wil)});
+        sched.push_back({0.5 * delt, make_args(1, 1, 0.5 * delt, alph, rob, wil), d->lradsw});
+        sched.push_back({delt, make_args(1, 2, delt, alph, rob, wil), d->lradsw});
     }
-    for (int i = 0; i < nsteps; ++i) sched.push_back({2 * delt, make_args(2, 2, 2 * delt, alph, rob, wil)});
+    for (int i = 0; i < nsteps; ++i) sched.push_back({2 * delt, make_args(2, 2, 2 * delt, alph, rob, wil), (i + 1) % d->nstrad == 1});
     int rc = SML_OK;
+    SML_REQUIRE(four_launch || !d->phys, "sml_dyn_window: the two-kernel form has no physics hook; select form 0");
     if (four_launch) {
         for (size_t i = 0; i < sched.size() && !rc; ++i) {
             rc = sml_dyn_impint(d, sched[i].dt_imp, alph);
-            if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st);
+            if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st, sched[i].lradsw);
         }
+        if (nsteps > 0) d->lradsw = sched.back().lradsw;
         if (!rc) rc = sml_dyn_impint(d, 2 * delt, alph);
         return rc;
     }

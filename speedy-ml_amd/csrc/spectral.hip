@@ -167,9 +167,21 @@ __device__ __forceinline__ double irot(const double *a, int base, int c, double 
 // One spectral coefficient of a DERIVED field, so that uvspec / grad need not be materialised before their inverse
 // transform (sml_spectral_grid_derived).  type 1 | 2: ucos | vcos of (vor = P, div = Q), uvspec :351-387;
 // type 3 | 4: d/dx | d/dy of P, grad :271-305.  Same expressions, in the same order, as k_uvvds / k_grad below.
-__device__ __forceinline__ double derived_coeff(const DevTables &T, int type, const double *__restrict__ P, const double *__restrict__ Q, int n, int c)
+// type 7: geopotential of level `lev` from the 8 temperature levels that start at field P and the surface geopotential,
+// dyn_geop.f90:19-35 (hydrostatic chain from the bottom layer up, then the m = 0 lapse-rate correction);
+// aux = xgeop1(8) | xgeop2(8) | corf(8) | phis(62x32).
+__device__ __forceinline__ double derived_coeff(const DevTables &T, int type, const double *__restrict__ P, const double *__restrict__ Q, int n, int c,
+                                                int lev = 0, const double *__restrict__ aux = nullptr)
 {
     const int m = c >> 1, row = n * MX2;
+    if (type == 7) {
+        constexpr int KX = 8;
+        const int e = row + c;
+        double phi = aux[24 + e] + aux[KX - 1] * P[(size_t)(KX - 1) * SPEC_N + e];
+        for (int k = KX - 2; k >= lev; --k) phi = phi + aux[8 + k + 1] * P[(size_t)(k + 1) * SPEC_N + e] + aux[k] * P[(size_t)k * SPEC_N + e];
+        if (m == 0 && lev >= 1 && lev <= KX - 2) phi = phi + aux[16 + lev] * (P[(size_t)(lev + 1) * SPEC_N + e] - P[(size_t)(lev - 1) * SPEC_N + e]);
+        return phi;
+    }
     if (type <= 2) {
         const double gx = T.uvdx[n * MX + m];
         const double *ym = T.uvdym, *yp = T.uvdyp;
@@ -191,9 +203,10 @@ __device__ __forceinline__ double derived_coeff(const DevTables &T, int type, co
 constexpr int TG = 512;     // phase ablation: staging+launch floor 6.7 us, Legendre 2.6 us, Fourier 6.5 us at 256 threads (two
                             // rounds of the 392 Fourier items); 512 threads do them in one round
 // desc (optional): int32 [nf][4] = (type, src0, src1, kcos) per output field; type 0 = field src0 of vorm as it is,
-// 1..4 = derived_coeff of fields src0 (P) and src1 (Q)
+// 1..4 = derived_coeff of fields src0 (P) and src1 (Q); 7 = geopotential of level src1 from the temperature levels at src0 (needs aux)
 __global__ __launch_bounds__(TG) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos_all,
-                                              const int *__restrict__ kcos_of_field, const int *__restrict__ desc)
+                                              const int *__restrict__ kcos_of_field, const int *__restrict__ desc,
+                                              const double *__restrict__ aux)
 {
     __shared__ double sv[SPEC_N];              // spectral coefficients
     __shared__ double sp[LATG][NX][MX];        // this workgroup's slab of the Legendre table (31 KB), staged with sv
@@ -208,6 +221,8 @@ __global__ __launch_bounds__(TG) void k_grid(DevTables T, const double *__restri
     // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
     if (type == 0) {
         for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = v[i];
+    } else if (type == 7) {
+        for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, 7, v, v, i / MX2, i % MX2, src1, aux);
     } else {
         const double *q = vorm + (size_t)src1 * SPEC_N;
         for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, type, v, q, i / MX2, i % MX2);
@@ -544,7 +559,8 @@ int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf
 {
     SML_REQUIRE(sp && nf >= 0 && (kcos == 1 || kcos == 2) && (nf == 0 || (vorm && vorg)), "sml_spectral_grid: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr, (const int *)nullptr);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr, (const int *)nullptr,
+                       (const double *)nullptr);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
@@ -560,19 +576,26 @@ int sml_spectral_grid_mixed(sml_spectral *sp, const double *vorm, double *vorg, 
 {
     SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg && kcos_dev)), "sml_spectral_grid_mixed: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev, (const int *)nullptr);
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev, (const int *)nullptr,
+                       (const double *)nullptr);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_grid_derived_aux(sml_spectral *sp, const double *spec_base, const int32_t *desc_dev, const double *aux_dev, double *vorg, int nf,
+                                  void *stream)
+{
+    SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (spec_base && desc_dev && vorg)), "sml_spectral_grid_derived: bad arguments");
+    if (!nf) return SML_OK;
+    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, spec_base, vorg, 1, (const int *)nullptr,
+                       (const int *)desc_dev, aux_dev);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
 
 int sml_spectral_grid_derived(sml_spectral *sp, const double *spec_base, const int32_t *desc_dev, double *vorg, int nf, void *stream)
 {
-    SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (spec_base && desc_dev && vorg)), "sml_spectral_grid_derived: bad arguments");
-    if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, spec_base, vorg, 1, (const int *)nullptr,
-                       (const int *)desc_dev);
-    SML_HIP(hipGetLastError());
-    return SML_OK;
+    return sml_spectral_grid_derived_aux(sp, spec_base, desc_dev, nullptr, vorg, nf, stream);
 }
 
 int sml_spectral_spec_mixed(sml_spectral *sp, const double *vorg, double *vorm, int nf, const int32_t *scale_dev, void *stream)

@@ -59,6 +59,17 @@ class Dynamics:
     def set_boundary(self, phis, tcorh, qcorh, stream=None):
         check(_lib.lib().sml_dyn_set_boundary(self._h, _chk(phis, (NX, MX2)), _chk(tcorh, (NX, MX2)), _chk(qcorh, (NX, MX2)), vp(stream)))
 
+    def attach_physics(self, physics, nstrad=3):
+        """grtend's physics call (src/dyn_grtend.f90:222-225): every later time step adds the column-physics tendencies of time
+        level 1 to the grid-point tendencies.  nstrad: short-wave radiation every nstrad-th step (src/dyn_stloop.f90:39).
+        None detaches."""
+        self._physics = physics          # keeps the handle alive
+        check(_lib.lib().sml_dyn_attach_physics(self._h, physics._h if physics is not None else None, int(nstrad)))
+
+    def set_lradsw(self, flag):
+        """the module flag lradsw (src/mod_lflags.f90:22) seen by step()/grtend() and by the stepone part of the next window"""
+        check(_lib.lib().sml_dyn_set_lradsw(self._h, 1 if flag else 0))
+
     def grtend(self, state, j2, out=None, stream=None):
         import torch
         out = torch.empty((NSTATE, NX, MX2), dtype=torch.float64, device=state.device) if out is None else out

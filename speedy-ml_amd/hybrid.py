@@ -120,7 +120,7 @@ class HybridRank:
 
     def __init__(self, regions, classes, world=1, rank=0, sea_mask=None, mode="hybrid", seed=20240000, n_override=None,
                  leapfrog_steps=LEAPFROG_PER_WINDOW, physical=True, pipeline=False, persistent_readout=True, drain_readout=True,
-                 start_hours=12000 + 24 * 14, slab=False):
+                 start_hours=12000 + 24 * 14, slab=False, physics=True):
         import torch
         self.torch = torch
         self.regions, self.classes, self.world, self.rank, self.mode = list(regions), classes, world, rank, mode
@@ -185,6 +185,9 @@ class HybridRank:
             self.sp.trunct(bc)
             self.phis, self.tcorh, self.qcorh = bc[0].contiguous(), bc[1].contiguous(), torch.zeros((NX, MX2), dtype=f64, device=dev)
             self.dyn.set_boundary(self.phis, self.tcorh, self.qcorh)
+            self.phys = None
+            if physics:
+                self.init_physics(sea_mask, g4)
             self.even_split = (NREG % world == 0)
             self.slab = None
             if slab:
@@ -205,6 +208,36 @@ class HybridRank:
             self.feedback.copy_(torch.from_numpy(rng.standard_normal((cap, self.bank.max_d))))
             self.local_model.copy_(torch.from_numpy(rng.standard_normal((cap, self.bank.max_n_model))))
         torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ SPEEDY column physics inside every time step
+    def init_physics(self, sea_mask, g4):
+        """phypar in grtend (src/dyn_grtend.f90:222-225) with synthetic surface boundary fields: land fraction from the land-sea
+        mask, the orography of the dynamics, a land temperature from the lowest model level of the start state, mid-range soil
+        wetness, snow-free albedos.  The sea temperature is the hybrid state's SST grid, refreshed every step (sst_am)."""
+        from .physics import NSTRAD, Physics
+        from .synth import land_mask
+        sea = (land_mask() if sea_mask is None else np.asarray(sea_mask)).reshape(IL, IX).astype(np.float64)
+        fmask = 1.0 - sea
+        phis0 = np.maximum(0.0, synthetic_orography())
+        tland = np.ascontiguousarray(g4[7, :, :, 0])
+        sia = np.asarray(self.sp.table(1)).ravel()                       # sines of the 24 northern Gauss latitudes
+        self.phys = Physics(np.concatenate([-np.arcsin(sia), np.arcsin(sia)[::-1]]))     # radang, src/ini_indyns.f90:72-80
+        alb_l, alb_s = np.full((IL, IX), 0.2), np.full((IL, IX), 0.07)
+        self.surface = dict(fmask=fmask, phis0=phis0, tland=tland, tsea=self.base_sst.cpu().numpy().reshape(IL, IX), swav=np.full((IL, IX), 0.5),
+                            alb_l=alb_l, alb_s=alb_s, albsfc=alb_s + fmask * (alb_l - alb_s), snowc=np.zeros((IL, IX)))
+        self.phys.set_surface(*[self.surface[k] for k in ("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc")])
+        self.phys_day = None
+        self.update_forcing()
+        self.dyn.attach_physics(self.phys, NSTRAD)
+
+    def update_forcing(self):
+        """fordate's daily call of sol_oz(tyear), tyear = (day of the 365-day year - 0.5) / 365 (src/ini_fordate.f90:47-50 with
+        src/mod_date.f90's tyear)"""
+        _, month, iday, _ = domain.calendar_date(self.start_hours + self.t * self.timestep_hours)
+        day = (0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334)[month - 1] + iday       # ndaycal(imonth, 2) + iday
+        if day != self.phys_day:
+            self.phys_day = day
+            self.phys.sol_oz((day - 0.5) / 365.0)
 
     # ------------------------------------------------------------------ slab ocean (BASELINE config 5)
     def init_slab(self, classes, sea_mask, seed, n_override, physical):
@@ -308,6 +341,9 @@ class HybridRank:
 
     def speedy_leg(self, stream):
         self.handoff_in(stream)
+        if self.phys is not None:
+            self.update_forcing()
+            self.phys.set_sst(self.G[domain.GS_OFF:domain.GT_OFF], stream=stream)
         if self.leapfrog_steps is not None:
             # agcm_init -> stepone, then stloop's first 6-hour window (src/dyn_stloop.f90:24-95 with onehr_hybrid)
             self.dyn.window(self.state, self.leapfrog_steps, start=True, delt=DELT, stream=stream)
@@ -384,13 +420,15 @@ class HybridRank:
         else:
             nst = 0 if self.leapfrog_steps is None else self.leapfrog_steps + 2
             wl = ("BASELINE config 3: 1152-reservoir batched predict + region exchange (scatter, clamps, gather, standardise) "
-                  "+ SPEEDY hand-off iogrid(30)/(31) + one 6-hour SPEEDY window of %d adiabatic time steps (stepone + leapfrog: "
-                  "50 inverse + 73 forward transforms, grid-point tendencies, semi-implicit spectral step each) on the device; "
-                  "column physics excluded (SURVEY section 8: out of scope)" % nst)
+                  "+ SPEEDY hand-off iogrid(30)/(31) + one 6-hour SPEEDY window of %d time steps (stepone + leapfrog: "
+                  "%d inverse + 73 forward transforms, grid-point tendencies, %ssemi-implicit spectral step each) on the device"
+                  % (nst, 91 if self.phys is not None else 50,
+                     "column physics (convection, condensation, clouds, SW every 3rd step, LW, surface fluxes, vertical diffusion), "
+                     if self.phys is not None else "no column physics, "))
         if self.mode == "hybrid" and self.slab is not None:
             wl += ("; + slab-ocean coupling (config 5): SST assembly from the slab reservoirs, 27-step input averaging ring, "
                    "predict_slab_ml of the SST-predicting regions every 28th step")
         return {"workload": wl, "regions_total": NREG, "regions_this_rank": len(self.regions),
-                "transforms_per_step": (99 + 123 * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
+                "transforms_per_step": (99 + (164 if self.phys is not None else 123) * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
                 "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s); "
                                + ("one all-gather of the outvec slab per step" if self.world > 1 else "no collective")}

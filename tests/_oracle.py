@@ -411,6 +411,7 @@ class DynOracle:
         L.do_timint.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
         L.do_grtend_dry.argtypes = [C.c_void_p, C.c_void_p] + [_dp] * 10
         L.do_step_dry.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 4 + [_dp] * 8
+        L.do_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 4 + [_dp] * 8 + [C.c_void_p, C.c_void_p]
         self.d = C.c_void_p(L.do_tables_new())
         L.do_indyns(self.d, self.o.t)
 
@@ -466,6 +467,32 @@ class DynOracle:
         a = [_flat(state[k]) for k in keys]
         c = [_flat(x) for x in (phis, tcorh, qcorh)]
         self.lib.do_step_dry(self.d, self.o.t, j1, j2, dt, alph, rob, wil, *[_p(x) for x in a], *[_p(x) for x in c])
+        return {k: x.reshape(np.shape(state[k]), order="F") for k, x in zip(keys, a)}
+
+
+    PHYS_FN = C.CFUNCTYPE(None, C.c_void_p, *([C.POINTER(C.c_double)] * 10))
+
+    def step(self, j1, j2, dt, alph, rob, wil, state, phis, tcorh, qcorh, phys=None):
+        """step() with the physics hook of grtend (src/dyn_grtend.f90:222-225).  phys(ug1, vg1, tg1, qg1, phig1, pslg1, utend,
+        vtend, ttend, qtend) gets (ngp, nlev) Fortran-ordered arrays ((ngp,) for pslg1) of time level 1 and returns the four
+        updated tendencies; None = adiabatic."""
+        if phys is None:
+            return self.step_dry(j1, j2, dt, alph, rob, wil, state, phis, tcorh, qcorh)
+        ngp = 96 * 48
+
+        def hook(ctx, *ptrs):
+            arr = [np.ctypeslib.as_array(q, shape=(ngp if i == 5 else 8 * ngp,)) for i, q in enumerate(ptrs)]
+            ins = [a.copy() if i == 5 else a.reshape((ngp, 8), order="F").copy(order="F") for i, a in enumerate(arr[:6])]
+            tends = [a.reshape((ngp, 8), order="F") for a in arr[6:]]
+            new = phys(*ins, *[t.copy(order="F") for t in tends])
+            for t, n in zip(tends, new):
+                t[...] = n
+
+        keys = ("vor", "div", "t", "tr", "ps")
+        a = [_flat(state[k]) for k in keys]
+        c = [_flat(x) for x in (phis, tcorh, qcorh)]
+        cb = self.PHYS_FN(hook)
+        self.lib.do_step(self.d, self.o.t, j1, j2, dt, alph, rob, wil, *[_p(x) for x in a], *[_p(x) for x in c], C.cast(cb, C.c_void_p), None)
         return {k: x.reshape(np.shape(state[k]), order="F") for k, x in zip(keys, a)}
 
 
@@ -571,19 +598,23 @@ def oracle_iogrid31(o, lvl):
     return F4, F2
 
 
-def oracle_window(dyn, lvl1, phis, tcorh, qcorh, nsteps, delt=900.0, alph=0.5, rob=0.05, wil=0.53):
+def oracle_window(dyn, lvl1, phis, tcorh, qcorh, nsteps, delt=900.0, alph=0.5, rob=0.05, wil=0.53, phys=None, nstrad=3):
     """stepone (istart = 2) + nsteps leapfrog steps (src/ini_stepone.f90, src/dyn_stloop.f90:28-43) from a level-1 state
-    (level 2 is whatever is passed: stepone's forward step overwrites it).  Returns the two-level state dict."""
+    (level 2 is whatever is passed: stepone's forward step overwrites it).  Returns the two-level state dict.
+    phys: a PhysHook for grtend's physics slot (its .lradsw is the module flag: kept through stepone, then
+    mod(istep, nstrad) == 1, src/dyn_stloop.f90:39); None = adiabatic."""
     two = lambda a: np.stack([a, a], axis=-1)
     cur = {k: two(lvl1[k]) for k in ("vor", "div", "t", "tr", "ps")}
     bc = (phis, tcorh, qcorh)
     dyn.impint(0.5 * delt, alph)
-    cur = dyn.step_dry(1, 1, 0.5 * delt, alph, rob, wil, cur, *bc)
+    cur = dyn.step(1, 1, 0.5 * delt, alph, rob, wil, cur, *bc, phys=phys)
     dyn.impint(delt, alph)
-    cur = dyn.step_dry(1, 2, delt, alph, rob, wil, cur, *bc)
+    cur = dyn.step(1, 2, delt, alph, rob, wil, cur, *bc, phys=phys)
     dyn.impint(2 * delt, alph)
-    for _ in range(nsteps):
-        cur = dyn.step_dry(2, 2, 2 * delt, alph, rob, wil, cur, *bc)
+    for i in range(nsteps):
+        if phys is not None:
+            phys.lradsw = (i + 1) % nstrad == 1
+        cur = dyn.step(2, 2, 2 * delt, alph, rob, wil, cur, *bc, phys=phys)
     return cur
 
 
@@ -701,3 +732,19 @@ class RefPhys:
                     evap=evap[:, 2].copy(), ustr=ustr[:, 2].copy(), vstr=vstr[:, 2].copy(), slr=slr, hfluxn_land=hfluxn[:, 0].copy(),
                     hfluxn_sea=hfluxn[:, 1].copy(), t0=t0, q0=q0, iptop=iptop.astype(float))
         return utend, vtend, ttend, qtend, diag
+
+
+class PhysHook:
+    """grtend's physics slot (src/dyn_grtend.f90:222-225) filled with the compiled reference parametrisations: callable as
+    DynOracle.step's `phys`.  surf: dict of (4608,) / (48,96) arrays fmask, phis0, tland, tsea, swav, alb_l, alb_s, albsfc, snowc."""
+
+    def __init__(self, ref, surf, tyear, lradsw=True):
+        self.ref, self.lradsw = ref, lradsw
+        self.s = {k: np.asarray(v, dtype=np.float64).ravel() for k, v in surf.items()}
+        ref.set_surface(self.s["phis0"], self.s["alb_l"], self.s["alb_s"], self.s["albsfc"], self.s["snowc"])
+        ref.sol_oz(tyear)
+
+    def __call__(self, ug, vg, tg, qg, phig, pslg, ut, vt, tt, qt):
+        s = self.s
+        return self.ref.phypar(ug, vg, tg, qg, phig, pslg, s["fmask"], s["phis0"], s["tland"], s["tsea"], s["swav"], self.lradsw,
+                               ut, vt, tt, qt)[:4]

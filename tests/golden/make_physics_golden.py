@@ -85,6 +85,49 @@ def run_reference(inp, ref):
     return out
 
 
+WINDOW_STEPS = 4          # leapfrog steps after stepone in the coupled fixture: short-wave flags 1 1 | 1 0 0 1
+WINDOW_KEEP = slice(None, None, 4)
+
+
+def coupled_inputs(seed=5):
+    """Spectral start state (both time levels equal, as the hybrid hand-off leaves it), boundary fields and surface fields of the
+    dynamics + physics window fixture.  Returns (state dict of (62,32,8,2)/(62,32,2), phis (62,32), surface dict)."""
+    from __graft_entry__ import load_package
+    load_package()
+    from speedy_ml_amd import synth
+    from _oracle import Oracle, oracle_iogrid30
+    o = Oracle()
+    g4, logp, _, _ = synth.synthetic_state(seed)
+    lvl = oracle_iogrid30(o, g4, logp)
+    st = {k: np.stack([lvl[k], lvl[k]], axis=-1) for k in ("vor", "div", "t", "tr", "ps")}
+    phis = o.trunct(o.spec(synth.synthetic_orography().T))
+    surf = physics_inputs(seed)
+    return o, st, phis, {k: surf[k] for k in ("fmask", "phis0", "tland", "tsea", "swav", "snowc", "alb_l", "alb_s", "albsfc")}
+
+
+def run_coupled_reference(o, st, phis, surf, ref, nsteps=WINDOW_STEPS, delt=900.0):
+    """stepone + nsteps leapfrog steps (src/ini_stepone.f90, src/dyn_stloop.f90:28-43) with the oracle's dynamics and, in grtend's
+    physics slot (src/dyn_grtend.f90:222-225), the compiled reference parametrisations."""
+    from _oracle import DynOracle
+    ref.set_surface(surf["phis0"], surf["alb_l"], surf["alb_s"], surf["albsfc"], surf["snowc"])
+    ref.sol_oz(TYEAR)
+    do = DynOracle(o)
+    zero = np.zeros((62, 32))
+    flag = {"lradsw": True}
+
+    def hook(ug, vg, tg, qg, phig, pslg, ut, vt, tt, qt):
+        return ref.phypar(ug, vg, tg, qg, phig, pslg, surf["fmask"], surf["phis0"], surf["tland"], surf["tsea"], surf["swav"],
+                          flag["lradsw"], ut, vt, tt, qt)[:4]
+
+    sched = [(1, 1, 0.5 * delt, 0.5 * delt, True), (1, 2, delt, delt, True)]
+    sched += [(2, 2, 2 * delt, 2 * delt, (i + 1) % 3 == 1) for i in range(nsteps)]
+    for j1, j2, dt_imp, dt, sw in sched:
+        do.impint(dt_imp, 0.5)
+        flag["lradsw"] = sw
+        st = do.step(j1, j2, dt, 0.5, 0.05, 0.53, st, phis, zero, zero, phys=hook)
+    return st
+
+
 def main():
     from _oracle import RefPhys
     ref = RefPhys(HSG, gaussian_latitudes())
@@ -98,6 +141,10 @@ def main():
     for tag, d in res.items():
         for k, v in d.items():
             out[f"{tag}_{k}"] = np.asarray(v)[KEEP]
+    o, st, phis, surf = coupled_inputs()
+    end = run_coupled_reference(o, st, phis, surf, RefPhys(HSG, gaussian_latitudes()))
+    for k, v in end.items():
+        out["window_" + k] = np.asarray(v).reshape(-1, order="F")[WINDOW_KEEP]
     path = os.path.join(os.path.dirname(__file__), "physics_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;",

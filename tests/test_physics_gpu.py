@@ -97,3 +97,66 @@ def test_physics_overwrite_mode_gives_the_physics_tendencies_alone():
     for k in ("utend", "vtend", "ttend", "qtend"):
         a = with_dyn["sw"][k] - inp[k]
         assert rel(a, phys_only["sw"][k]) < 1e-9          # (dyn + phys) - dyn == phys up to the rounding of the larger sum
+
+
+# ---- the physics inside the time step (src/dyn_grtend.f90:222-225): stepone + leapfrog steps with the parametrisations attached ----
+WTOL = 1e-10        # north_star: fields within 1e-10 relative after the window
+
+
+def device_window(st, phis, surf, nsteps):
+    from make_physics_golden import TYEAR as TY
+    from speedy_ml_amd.dynamics import Dynamics
+    from speedy_ml_amd.spectral import Spectral
+    sp = Spectral()
+    dyn = Dynamics(sp)
+    ph = Physics(gaussian_latitudes())
+    g = lambda a: np.asarray(a).reshape(48, 96)
+    ph.set_surface(*[g(surf[k]) for k in ("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc")])
+    ph.sol_oz(TY)
+    dyn.attach_physics(ph)
+    dev2 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a).T)).cuda()
+    zero = np.zeros((62, 32))
+    dyn.set_boundary(dev2(phis), dev2(zero), dev2(zero))
+    state = np.zeros((2, 33, 32, 62))
+    for j in range(2):
+        for off, k in ((0, "vor"), (8, "div"), (16, "t"), (24, "tr")):
+            state[j, off:off + 8] = st[k][..., j].transpose(2, 1, 0)
+        state[j, 32] = st["ps"][..., j].T
+    dstate = torch.from_numpy(state).cuda()
+    dyn.window(dstate, nsteps, start=True)
+    torch.cuda.synchronize()
+    got = dstate.cpu().numpy()
+    out = {k: np.stack([got[j, off:off + 8].transpose(2, 1, 0) for j in range(2)], axis=-1) for off, k in ((0, "vor"), (8, "div"), (16, "t"), (24, "tr"))}
+    out["ps"] = np.stack([got[j, 32].T for j in range(2)], axis=-1)
+    return out, dyn, ph
+
+
+def test_window_with_physics_matches_reference_fixture():
+    from make_physics_golden import WINDOW_KEEP, WINDOW_STEPS, coupled_inputs
+    gold = np.load(GOLD)
+    _, st, phis, surf = coupled_inputs()
+    got, _, _ = device_window(st, phis, surf, WINDOW_STEPS)
+    for k in ("vor", "div", "t", "tr", "ps"):
+        a, b = got[k].reshape(-1, order="F")[WINDOW_KEEP], gold["window_" + k]
+        assert rel(a, b) < WTOL, (k, rel(a, b))
+
+
+def test_window_with_physics_matches_oracle_plus_compiled_reference():
+    from _oracle import RefPhys
+    from make_physics_golden import coupled_inputs, run_coupled_reference
+    if not RefPhys.available():
+        pytest.skip("oracle/_ref/libref_phy.so not present")
+    o, st, phis, surf = coupled_inputs(seed=9)
+    want = run_coupled_reference(o, st, phis, surf, RefPhys(HSG, gaussian_latitudes()), nsteps=7)
+    got, dyn, _ = device_window(st, phis, surf, 7)
+    for k in ("vor", "div", "t", "tr", "ps"):
+        assert rel(got[k], want[k]) < WTOL, (k, rel(got[k], want[k]))
+    # the physics did something: the adiabatic window ends somewhere else
+    from _oracle import DynOracle
+    do = DynOracle(o)
+    dry = dict(st)
+    zero = np.zeros((62, 32))
+    for j1, j2, dt in [(1, 1, 450.0), (1, 2, 900.0)] + [(2, 2, 1800.0)] * 7:
+        do.impint(dt, 0.5)
+        dry = do.step_dry(j1, j2, dt, 0.5, 0.05, 0.53, dry, phis, zero, zero)
+    assert rel(dry["t"], want["t"]) > 1e-6
