@@ -102,7 +102,7 @@ def cpu_baseline(model, budget_s=12.0):
         phys_note = ""
         if getattr(model, "phys", None) is not None:
             # the column physics: the reference's own phy_*.f90 (oracle/_ref/libref_phy.so) through the phypar call sequence, a
-            # short-wave step and a step without; + 41 more inverse transforms per step
+            # short-wave step and a step without; + phypar's 41 inverse transforms per step (the reference does all of them)
             from _oracle import RefPhys
             per_step += 41 * per_tr
             if RefPhys.available():

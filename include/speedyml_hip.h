@@ -359,8 +359,9 @@ int sml_dyn_step(sml_dyn *dyn, double *state_dev, int j1, int j2, double dt, dou
 int sml_dyn_window(sml_dyn *dyn, double *state_dev, int start, int nsteps, double delt, double alph, double rob, double wil,
                    void *stream);
 /* Column physics inside grtend (src/dyn_grtend.f90:222-225: geop(j1); phypar(...)): once attached, every time step also
- * transforms time level 1 to phypar's 41 grids (same launch as grtend's 50) and adds sml_phys_tendencies to the grid-point
- * tendencies before the forward transforms.  phys == NULL detaches.  nstrad: short-wave radiation every nstrad-th leapfrog
+ * transforms time level 1 to the 27 of phypar's 41 grids that the parametrisations read (same launch as grtend's 50; the
+ * winds above the lowest level are never used) and adds sml_phys_tendencies_sfcwind to the grid-point tendencies before the
+ * forward transforms.  phys == NULL detaches.  nstrad: short-wave radiation every nstrad-th leapfrog
  * step of a window, lradsw = (mod(istep, nstrad) == 1) (src/dyn_stloop.f90:39); sml_dyn_set_lradsw sets the flag that single
  * sml_dyn_step / sml_dyn_grtend calls and a window's stepone use (the module variable lradsw, src/mod_lflags.f90:22). */
 int sml_dyn_attach_physics(sml_dyn *dyn, sml_phys *phys, int nstrad);
@@ -398,6 +399,11 @@ int sml_phys_get_tables(sml_phys *phys, double *zonal_host, double *fband_host, 
  * in the reference's order.  lradsw: this is a short-wave step (every nstrad = 3rd, src/dyn_stloop.f90:36). */
 int sml_phys_tendencies(sml_phys *phys, const double *grids_dev, int lradsw, double *tend_dev, int off_u, int off_v, int off_t, int off_q,
                         int accumulate, void *stream);
+/* The same with the inputs the parametrisations actually read: of the winds only the lowest level enters (suflux,
+ * src/phy_suflux.f90:104-116), so grids_dev is [27][48][96] = ug1(:,kx) vg1(:,kx) tg1(8) qg1(8) phig1(8) pslg1 and 14 of
+ * phypar's 41 inverse transforms need not be done at all.  want_diag == 0 skips the 2-D diagnostics (sml_phys_diag). */
+int sml_phys_tendencies_sfcwind(sml_phys *phys, const double *grids_dev, int lradsw, double *tend_dev, int off_u, int off_v, int off_t,
+                                int off_q, int accumulate, int want_diag, void *stream);
 /* per-column diagnostics of the last call, host [48][96]: 0 precnv 1 precls 2 cbmf 3 ts 4 tskin 5 ssrd 6 slrd 7 olr 8 shf 9 evap
  * 10 ustr 11 vstr 12 cloudc 13 clstr 14 tsr 15 ssr 16 slr 17 hfluxn(land) 18 hfluxn(sea) 19 t0 20 q0 21 iptop 22 icltop */
 int sml_phys_diag(sml_phys *phys, int which, double *out_host);

@@ -38,7 +38,8 @@ constexpr int NSTATE = 33;         // fields per time level
 constexpr int F_VOR = 0, F_DIV = 8, F_T = 16, F_TR = 24, F_PS = 32;
 constexpr int NB_SPEC = 50;        // inverse batch: the 32 3-D state fields, ucos(8), vcos(8), d(ps)/dx, d(ps)/dy
 constexpr int NB_GRID = 73;        // forward batch, see k_gridtend
-constexpr int NB_PHYS = 41;        // phypar's inverse set of time level 1: u(8) v(8) t(8) q(8) phi(8) ps (phy_phypar.f90:54-66)
+constexpr int NB_PHYS = 27;        // phypar's inverse set of time level 1 (phy_phypar.f90:54-66) without the 14 wind levels that no
+                                   // parametrisation reads: u(kx) v(kx) t(8) q(8) phi(8) ps
 constexpr int NB_ALL = NB_SPEC + NB_PHYS;
 
 // src/mod_dyncon0.f90:9-45, src/mod_dyncon1.f90:12-27 (all reals are promoted to 8 bytes, src/makefile:6,12)
@@ -1002,6 +1003,7 @@ struct sml_dyn {
     double *own_state = nullptr;       // [2][33][SP] for hosts that keep the state in Fortran arrays (sml_dyn_*_host)
     double *batch_grid = nullptr;      // [50 + 41][GR]: grtend's inverse set | phypar's inverse set (time level 1)
     sml_phys *phys = nullptr;          // column physics added to the grid-point tendencies (sml_dyn_attach_physics), not owned
+    int phys_diag = 1;                 // keep the physics' 2-D diagnostics up to date (sml_phys_diag) during time steps
     int nstrad = 3, lradsw = 1;        // short-wave radiation every nstrad-th step; flag of the next sml_dyn_step (mod_lflags.f90:22)
     int32_t *desc_phys = nullptr;      // inverse-batch descriptors with physics: [2 (j2)][91][4], fields relative to the whole state
     double *aux = nullptr;             // xgeop1 | xgeop2 | corf | phis: geopotential operands of the type-7 rows
@@ -1036,14 +1038,15 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
 {
     const double *sj2 = state + (size_t)(a.j2 - 1) * NSTATE * SP;
     // the 50 inverse transforms of grtend (:61-99) straight from the state: uvspec and grad are formed while the fields are staged.
-    // With physics attached the same launch also produces phypar's 41 grids of time level 1 (phy_phypar.f90:54-66), geop(1) included.
+    // With physics attached the same launch also produces the 27 grids of time level 1 that phypar's parametrisations read
+    // (phy_phypar.f90:54-66 minus the unused wind levels), geop(1) included.
     int rc = d->phys ? sml_spectral_grid_derived_aux(d->sp, state, d->desc_phys + (size_t)(a.j2 - 1) * NB_ALL * 4, d->aux, d->batch_grid, NB_ALL, st)
                      : sml_spectral_grid_derived(d->sp, sj2, d->desc, d->batch_grid, NB_SPEC, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gridtend, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid);
     SML_HIP(hipGetLastError());
     if (d->phys) {      // dyn_grtend.f90:222-225: phypar adds its tendencies to utend, vtend, ttend, trtend before the forward transforms
-        rc = sml_phys_tendencies(d->phys, d->batch_grid + (size_t)NB_SPEC * GR, lradsw, d->tend_grid, 0, 8, 56, 64, 1, st);
+        rc = sml_phys_tendencies_sfcwind(d->phys, d->batch_grid + (size_t)NB_SPEC * GR, lradsw, d->tend_grid, 0, 8, 56, 64, 1, d->phys_diag, st);
         if (rc) return rc;
     }
     rc = sml_spectral_spec_mixed(d->sp, d->tend_grid, d->tend_spec, NB_GRID, d->scale, st);
@@ -1161,7 +1164,7 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
         if (!rc) { d->allocs.push_back(d->desc); rc = sml::dev_upload(&d->scale, sc, NB_GRID); }
         if (!rc) d->allocs.push_back(d->scale);
         // the same set addressed from the start of the state for j2 = 1 | 2, followed by phypar's set of time level 1:
-        // u v (uvspec, kcos 2) | t q (kcos 1) | phi (type 7) | ps
+        // u(kx) v(kx) (uvspec, kcos 2) | t q (kcos 1) | phi (type 7) | ps
         static int32_t kp[2][NB_ALL][4];
         for (int j2 = 0; j2 < 2; ++j2) {
             for (int f = 0; f < NB_SPEC; ++f) {
@@ -1169,11 +1172,11 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
             }
             for (int f = 0; f < NB_PHYS; ++f) {
                 int32_t *r = kp[j2][NB_SPEC + f];
-                const int k = f & 7;
-                if (f < 16) { r[0] = f < 8 ? 1 : 2; r[1] = F_VOR + k; r[2] = F_DIV + k; r[3] = 2; }
-                else if (f < 24) { r[0] = 0; r[1] = r[2] = F_T + k; r[3] = 1; }
-                else if (f < 32) { r[0] = 0; r[1] = r[2] = F_TR + k; r[3] = 1; }
-                else if (f < 40) { r[0] = 7; r[1] = F_T; r[2] = k; r[3] = 1; }
+                const int k = (f - 2) & 7;
+                if (f < 2) { r[0] = f == 0 ? 1 : 2; r[1] = F_VOR + KX - 1; r[2] = F_DIV + KX - 1; r[3] = 2; }
+                else if (f < 10) { r[0] = 0; r[1] = r[2] = F_T + k; r[3] = 1; }
+                else if (f < 18) { r[0] = 0; r[1] = r[2] = F_TR + k; r[3] = 1; }
+                else if (f < 26) { r[0] = 7; r[1] = F_T; r[2] = k; r[3] = 1; }
                 else { r[0] = 0; r[1] = r[2] = F_PS; r[3] = 1; }
             }
         }

@@ -159,9 +159,24 @@ __device__ __forceinline__ double qsat_of(double ta, double p)
     return 622. * q / (p - 0.378 * q);
 }
 
-struct Column {                  // level arrays are 1-based like the Fortran
-    double ug[NLP], vg[NLP], tg[NLP], qg[NLP], phig[NLP], se[NLP], rh[NLP], qsat[NLP];
-    double psg, rps;
+// Level arrays are 1-based like the Fortran.  Every level index below is a compile-time constant once the loops are unrolled
+// (run-time tops -- convection top, cloud top -- are predicates inside fixed-bound loops), so the arrays live in registers: with
+// run-time indices the compiler put them in scratch (1264 B per lane) and the kernel spent most of its 26 us waiting on scratch
+// round trips.  The winds enter the parametrisations at the lowest level only (suflux), so only ug1(kx), vg1(kx) are kept.
+// Long-lived, rarely touched per-column arrays (the tendency accumulators, the short-wave heating, the long-wave table rows)
+// are parked in LDS, lane-interleaved (element k of a thread's array at base[k * 64]): left to the register allocator they were
+// spilled to scratch and re-read one waited-for load at a time (6 us of the kernel's tail).
+struct LA {
+    double *b;
+    __device__ __forceinline__ double &operator[](int k) const { return b[k << 6]; }
+};
+template <int NB> struct LA2 {       // [level][band]
+    double *b;
+    __device__ __forceinline__ LA operator[](int k) const { return LA{b + ((k * NB) << 6)}; }
+};
+struct Column {
+    double tg[NLP], qg[NLP], phig[NLP], se[NLP], rh[NLP], qsat[NLP];
+    double usfc, vsfc, psg, rps;
 };
 
 __device__ void convmf(const PhysLev &L, const Column &c, int &itop, double &cbmf, double &precnv, double *dfse, double *dfqa)
@@ -210,7 +225,9 @@ __device__ void convmf(const PhysLev &L, const Column &c, int &itop, double &cbm
     double fds = fmass * sb, fdq = fmass * qb;
     dfse[k] = fds - fus;
     dfqa[k] = fdq - fuq;
-    for (k = KX - 1; k >= itop + 1; --k) {
+#pragma unroll
+    for (k = KX - 1; k >= 4; --k) {          // do k = kx-1, itop+1, -1 with itop >= 3: the top is a predicate (no run-time index)
+        if (k < itop + 1) continue;
         k1 = k - 1;
         dfse[k] = fus - fds;
         dfqa[k] = fuq - fdq;
@@ -231,11 +248,14 @@ __device__ void convmf(const PhysLev &L, const Column &c, int &itop, double &cbm
             dfqa[KX] = dfqa[KX] - fsq;
         }
     }
-    k = itop;
-    const double qsatb = c.qsat[k] + L.wvi2[k] * (c.qsat[k + 1] - c.qsat[k]);
-    precnv = fmax(fuq - fmass * qsatb, 0.0);
-    dfse[k] = fus - fds + ALHC * precnv;
-    dfqa[k] = fuq - fdq - precnv;
+#pragma unroll
+    for (k = 3; k <= KX - 1; ++k) {          // k = itop
+        if (k != itop) continue;
+        const double qsatb = c.qsat[k] + L.wvi2[k] * (c.qsat[k + 1] - c.qsat[k]);
+        precnv = fmax(fuq - fmass * qsatb, 0.0);
+        dfse[k] = fus - fds + ALHC * precnv;
+        dfqa[k] = fuq - fdq - precnv;
+    }
 }
 
 __device__ void lscond(const PhysLev &L, const Column &c, int &itop, double &precls, double *dtlsc, double *dqlsc)
@@ -299,7 +319,9 @@ __device__ void radsw(const PhysLev &L, const Column &c, int icltop, double clou
     const double fband2 = 0.05, fband1 = 1. - fband2;
     const double psa = c.psg;
     for (int k = 1; k <= KX; ++k) for (int b = 1; b <= 4; ++b) tau2[k][b] = 0.0;
-    if (icltop <= KX) tau2[icltop][3] = ALBCL * cloudc;
+#pragma unroll
+    for (int k = 1; k <= KX; ++k)
+        if (k == icltop) tau2[k][3] = ALBCL * cloudc;
     tau2[KX][3] = ALBCLS * clstr;
     const double psaz = psa * zenit;
     const double acloud = cloudc * fmin(ABSCL1 * qcloud, ABSCL2);
@@ -387,7 +409,7 @@ __device__ __forceinline__ double fband_of(const double *__restrict__ fband, dou
     return fband[(size_t)(it - 100) * 4 + (jb - 1)];
 }
 
-struct LwState { double st4a[NLP][3], flux[5]; };
+struct LwState { double st4a[NLP][3], flux[5]; LA2<5> fb; };
 
 // radlw(-1, ...): downward pass.  radlw(+1, ...): upward pass; both use the column's tau2 / st4a / flux
 __device__ void radlw_down(const PhysLev &L, const Column &c, const double *__restrict__ fband, const double (*tau2)[5], LwState &s, double &fsfcd,
@@ -412,10 +434,13 @@ __device__ void radlw_down(const PhysLev &L, const Column &c, const double *__re
     }
     fsfcd = 0.0;
     for (int k = 1; k <= KX; ++k) dfabs[k] = 0.0;
+    // the table rows of the 8 level temperatures, fetched in one batch (one exposed latency) and kept for the upward pass
+    for (int k = 1; k <= KX; ++k)
+        for (int jb = 1; jb <= 4; ++jb) s.fb[k][jb] = fband_of(fband, c.tg[k], jb);
     int k = 1;
     for (int jb = 1; jb <= 2; ++jb) {
         const double emis = 1. - tau2[k][jb];
-        const double brad = fband_of(fband, c.tg[k], jb) * (s.st4a[k][1] + emis * s.st4a[k][2]);
+        const double brad = s.fb[k][jb] * (s.st4a[k][1] + emis * s.st4a[k][2]);
         s.flux[jb] = emis * brad;
         dfabs[k] = dfabs[k] - s.flux[jb];
     }
@@ -423,7 +448,7 @@ __device__ void radlw_down(const PhysLev &L, const Column &c, const double *__re
     for (int jb = 1; jb <= 4; ++jb)
         for (k = 2; k <= KX; ++k) {
             const double emis = 1. - tau2[k][jb];
-            const double brad = fband_of(fband, c.tg[k], jb) * (s.st4a[k][1] + emis * s.st4a[k][2]);
+            const double brad = s.fb[k][jb] * (s.st4a[k][1] + emis * s.st4a[k][2]);
             dfabs[k] = dfabs[k] + s.flux[jb];
             s.flux[jb] = tau2[k][jb] * s.flux[jb] + emis * brad;
             dfabs[k] = dfabs[k] - s.flux[jb];
@@ -445,7 +470,7 @@ __device__ void radlw_up(const PhysLev &L, const Column &c, const double *__rest
     for (int jb = 1; jb <= 4; ++jb)
         for (int k = KX; k >= 2; --k) {
             const double emis = 1. - tau2[k][jb];
-            const double brad = fband_of(fband, c.tg[k], jb) * (s.st4a[k][1] - emis * s.st4a[k][2]);
+            const double brad = s.fb[k][jb] * (s.st4a[k][1] - emis * s.st4a[k][2]);
             dfabs[k] = dfabs[k] + s.flux[jb];
             s.flux[jb] = tau2[k][jb] * s.flux[jb] + emis * brad;
             dfabs[k] = dfabs[k] - s.flux[jb];
@@ -453,7 +478,7 @@ __device__ void radlw_up(const PhysLev &L, const Column &c, const double *__rest
     const int k = 1;
     for (int jb = 1; jb <= 2; ++jb) {
         const double emis = 1. - tau2[k][jb];
-        const double brad = fband_of(fband, c.tg[k], jb) * (s.st4a[k][1] - emis * s.st4a[k][2]);
+        const double brad = s.fb[k][jb] * (s.st4a[k][1] - emis * s.st4a[k][2]);
         dfabs[k] = dfabs[k] + s.flux[jb];
         s.flux[jb] = tau2[k][jb] * s.flux[jb] + emis * brad;
         dfabs[k] = dfabs[k] - s.flux[jb];
@@ -477,8 +502,8 @@ __device__ void suflux(const PhysLev &L, const Column &c, double phi0, double fm
     const double ghum0 = 1. - FHUM0;
     const double dlambda = CLAMBSN - CLAMBDA;
     const int nl1 = KX - 1;
-    o.u0 = FWIND0 * c.ug[KX];
-    o.v0 = FWIND0 * c.vg[KX];
+    o.u0 = FWIND0 * c.usfc;
+    o.v0 = FWIND0 * c.vsfc;
     const double gtemp0 = 1. - FTEMP0, rcp = 1. / CP, rdphi0 = -1. / (RD * 288. * L.sigl[KX]);
     const double dt1 = L.wvi2[KX] * (c.tg[KX] - c.tg[nl1]);
     double t1[3], t2[3], q1[3], qsat0[3], denvvs[3];
@@ -503,8 +528,8 @@ __device__ void suflux(const PhysLev &L, const Column &c, double phi0, double fm
     else dthl = fmax(-DTHETA, astab * (tskin - t2[1]));
     denvvs[1] = denvvs[0] * (1. + dthl * rdth);
     const double cdldv = CDL * denvvs[0] * forog;
-    o.ustr[1] = -cdldv * c.ug[KX];
-    o.vstr[1] = -cdldv * c.vg[KX];
+    o.ustr[1] = -cdldv * c.usfc;
+    o.vstr[1] = -cdldv * c.vsfc;
     const double chlcp = CHL * CP;
     o.shf[1] = chlcp * denvvs[1] * (tskin - t1[1]);
     if (FHUM0 > 0.) {
@@ -548,8 +573,8 @@ __device__ void suflux(const PhysLev &L, const Column &c, double phi0, double fm
     }
     const int ks = 2;
     const double cdsdv = CDS * denvvs[ks];
-    o.ustr[2] = -cdsdv * c.ug[KX];
-    o.vstr[2] = -cdsdv * c.vg[KX];
+    o.ustr[2] = -cdsdv * c.usfc;
+    o.vstr[2] = -cdsdv * c.vsfc;
     const double chscp = CHS * CP;
     o.shf[2] = chscp * denvvs[ks] * (tsea - t1[2]);
     qsat0[2] = qsat_of(tsea, psa);
@@ -570,7 +595,7 @@ __device__ void suflux(const PhysLev &L, const Column &c, double phi0, double fm
     o.q0 = q1[2] + fmask * (q1[1] - q1[2]);
 }
 
-__device__ void vdifsc(const PhysLev &L, const Column &c, int icnv, double *ut, double *vt, double *tt, double *qt)
+__device__ void vdifsc(const PhysLev &L, const Column &c, int icnv, double *tt, double *qt)
 {
     const int nl1 = KX - 1;
     const double cshc = L.dsig[KX] / 3600.;
@@ -580,7 +605,7 @@ __device__ void vdifsc(const PhysLev &L, const Column &c, int icnv, double *ut, 
     double rsig[NLP], rsig1[NLP];
     for (int k = 1; k <= nl1; ++k) { rsig[k] = 1. / L.dsig[k]; rsig1[k] = 1. / (1. - L.sigh[k]); }
     rsig[KX] = 1. / L.dsig[KX];
-    for (int k = 1; k <= KX; ++k) { ut[k] = 0.0; vt[k] = 0.0; tt[k] = 0.0; qt[k] = 0.0; }
+    for (int k = 1; k <= KX; ++k) { tt[k] = 0.0; qt[k] = 0.0; }     // utenvd = vtenvd = 0 (:44-49): the winds only feel the surface stress
     double drh0 = RHGRAD * (L.sig[KX] - L.sig[nl1]);
     double fvdiq2 = fvdiq * L.sigh[nl1];
     {
@@ -625,26 +650,64 @@ __device__ void vdifsc(const PhysLev &L, const Column &c, int icnv, double *ut, 
     }
 }
 
+// phase time stamps of one tropical workgroup (profiles/micro/physics_phase_stamps.py); compiled in with -DSML_PHYS_STAMPS only
+__device__ unsigned long long g_phys_dbg[16];
+#ifdef SML_PHYS_STAMPS
+#define PSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); \
+        if (blockIdx.x == 36 && threadIdx.x == 0) g_phys_dbg[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#endif
+
+// where phypar's grid-point inputs of time level 1 are: 8 consecutive level fields each for t, q, phi; ONE field each for the
+// lowest-level winds ug1(:,kx), vg1(:,kx) (the only wind levels the parametrisations read) and for log(ps)
+struct PhysIn { const double *usfc, *vsfc, *t, *q, *phi, *ps; };
+
 // the grid-point part of phypar (src/phy_phypar.f90:80-230) for one column.
-// grids: [41][GR] = ug1(8) vg1(8) tg1(8) qg1(8) phig1(8) pslg1 of time level 1.  tend: the grid-point tendencies utend, vtend,
-// ttend, qtend as 8 consecutive fields each, starting at fields off_u, off_v, off_t, off_q of `tend`.  accumulate != 0: they
-// hold the dynamical tendencies and the physics is ADDED in the reference's order (:117-118,172-174,193-196: each `x = x + a + b`
-// is two roundings, left to right); accumulate == 0: they are overwritten with the physics tendencies alone.
-__global__ __launch_bounds__(64) void k_physics(PhysLev L, PhysDev D, const double *__restrict__ grids, double *__restrict__ tend, int lradsw,
-                                                 int off_u, int off_v, int off_t, int off_q, int accumulate)
+// tend: the grid-point tendencies utend, vtend, ttend, qtend as 8 consecutive fields each, starting at fields off_u, off_v,
+// off_t, off_q of `tend`.  accumulate != 0: they hold the dynamical tendencies and the physics is ADDED in the reference's order
+// (:117-118,172-174,193-196: each `x = x + a + b` is two roundings, left to right); accumulate == 0: they are overwritten with
+// the physics tendencies alone.  The wind tendencies of the physics are zero above the lowest level (vdifsc :44-49 leaves
+// utenvd = vtenvd = 0; only the surface stress acts), so with accumulate the upper 7 levels of utend, vtend are not touched.
+// want_diag == 0 skips the 2-D diagnostics.
+__global__ __launch_bounds__(64) void k_physics(PhysLev L, PhysDev D, PhysIn in, double *__restrict__ tend, int lradsw,
+                                                 int off_u, int off_v, int off_t, int off_q, int accumulate, int want_diag)
 {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= GR) return;
     const int jlat = p / IX;
+    PSTAMP(0);
     Column c;
+    // every global load the column needs, issued in one batch
     for (int k = 1; k <= KX; ++k) {
-        c.ug[k] = grids[(size_t)(k - 1) * GR + p];
-        c.vg[k] = grids[(size_t)(8 + k - 1) * GR + p];
-        c.tg[k] = grids[(size_t)(16 + k - 1) * GR + p];
-        c.qg[k] = grids[(size_t)(24 + k - 1) * GR + p];
-        c.phig[k] = grids[(size_t)(32 + k - 1) * GR + p];
+        c.tg[k] = in.t[(size_t)(k - 1) * GR + p];
+        c.qg[k] = in.q[(size_t)(k - 1) * GR + p];
+        c.phig[k] = in.phi[(size_t)(k - 1) * GR + p];
     }
-    c.psg = exp(grids[(size_t)40 * GR + p]);
+    c.usfc = in.usfc[p];
+    c.vsfc = in.vsfc[p];
+    const double pslg = in.ps[p];
+    __shared__ double park[(3 * NLP + 5 * NLP) * 64];
+    LA tt{park + threadIdx.x}, qt{park + NLP * 64 + threadIdx.x}, tt_rsw{park + 2 * NLP * 64 + threadIdx.x};
+    for (int k = 1; k <= KX; ++k) {
+        tt[k] = accumulate ? tend[(size_t)(off_t + k - 1) * GR + p] : 0.0;
+        qt[k] = accumulate ? tend[(size_t)(off_q + k - 1) * GR + p] : 0.0;
+    }
+    const double u_dyn = accumulate ? tend[(size_t)(off_u + KX - 1) * GR + p] : 0.0;
+    const double v_dyn = accumulate ? tend[(size_t)(off_v + KX - 1) * GR + p] : 0.0;
+    const double s_fmask = D.fmask[p], s_phis0 = D.phis0[p], s_tland = D.tland[p], s_tsea = D.tsea[p], s_swav = D.swav[p];
+    const double s_alb_l = D.alb_l[p], s_alb_s = D.alb_s[p], s_snowc = D.snowc[p], s_forog = D.forog[p], s_albsfc = D.albsfc[p];
+    double tau2[NLP][5], stratc[3], ssrd;
+    if (!lradsw) {      // the short-wave step's leftovers: long-wave transmissivities, stratospheric corrections, heating, surface flux
+        for (int k = 1; k <= KX; ++k) {
+            for (int b = 1; b <= 4; ++b) tau2[k][b] = D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p];
+            tt_rsw[k] = D.tt_rsw[(size_t)(k - 1) * GR + p];
+        }
+        stratc[1] = D.stratc[p];
+        stratc[2] = D.stratc[GR + p];
+        ssrd = D.ssrd[p];
+    }
+    c.psg = exp(pslg);
     c.rps = 1. / c.psg;
     for (int k = 1; k <= KX; ++k) {
         c.qg[k] = fmax(c.qg[k], 0.);
@@ -652,77 +715,79 @@ __global__ __launch_bounds__(64) void k_physics(PhysLev L, PhysDev D, const doub
         c.qsat[k] = qsat_of(c.tg[k], L.sig[k] * c.psg);
         c.rh[k] = c.qg[k] / c.qsat[k];
     }
-    double tt[NLP], qt[NLP], ut[NLP], vt[NLP];
-    for (int k = 1; k <= KX; ++k) {
-        tt[k] = accumulate ? tend[(size_t)(off_t + k - 1) * GR + p] : 0.0;
-        qt[k] = accumulate ? tend[(size_t)(off_q + k - 1) * GR + p] : 0.0;
-    }
     // 2. precipitation
     int iptop;
     double cbmf, precnv, precls, a1[NLP], a2[NLP], b1[NLP], b2[NLP];
+    PSTAMP(1);
     convmf(L, c, iptop, cbmf, precnv, a1, a2);
+    PSTAMP(2);
     for (int k = 2; k <= KX; ++k) { a1[k] = a1[k] * c.rps * L.grdscp[k]; a2[k] = a2[k] * c.rps * L.grdsig[k]; }
     const int icnv = KX - iptop;
     lscond(L, c, iptop, precls, b1, b2);
     for (int k = 1; k <= KX; ++k) { tt[k] = tt[k] + a1[k] + b1[k]; qt[k] = qt[k] + a2[k] + b2[k]; }     // ttend = ttend + tt_cnv + tt_lsc
+    PSTAMP(3);
     // 3. radiation and surface fluxes
-    double tau2[NLP][5], stratc[3];
-    double ssrd, ssr = 0., tsr = 0., cloudc = 0., clstr = 0.;
+    double ssr = 0., tsr = 0., cloudc = 0., clstr = 0.;
     int icltop = 0;
     if (lradsw) {
         const double gse = (c.se[KX - 1] - c.se[KX]) / (c.phig[KX - 1] - c.phig[KX]);
         double qcloud;
-        cloud(c, precnv, precls, iptop, gse, D.fmask[p], icltop, cloudc, clstr, qcloud);
-        radsw(L, c, icltop, cloudc, clstr, qcloud, D.fsol[jlat], D.ozone[jlat], D.ozupp[jlat], D.zenit[jlat], D.stratz[jlat], D.albsfc[p],
+        cloud(c, precnv, precls, iptop, gse, s_fmask, icltop, cloudc, clstr, qcloud);
+        radsw(L, c, icltop, cloudc, clstr, qcloud, D.fsol[jlat], D.ozone[jlat], D.ozupp[jlat], D.zenit[jlat], D.stratz[jlat], s_albsfc,
               tau2, stratc, ssrd, ssr, tsr, a1);
         for (int k = 1; k <= KX; ++k) {
-            D.tt_rsw[(size_t)(k - 1) * GR + p] = a1[k] * c.rps * L.grdscp[k];
+            tt_rsw[k] = a1[k] * c.rps * L.grdscp[k];
+            D.tt_rsw[(size_t)(k - 1) * GR + p] = tt_rsw[k];
             for (int b = 1; b <= 4; ++b) D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p] = tau2[k][b];
         }
         D.stratc[p] = stratc[1];
         D.stratc[GR + p] = stratc[2];
         D.ssrd[p] = ssrd;
-        D.diag[(size_t)D_CLOUDC * GR + p] = cloudc; D.diag[(size_t)D_CLSTR * GR + p] = clstr;
-        D.diag[(size_t)D_TSR * GR + p] = tsr; D.diag[(size_t)D_SSR * GR + p] = ssr; D.diag[(size_t)D_ICLTOP * GR + p] = icltop;
-    } else {
-        for (int k = 1; k <= KX; ++k)
-            for (int b = 1; b <= 4; ++b) tau2[k][b] = D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p];
-        stratc[1] = D.stratc[p];
-        stratc[2] = D.stratc[GR + p];
-        ssrd = D.ssrd[p];
+        if (want_diag) {
+            D.diag[(size_t)D_CLOUDC * GR + p] = cloudc; D.diag[(size_t)D_CLSTR * GR + p] = clstr;
+            D.diag[(size_t)D_TSR * GR + p] = tsr; D.diag[(size_t)D_SSR * GR + p] = ssr; D.diag[(size_t)D_ICLTOP * GR + p] = icltop;
+        }
     }
     LwState lw;
+    lw.fb = LA2<5>{park + 3 * NLP * 64 + threadIdx.x};
     double slrd, slr, olr;
+    PSTAMP(4);
     radlw_down(L, c, D.fband, tau2, lw, slrd, a2);      // a2 = dfabs of the long-wave scheme from here to radlw_up
+    PSTAMP(5);
     Surface sf;
-    suflux(L, c, D.phis0[p], D.fmask[p], D.tland[p], D.tsea[p], D.swav[p], ssrd, slrd, D.alb_l[p], D.alb_s[p], D.snowc[p], D.forog[p],
-           D.sqclat[jlat], sf);
+    suflux(L, c, s_phis0, s_fmask, s_tland, s_tsea, s_swav, ssrd, slrd, s_alb_l, s_alb_s, s_snowc, s_forog, D.sqclat[jlat], sf);
+    PSTAMP(6);
     radlw_up(L, c, D.fband, tau2, stratc, lw, sf.tsfc, slrd, sf.slru[3], slr, olr, a2);
+    PSTAMP(7);
     for (int k = 1; k <= KX; ++k) {
         const double tt_rlw = a2[k] * c.rps * L.grdscp[k];
-        tt[k] = tt[k] + D.tt_rsw[(size_t)(k - 1) * GR + p] + tt_rlw;
+        tt[k] = tt[k] + tt_rsw[k] + tt_rlw;
     }
     // 4. PBL
-    vdifsc(L, c, icnv, ut, vt, a1, a2);
-    ut[KX] = ut[KX] + sf.ustr[3] * c.rps * L.grdsig[KX];
-    vt[KX] = vt[KX] + sf.vstr[3] * c.rps * L.grdsig[KX];
+    vdifsc(L, c, icnv, a1, a2);
+    PSTAMP(8);
+    const double ut = 0.0 + sf.ustr[3] * c.rps * L.grdsig[KX];        // ut_pbl(:,kx) = utenvd (0) + stress term (:187-190)
+    const double vt = 0.0 + sf.vstr[3] * c.rps * L.grdsig[KX];
     a1[KX] = a1[KX] + sf.shf[3] * c.rps * L.grdscp[KX];
     a2[KX] = a2[KX] + sf.evap[3] * c.rps * L.grdsig[KX];
+    if (!accumulate)
+        for (int k = 1; k < KX; ++k) { tend[(size_t)(off_u + k - 1) * GR + p] = 0.0; tend[(size_t)(off_v + k - 1) * GR + p] = 0.0; }
+    tend[(size_t)(off_u + KX - 1) * GR + p] = u_dyn + ut;
+    tend[(size_t)(off_v + KX - 1) * GR + p] = v_dyn + vt;
     for (int k = 1; k <= KX; ++k) {
-        const double u_dyn = accumulate ? tend[(size_t)(off_u + k - 1) * GR + p] : 0.0;
-        const double v_dyn = accumulate ? tend[(size_t)(off_v + k - 1) * GR + p] : 0.0;
-        tend[(size_t)(off_u + k - 1) * GR + p] = u_dyn + ut[k];
-        tend[(size_t)(off_v + k - 1) * GR + p] = v_dyn + vt[k];
         tend[(size_t)(off_t + k - 1) * GR + p] = tt[k] + a1[k];
         tend[(size_t)(off_q + k - 1) * GR + p] = qt[k] + a2[k];
     }
-    double *dg = D.diag;
-    dg[(size_t)D_PRECNV * GR + p] = precnv; dg[(size_t)D_PRECLS * GR + p] = precls; dg[(size_t)D_CBMF * GR + p] = cbmf;
-    dg[(size_t)D_TS * GR + p] = sf.tsfc; dg[(size_t)D_TSKIN * GR + p] = sf.tskin; dg[(size_t)D_SSRD * GR + p] = ssrd;
-    dg[(size_t)D_SLRD * GR + p] = slrd; dg[(size_t)D_OLR * GR + p] = olr; dg[(size_t)D_SHF * GR + p] = sf.shf[3];
-    dg[(size_t)D_EVAP * GR + p] = sf.evap[3]; dg[(size_t)D_USTR * GR + p] = sf.ustr[3]; dg[(size_t)D_VSTR * GR + p] = sf.vstr[3];
-    dg[(size_t)D_SLR * GR + p] = slr; dg[(size_t)D_HFLUXN1 * GR + p] = sf.hfluxn[1]; dg[(size_t)D_HFLUXN2 * GR + p] = sf.hfluxn[2];
-    dg[(size_t)D_T0 * GR + p] = sf.t0; dg[(size_t)D_Q0 * GR + p] = sf.q0; dg[(size_t)D_IPTOP * GR + p] = iptop;
+    if (want_diag) {
+        double *dg = D.diag;
+        dg[(size_t)D_PRECNV * GR + p] = precnv; dg[(size_t)D_PRECLS * GR + p] = precls; dg[(size_t)D_CBMF * GR + p] = cbmf;
+        dg[(size_t)D_TS * GR + p] = sf.tsfc; dg[(size_t)D_TSKIN * GR + p] = sf.tskin; dg[(size_t)D_SSRD * GR + p] = ssrd;
+        dg[(size_t)D_SLRD * GR + p] = slrd; dg[(size_t)D_OLR * GR + p] = olr; dg[(size_t)D_SHF * GR + p] = sf.shf[3];
+        dg[(size_t)D_EVAP * GR + p] = sf.evap[3]; dg[(size_t)D_USTR * GR + p] = sf.ustr[3]; dg[(size_t)D_VSTR * GR + p] = sf.vstr[3];
+        dg[(size_t)D_SLR * GR + p] = slr; dg[(size_t)D_HFLUXN1 * GR + p] = sf.hfluxn[1]; dg[(size_t)D_HFLUXN2 * GR + p] = sf.hfluxn[2];
+        dg[(size_t)D_T0 * GR + p] = sf.t0; dg[(size_t)D_Q0 * GR + p] = sf.q0; dg[(size_t)D_IPTOP * GR + p] = iptop;
+    }
+    PSTAMP(9);
 }
 
 }  // namespace
@@ -815,13 +880,36 @@ int sml_phys_get_tables(sml_phys *ph, double *zonal_host /* [6][48] */, double *
     return SML_OK;
 }
 
-int sml_phys_tendencies(sml_phys *ph, const double *grids_dev, int lradsw, double *tend_dev, int off_u, int off_v, int off_t, int off_q,
-                        int accumulate, void *stream)
+static int launch_physics(sml_phys *ph, const PhysIn &in, int lradsw, double *tend_dev, int off_u, int off_v, int off_t, int off_q,
+                          int accumulate, int want_diag, void *stream)
 {
-    SML_REQUIRE(ph && grids_dev && tend_dev && off_u >= 0 && off_v >= 0 && off_t >= 0 && off_q >= 0, "sml_phys_tendencies: bad arguments");
-    hipLaunchKernelGGL(k_physics, dim3(GR / 64), dim3(64), 0, sml::as_stream(stream), ph->lev, ph->dev, grids_dev, tend_dev, lradsw ? 1 : 0,
-                       off_u, off_v, off_t, off_q, accumulate ? 1 : 0);
+    SML_REQUIRE(ph && in.t && tend_dev && off_u >= 0 && off_v >= 0 && off_t >= 0 && off_q >= 0, "sml_phys_tendencies: bad arguments");
+    hipLaunchKernelGGL(k_physics, dim3(GR / 64), dim3(64), 0, sml::as_stream(stream), ph->lev, ph->dev, in, tend_dev, lradsw ? 1 : 0,
+                       off_u, off_v, off_t, off_q, accumulate ? 1 : 0, want_diag ? 1 : 0);
     SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_phys_tendencies(sml_phys *ph, const double *g, int lradsw, double *tend_dev, int off_u, int off_v, int off_t, int off_q,
+                        int accumulate, void *stream)
+{   // phypar's full set [41][GR]: ug1(8) vg1(8) tg1(8) qg1(8) phig1(8) pslg1
+    SML_REQUIRE(g, "sml_phys_tendencies: bad arguments");
+    PhysIn in{g + (size_t)7 * GR, g + (size_t)15 * GR, g + (size_t)16 * GR, g + (size_t)24 * GR, g + (size_t)32 * GR, g + (size_t)40 * GR};
+    return launch_physics(ph, in, lradsw, tend_dev, off_u, off_v, off_t, off_q, accumulate, 1, stream);
+}
+
+int sml_phys_tendencies_sfcwind(sml_phys *ph, const double *g, int lradsw, double *tend_dev, int off_u, int off_v, int off_t, int off_q,
+                                int accumulate, int want_diag, void *stream)
+{   // the set the parametrisations actually read, [27][GR]: ug1(:,kx) vg1(:,kx) tg1(8) qg1(8) phig1(8) pslg1
+    SML_REQUIRE(g, "sml_phys_tendencies_sfcwind: bad arguments");
+    PhysIn in{g, g + (size_t)GR, g + (size_t)2 * GR, g + (size_t)10 * GR, g + (size_t)18 * GR, g + (size_t)26 * GR};
+    return launch_physics(ph, in, lradsw, tend_dev, off_u, off_v, off_t, off_q, accumulate, want_diag, stream);
+}
+
+int sml_phys_debug_stamps(unsigned long long *out)      // not part of the C-ABI (no declaration in include/): phase profiling aid
+{
+    SML_HIP(hipDeviceSynchronize());
+    SML_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_dbg), sizeof(unsigned long long) * 16));
     return SML_OK;
 }
 

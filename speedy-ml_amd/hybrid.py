@@ -422,13 +422,13 @@ class HybridRank:
             wl = ("BASELINE config 3: 1152-reservoir batched predict + region exchange (scatter, clamps, gather, standardise) "
                   "+ SPEEDY hand-off iogrid(30)/(31) + one 6-hour SPEEDY window of %d time steps (stepone + leapfrog: "
                   "%d inverse + 73 forward transforms, grid-point tendencies, %ssemi-implicit spectral step each) on the device"
-                  % (nst, 91 if self.phys is not None else 50,
+                  % (nst, 77 if self.phys is not None else 50,
                      "column physics (convection, condensation, clouds, SW every 3rd step, LW, surface fluxes, vertical diffusion), "
                      if self.phys is not None else "no column physics, "))
         if self.mode == "hybrid" and self.slab is not None:
             wl += ("; + slab-ocean coupling (config 5): SST assembly from the slab reservoirs, 27-step input averaging ring, "
                    "predict_slab_ml of the SST-predicting regions every 28th step")
         return {"workload": wl, "regions_total": NREG, "regions_this_rank": len(self.regions),
-                "transforms_per_step": (99 + (164 if self.phys is not None else 123) * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
+                "transforms_per_step": (99 + (150 if self.phys is not None else 123) * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
                 "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s); "
                                + ("one all-gather of the outvec slab per step" if self.world > 1 else "no collective")}
