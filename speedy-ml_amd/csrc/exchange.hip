@@ -90,7 +90,7 @@ __global__ void k_pack(const double *__restrict__ slab, int stride, const int32_
 }
 
 // ---- hybrid <-> SPEEDY hand-off (src/ppo_iogrid.f90:497-601) ----
-constexpr int NGP = 96 * 48, NLEV = 8, NFIELD = 33;
+constexpr int NGP = 96 * 48, NFIELD = 33;
 
 // field f: 0..7 T(k), 8..15 u(k), 16..23 v(k), 24..31 q(k), 32 ps ; G4 variable order is (T,u,v,q) (:499-505)
 __global__ void k_to_fields(const double *__restrict__ g, double *__restrict__ fields)

@@ -30,7 +30,6 @@ namespace {
 constexpr int IX = 96, IY = 24, IL = 48, NX = 32, MX = 31, MX2 = 62, NTRUN = 30, NTRUN1 = 31, NXP = 33, MXP = 31;
 constexpr int SPEC_N = MX2 * NX;   // 1984
 constexpr int GRID_N = IX * IL;    // 4608
-constexpr int FOUR_N = MX2 * IL;   // 2976
 
 struct HostTables {
     double sia[IY], coa[IY], wt[IY], wght[IY], cosg[IL], cosgr[IL], cosgr2[IL];
