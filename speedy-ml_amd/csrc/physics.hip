@@ -12,9 +12,11 @@
 // diabatic forcing and SPPT.  The daily coupler (land / sea-ice models, dmflux) stays with the host: the surface state is an
 // input (sml_phys_set_surface).
 //
-// The work is independent per column: ONE kernel, one thread per column (4608 threads), runs the whole sequence with the
-// column's 8 levels in registers / scratch; per-level arrays are indexed 1..8 as in the Fortran so that the statements can
-// be read side by side.  What the reference keeps in module variables between calls -- the long-wave transmissivities, the
+// The work is independent per column: one thread per column (4608 threads) runs the whole sequence with the column's 8 levels
+// in registers (run-time level indices are predicates in fixed-bound loops) and the long-lived accumulators parked in LDS; per-level
+// arrays are indexed 1..8 as in the Fortran so that the statements can be read side by side.  The device code is in
+// physics_dev.h: this file holds the stand-alone kernel and the C-ABI, dynamics.hip fuses the same column function behind
+// grtend's grid-point tendencies (k_gridtend_physics).  What the reference keeps in module variables between calls -- the long-wave transmissivities, the
 // stratospheric correction, the short-wave heating and surface flux of the last short-wave step (every nstrad-th) -- lives in
 // the handle's device arrays.  Operation order is the reference's (no FMA contraction); exp/sqrt come from the device libm
 // (<= 1-2 ulp from the host's).

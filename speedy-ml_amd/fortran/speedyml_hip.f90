@@ -197,6 +197,51 @@ module speedyml_hip
       real(c_double), value :: delt, alph, rob, wil
       integer(c_int) :: rc
     end function
+    ! ---- SPEEDY column physics (src/phy_phypar.f90 grid-point part), attached to the time step like grtend's phypar call ----
+    function sml_phys_create(hsg9, rlat48, phys) bind(C, name="sml_phys_create") result(rc)
+      import :: c_int, c_double, c_ptr
+      real(c_double), intent(in) :: hsg9(*), rlat48(*)
+      type(c_ptr), intent(out) :: phys
+      integer(c_int) :: rc
+    end function
+    function sml_phys_destroy(phys) bind(C, name="sml_phys_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: phys
+      integer(c_int) :: rc
+    end function
+    ! fmask1, phis0, stl_am, sst_am, soilw_am, alb_l, alb_s, albsfc, snowc: real(ix,il) host arrays
+    function sml_phys_set_surface(phys, fmask, phis0, tland, tsea, swav, alb_l, alb_s, albsfc, snowc) &
+        bind(C, name="sml_phys_set_surface") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: phys
+      real(c_double), intent(in) :: fmask(*), phis0(*), tland(*), tsea(*), swav(*), alb_l(*), alb_s(*), albsfc(*), snowc(*)
+      integer(c_int) :: rc
+    end function
+    function sml_phys_sol_oz(phys, tyear) bind(C, name="sml_phys_sol_oz") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: phys
+      real(c_double), value :: tyear
+      integer(c_int) :: rc
+    end function
+    function sml_phys_diag(phys, which, out_host) bind(C, name="sml_phys_diag") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: phys
+      integer(c_int), value :: which
+      real(c_double), intent(out) :: out_host(*)
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_attach_physics(dyn, phys, nstrad) bind(C, name="sml_dyn_attach_physics") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: dyn, phys
+      integer(c_int), value :: nstrad
+      integer(c_int) :: rc
+    end function
+    function sml_dyn_set_lradsw(dyn, lradsw) bind(C, name="sml_dyn_set_lradsw") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: dyn
+      integer(c_int), value :: lradsw
+      integer(c_int) :: rc
+    end function
   end interface
 
 contains

@@ -216,6 +216,48 @@ program test_driver
   print '(a,es10.3,a,es10.3)', '6-hour window: max|vor| = ', maxval(abs(vor)), '   max|T| = ', maxval(abs(t))
   if (.not. (maxval(abs(vor)) < 1.0e-3_dp .and. maxval(abs(t)) < 1.0e3_dp)) nfail = nfail + 1
 
+  ! ---- the same with the column physics attached (grtend's phypar call): externals vs device-resident window, identical bits ----
+  block
+    real(kind=dp) :: hsg(9), radang(48), sfc(96,48,9), lat
+    integer :: jl, il2
+    hsg = (/0.0_dp, 0.05_dp, 0.14_dp, 0.26_dp, 0.42_dp, 0.60_dp, 0.77_dp, 0.90_dp, 1.0_dp/)
+    do jl = 1, 48
+      radang(jl) = (-87.159_dp + (jl - 1)*(2.0_dp*87.159_dp/47.0_dp))*3.14159265358979_dp/180.0_dp
+    end do
+    call dyn_hip_physics_init(hsg, radang, 3)
+    do jl = 1, 48
+      lat = radang(jl)
+      do il2 = 1, 96
+        sfc(il2,jl,1) = merge(1.0_dp, 0.0_dp, mod(il2/12 + jl/8, 3) == 0)       ! land fraction
+        sfc(il2,jl,2) = 0.0_dp                                                  ! phis0
+        sfc(il2,jl,3) = 288.0_dp - 30.0_dp*sin(lat)**2                          ! land temperature
+        sfc(il2,jl,4) = max(272.0_dp, 300.0_dp - 30.0_dp*sin(lat)**2)           ! sea temperature
+        sfc(il2,jl,5) = 0.5_dp                                                  ! soil wetness
+        sfc(il2,jl,6) = 0.2_dp; sfc(il2,jl,7) = 0.07_dp                         ! land / sea albedo
+        sfc(il2,jl,8) = 0.07_dp + sfc(il2,jl,1)*0.13_dp; sfc(il2,jl,9) = 0.0_dp ! surface albedo, snow cover
+      end do
+    end do
+    call dyn_hip_surface(sfc(:,:,1), sfc(:,:,2), sfc(:,:,3), sfc(:,:,4), sfc(:,:,5), sfc(:,:,6), sfc(:,:,7), sfc(:,:,8), sfc(:,:,9), 0.37_dp)
+    do kk = 1, kx           ! some moisture so that condensation and convection have something to do
+      tr0(1,1,kk,:,1) = cmplx(8.0_dp*fsg(kk)**3*sqrt(2.0_dp), 0.0_dp, kind=dp)
+    end do
+    vor = vor0; div = div0; t = t0; ps = ps0; tr = tr0
+    lradsw = .true.
+    call dyn_hip_window(0)
+    vorA = vor; tA = t; psA = ps
+    vor = vor0; div = div0; t = t0; ps = ps0; tr = tr0
+    lradsw = .true.
+    call stepone
+    errx = maxval(abs(vor - vorA)) + maxval(abs(t - tA)) + maxval(abs(ps - psA))
+    print '(a,es10.3)', 'stepone with column physics: externals vs device-resident window, sum of max|diff| = ', errx
+    if (errx /= 0.0_dp) nfail = nfail + 1
+    vorA = vor; tA = t
+    lradsw = .true.
+    call dyn_hip_window(24)
+    print '(a,es10.3,a,es10.3)', '6-hour window with physics: max|vor| = ', maxval(abs(vor)), '   max|T| = ', maxval(abs(t))
+    if (.not. (maxval(abs(vor)) < 1.0e-3_dp .and. maxval(abs(t)) < 1.0e3_dp)) nfail = nfail + 1
+  end block
+
   if (nfail == 0) then
     print *, 'FORTRAN HOST PARITY OK'
   else
