@@ -195,3 +195,32 @@ def test_split_readout_equals_predict(oracle, variant):
         assert np.max(np.abs(oa - ob)) <= 1e-13 * max(1.0, np.max(np.abs(oa))), (variant, i)
         _, ow = oracle_predict(oracle, r, x0[i], r.stat)
         assert np.max(np.abs(ob - ow)) <= OUT_TOL * max(1.0, np.max(np.abs(ow)))
+
+
+def test_weights_file_roundtrip_to_device(oracle, tmp_path):
+    """The reference's trained-weights file (classic NetCDF, float32 reals: src/mod_reservoir.f90:1727-1736, src/mod_io.f90:2938-2983)
+    written, read back and loaded into the bank: the device predicts with exactly the float32-rounded weights the reference would
+    have after read_trained_res."""
+    from speedy_ml_amd import weights
+    r = make_reservoir(n=1152, d=576, n_model=132, n_out=136, seed=77)
+    path = str(tmp_path / weights.trained_res_filename(954, "trial"))
+    weights.write_trained_res(path, r.win, r.wout, r.rows, r.cols, r.vals, r.mean, r.std)
+    bank = ReservoirBank(1)
+    stat = (np.arange(r.n_out) % 36).astype(np.int32)
+    w = weights.load_trained_res(bank, 0, path, r.n_model, stat)
+    f32 = lambda a: np.asarray(a).astype(np.float32).astype(np.float64)
+    assert np.array_equal(w["win"], f32(r.win)) and np.array_equal(w["wout"], f32(r.wout)) and np.array_equal(w["rows"], r.rows)
+    rng = np.random.default_rng(5)
+    x0 = rng.standard_normal(r.n) * 0.3
+    bank.set_state(0, x0)
+    bank.set_feedback(0, r.feedback)
+    bank.set_local_model(0, r.local_model)
+    bank.predict()
+    torch.cuda.synchronize()
+    x1, out = oracle.predict_raw(r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, f32(r.vals), f32(r.win), f32(r.wout), 1.0, r.feedback,
+                                 r.local_model, x0)
+    out = out * f32(r.std)[stat] + f32(r.mean)[stat]
+    assert np.max(np.abs(bank.get_state(0) - x1)) <= X_TOL
+    assert np.max(np.abs(bank.get_outvec(0) - out)) <= OUT_TOL * np.max(np.abs(out))
+    with pytest.raises(ValueError):
+        weights.load_trained_res(bank, 0, path, r.n_model + 1, stat)          # wout columns must be n + n_model
