@@ -60,6 +60,29 @@ def cpu_baseline(model, budget_s=12.0):
     sample = (f"{n} reference-faithful predict calls (COO SpMV, dense 26.5 MB W_in matmul, W_out GEMV) of one interior "
               f"reservoir: {per_predict * 1e3:.3f} ms each, x1152 per step")
     total = per_predict * NREG
+    # the same predict on every host core at once (one reservoir copy per thread, as every MPI rank of the reference owns its
+    # matrices; ctypes releases the GIL): the aggregate rate prices the all-cores variant of the baseline below
+    import threading
+    ncores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
+    counts = [0] * ncores
+
+    def worker(i):
+        rr = make_reservoir(seed=20240954 + i)
+        xx = np.zeros(rr.n)
+        t_end = time.perf_counter() + 4.0
+        while time.perf_counter() < t_end:
+            xx, _ = o.predict_raw(rr.n, rr.d, rr.n_model, rr.n_out, rr.rows, rr.cols, rr.vals, rr.win, rr.wout, 1.0, rr.feedback,
+                                  rr.local_model, xx)
+            counts[i] += 1
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(ncores)]
+    t1 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    par_rate = sum(counts) / (time.perf_counter() - t1)          # predicts per second, all cores
+    total_par = NREG / par_rate
     if model.mode == "hybrid":
         from _oracle import DynOracle, RefSpectral
         rng = np.random.default_rng(1)
@@ -126,11 +149,15 @@ def cpu_baseline(model, budget_s=12.0):
             else:
                 phys_note = "; column physics NOT priced (oracle/_ref/libref_phy.so absent): the baseline is flattered"
         total += per_tr * 99 + per_step * nst
+        total_par += total - per_predict * NREG                   # the SPEEDY leg is serial in the reference (root rank only)
         sample += (f"; SPEEDY leg: {m} grid+spec pairs with the {which}: {per_pair * 1e6:.0f} us per pair (incl. ctypes overhead); "
                    f"{ns} adiabatic time steps with the oracle: {per_step_oracle * 1e3:.2f} ms each, of which its 123 direct-DFT "
                    f"transforms are re-priced at the reference's transform cost -> {per_step * 1e3:.2f} ms per step, x{nst} steps "
                    f"+ 99 hand-off transforms per hybrid step; exchange tilers not timed (small)" + phys_note)
-    return {"value": 1.0 / total, "unit": "steps/s", "cores": 1, "kind": "port", "sample": sample}
+    sample += (f"; all-cores variant: {ncores} threads predicting concurrently reach {par_rate:.0f} predicts/s in aggregate "
+               f"(W_in is streamed from DRAM), SPEEDY leg serial as in the reference")
+    return {"value": 1.0 / total, "unit": "steps/s", "cores": 1, "kind": "port", "sample": sample,
+            "all_cores": {"value": 1.0 / total_par, "unit": "steps/s", "cores": ncores}}
 
 
 def main():
