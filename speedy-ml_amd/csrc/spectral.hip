@@ -151,7 +151,10 @@ constexpr int TT = 256;
 // synthesis are both independent per latitude), zonal wavenumbers for the forward transform (the DFT is independent
 // per wavenumber and the Legendre analysis only sums over latitude within one wavenumber).  Every workgroup re-reads
 // its field from L2 (16-37 KB); nothing is exchanged between workgroups.
-constexpr int LATG = 4;                 // latitude pairs per workgroup (inverse)
+#ifndef SML_LATG
+#define SML_LATG 4
+#endif
+constexpr int LATG = SML_LATG;          // latitude pairs per workgroup (inverse)
 constexpr int NLG = IY / LATG;          // 6 workgroups per field
 constexpr int MG = 4;                   // zonal wavenumbers per workgroup (forward)
 constexpr int NMG = (MX + MG - 1) / MG; // 8 workgroups per field

@@ -55,6 +55,14 @@ class Physics:
                                              1 if accumulate else 0, vp(stream)))
         return tend
 
+    def tendencies_sfcwind(self, grids, lradsw, tend, off=(0, 8, 16, 24), accumulate=False, want_diag=True, stream=None):
+        """The same from the 27 grids the parametrisations read: ug1(:,kx) vg1(:,kx) tg1(8) qg1(8) phig1(8) pslg1"""
+        assert grids.is_cuda and grids.is_contiguous() and tuple(grids.shape) == (27, 48, 96)
+        assert tend.is_cuda and tend.is_contiguous() and tend.shape[0] >= max(off) + 8
+        check(_lib.lib().sml_phys_tendencies_sfcwind(self._h, dp(grids.data_ptr()), 1 if lradsw else 0, dp(tend.data_ptr()),
+                                                     *[int(o) for o in off], 1 if accumulate else 0, 1 if want_diag else 0, vp(stream)))
+        return tend
+
     def diag(self, name):
         out = np.zeros((48, 96))
         check(_lib.lib().sml_phys_diag(self._h, DIAG[name], dp(out)))

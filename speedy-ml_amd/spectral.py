@@ -73,15 +73,21 @@ class Spectral:
                                                  _lib.ip(kcos_flags.data_ptr()), vp(stream)))
         return out
 
-    def grid_derived(self, base, desc, out=None, stream=None):
+    def grid_derived(self, base, desc, out=None, stream=None, aux=None):
         """Inverse transforms of derived fields in one launch: desc is an int32 device tensor [nf, 4] of
         (type, src0, src1, kcos) rows indexing the fields of `base` ([., 32, 62]); type 0 plain, 1|2 ucos|vcos of
-        uvspec(src0, src1), 3|4 d/dx|d/dy of grad(src0)."""
+        uvspec(src0, src1), 3|4 d/dx|d/dy of grad(src0), 7 geopotential of level src1 from the 8 temperature levels at src0
+        (src/dyn_geop.f90; needs aux = xgeop1(8) | xgeop2(8) | corf(8) | phis(32x62) as one float64 device vector)."""
         self._chk(base, (NX, MX2))
         nf = desc.shape[0]
         assert desc.is_cuda and desc.element_size() == 4 and desc.is_contiguous() and tuple(desc.shape) == (nf, 4)
         out = self._new(base, nf, (IL, IX)) if out is None else out
-        check(_lib.lib().sml_spectral_grid_derived(self._h, dp(base.data_ptr()), _lib.ip(desc.data_ptr()), dp(out.data_ptr()), nf, vp(stream)))
+        if aux is None:
+            check(_lib.lib().sml_spectral_grid_derived(self._h, dp(base.data_ptr()), _lib.ip(desc.data_ptr()), dp(out.data_ptr()), nf, vp(stream)))
+        else:
+            assert aux.is_cuda and aux.element_size() == 8 and aux.is_contiguous() and aux.numel() == 24 + NX * MX2
+            check(_lib.lib().sml_spectral_grid_derived_aux(self._h, dp(base.data_ptr()), _lib.ip(desc.data_ptr()), dp(aux.data_ptr()),
+                                                           dp(out.data_ptr()), nf, vp(stream)))
         return out
 
     def spec_post(self, spec_in, desc, out, stream=None):

@@ -99,6 +99,76 @@ def test_physics_overwrite_mode_gives_the_physics_tendencies_alone():
         assert rel(a, phys_only["sw"][k]) < 1e-9          # (dyn + phys) - dyn == phys up to the rounding of the larger sum
 
 
+def test_sfcwind_entry_equals_full_entry_and_diag_switch():
+    """sml_phys_tendencies_sfcwind reads only the lowest-level winds: same bits as the 41-grid entry; want_diag = 0 leaves the
+    diagnostics of the previous call untouched."""
+    inp = physics_inputs(seed=13)
+    ph = Physics(gaussian_latitudes())
+    g = lambda a: np.asarray(a).reshape(48, 96)
+    ph.set_surface(*[g(inp[k]) for k in ("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc")])
+    ph.sol_oz(TYEAR)
+    grids = np.zeros((41, 4608))
+    for i, k in enumerate(("ug", "vg", "tg", "qg", "phig")):
+        grids[8 * i:8 * i + 8] = inp[k].T
+    grids[40] = inp["pslg"]
+    tend0 = np.concatenate([inp[k].T for k in ("utend", "vtend", "ttend", "qtend")]).reshape(32, 48, 96)
+    full = torch.from_numpy(tend0.copy()).cuda()
+    ph.tendencies(torch.from_numpy(grids.reshape(41, 48, 96)).cuda(), True, full, accumulate=True)
+    olr = ph.diag("olr").copy()
+    g27 = np.concatenate([grids[7:8], grids[15:16], grids[16:41]]).reshape(27, 48, 96)
+    part = torch.from_numpy(tend0.copy()).cuda()
+    ph.tendencies_sfcwind(torch.from_numpy(g27.copy()).cuda(), True, part, accumulate=True, want_diag=True)
+    assert torch.equal(full, part)
+    assert np.array_equal(ph.diag("olr"), olr)
+    # a warmer column set without diagnostics: tendencies change, the stored diagnostics do not
+    g27[2:10] += 2.0
+    ph.tendencies_sfcwind(torch.from_numpy(g27.copy()).cuda(), False, part, accumulate=False, want_diag=False)
+    assert np.array_equal(ph.diag("olr"), olr)
+    ph.tendencies_sfcwind(torch.from_numpy(g27.copy()).cuda(), False, part, accumulate=False, want_diag=True)
+    assert not np.array_equal(ph.diag("olr"), olr)
+    # accumulate = 0 overwrites: no wind tendency above the lowest level
+    assert float(part[0:7].abs().max()) == 0.0 and float(part[8:15].abs().max()) == 0.0 and float(part[7].abs().max()) > 0.0
+
+
+def test_attach_detach_and_shortwave_flag():
+    """sml_dyn_attach_physics / sml_dyn_set_lradsw: detached = the adiabatic step (bit for bit), the short-wave flag changes the step"""
+    from make_physics_golden import coupled_inputs
+    from speedy_ml_amd.dynamics import Dynamics
+    _, st, phis, surf = coupled_inputs(seed=2)
+    got_phys, dyn, ph = device_window(st, phis, surf, 0)
+
+    def one_step(dyn):
+        state = np.zeros((2, 33, 32, 62))
+        for j in range(2):
+            for off, k in ((0, "vor"), (8, "div"), (16, "t"), (24, "tr")):
+                state[j, off:off + 8] = st[k][..., j].transpose(2, 1, 0)
+            state[j, 32] = st["ps"][..., j].T
+        d = torch.from_numpy(state).cuda()
+        dyn.impint(1800.0)
+        dyn.step(d, 2, 2, 1800.0)
+        return d
+
+    dyn.set_lradsw(True)
+    a = one_step(dyn)
+    dyn.set_lradsw(False)
+    b = one_step(dyn)                       # no short-wave call: everything it would have produced was kept from the previous step
+    assert torch.equal(a, b)                # (transmissivities, stratospheric terms, heating, surface flux), so same state -> same bits
+    ph2 = Physics(gaussian_latitudes())     # a handle that never ran the short-wave scheme has nothing to fall back on
+    g = lambda x: np.asarray(x).reshape(48, 96)
+    ph2.set_surface(*[g(surf[k]) for k in ("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc")])
+    ph2.sol_oz(TYEAR)
+    dyn.attach_physics(ph2)
+    dyn.set_lradsw(False)
+    c = one_step(dyn)
+    assert not torch.equal(a, c)
+    dyn.attach_physics(None)
+    dry = one_step(dyn)
+    fresh = Dynamics(dyn.sp)
+    dev2 = lambda x: torch.from_numpy(np.ascontiguousarray(np.asarray(x).T)).cuda()
+    fresh.set_boundary(dev2(phis), dev2(np.zeros((62, 32))), dev2(np.zeros((62, 32))))
+    assert torch.equal(dry, one_step(fresh)) and not torch.equal(dry, a)
+
+
 # ---- the physics inside the time step (src/dyn_grtend.f90:222-225): stepone + leapfrog steps with the parametrisations attached ----
 WTOL = 1e-10        # north_star: fields within 1e-10 relative after the window
 

@@ -203,6 +203,38 @@ def test_grid_derived_equals_separate_operators(sp):
         assert torch.equal(got[f], want[0]), (f, typ)
 
 
+def test_grid_derived_geopotential_matches_geop_then_grid(sp, oracle):
+    """type 7 of sml_spectral_grid_derived_aux: phypar's grid(phi1) with geop (src/dyn_geop.f90:19-35) folded into the staging,
+    against the oracle's geop followed by its grid.  Spectral geopotential is formed with the reference's operation order (bit
+    exact); the transform's DFT sums in another order: 1e-12 of the field's max."""
+    from _oracle import DynOracle
+    from speedy_ml_amd.dynamics import Dynamics
+    do = DynOracle(oracle)
+    dyn = Dynamics(sp)
+    rng = np.random.default_rng(21)
+    mask = np.repeat(oracle.table(11), 2, axis=0)                     # trfilt on (62, 32)
+    t = rng.standard_normal((62, 32, 8)) * mask[..., None]
+    t[0, 0] += 250.0 * np.sqrt(2.0)
+    t[1, :] = 0.0                                                     # zonal means are real
+    phis = rng.standard_normal((62, 32)) * 500.0 * mask
+    phis[1, :] = 0.0
+    want_spec = do.geop(t, phis)                                      # (62, 32, 8)
+    xg1, xg2, hsg, fsg = dyn.table(7), dyn.table(8), dyn.table(1), dyn.table(3)
+    corf = np.zeros(8)
+    for k in range(1, 7):
+        corf[k] = xg1[k] * 0.5 * np.log(hsg[k + 1] / fsg[k]) / np.log(fsg[k + 1] / fsg[k - 1])
+    aux = torch.from_numpy(np.concatenate([xg1, xg2, corf, phis.T.ravel()])).cuda()
+    base = torch.from_numpy(np.ascontiguousarray(t.transpose(2, 1, 0))).cuda()        # [8][32][62]
+    desc = torch.tensor([(7, 0, k, 1) for k in range(8)], dtype=torch.int32, device="cuda")
+    got = sp.grid_derived(base, desc, aux=aux).cpu().numpy()
+    for k in range(8):
+        want = oracle.grid(want_spec[..., k], 1).T
+        assert np.max(np.abs(got[k] - want)) <= 1e-12 * np.max(np.abs(want)), k
+    # the spectral geopotential itself, bit for bit: transform back is not needed -- level 7 has no correction and a single term
+    back = sp.spec(torch.from_numpy(got[7:8].copy()).cuda()).cpu().numpy()[0].T
+    assert np.max(np.abs(back - want_spec[..., 7] * mask)) <= 1e-11 * np.max(np.abs(want_spec[..., 7]))
+
+
 def test_spec_post_equals_separate_operators(sp):
     """vds + trunct by descriptor give the same bits as vds followed by trunct."""
     rng = np.random.default_rng(12)
