@@ -78,6 +78,11 @@ int sml_domain_sizes(const sml_region *g, int m, int deg, int local_predictvars,
 /* getsend_receive_size_{res,speedy,input,res_slab,input_slab} (src/mpires.f90:806-925) -> sizes5[0..4] */
 int sml_domain_message_sizes(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
                              int vert_overlap, int precip_bool, int ohtc_bool_input, int32_t *sizes5);
+/* tile_full_input_to_target_data (src/res_domain.f90:602-689) as an index map: 0-based positions in the region's input
+ * vector u(t) of the entries that form its target vector (chunk_size_prediction of them: (var,x,y,z) of the res patch, var
+ * fastest, then logp, then precip when predicted).  Returns the count. */
+int sml_domain_target_map(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
+                          int vert_overlap, int precip_bool, int32_t *in_pos, int capacity);
 /* find_closest_divisor (src/mod_utilities.f90:1598-1636); returns the divisor (>0) or <0 on bad arguments */
 int sml_find_closest_divisor(int target, int number);
 

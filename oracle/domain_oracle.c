@@ -296,6 +296,30 @@ void rd_tile_res(int num_regions, int num_vert_levels, int region_num, int vert_
 }
 
 /* standardize_data_given_pars*: subtract, then divide (src/mod_utilities.f90:1283-1329) */
+/* tile_full_input_to_target_data2d (src/res_domain.f90:602-689): statevec(reservoir_numinputs, T) column-major ->
+ * tiled(chunk_size_prediction, T).  The reshape/slice/reshape of the Fortran is spelt out element by element in column-major
+ * order: temp5d(var, x, y, z, t) = statevec(var + nv*((x-1) + nxi*((y-1) + nyi*(z-1))), t). */
+void rd_tile_target(const rd_grid *g, const rd_sizes *s, int local_predictvars, int logp_bool, int precip_bool,
+                    const double *statevec, int ld_in, int T, double *tiled, int ld_out)
+{
+    const int nv = local_predictvars, nxi = g->inputxchunk, nyi = g->inputychunk;
+    for (int t = 0; t < T; ++t) {
+        const double *u = statevec + (size_t)t * ld_in;
+        double *o = tiled + (size_t)t * ld_out;
+        int q = 0;
+        for (int z = g->tdata_zstart; z <= g->tdata_zend; ++z)
+            for (int y = g->tdata_ystart; y <= g->tdata_yend; ++y)
+                for (int x = g->tdata_xstart; x <= g->tdata_xend; ++x)
+                    for (int v = 1; v <= nv; ++v) o[q++] = u[(v - 1) + nv * ((x - 1) + nxi * ((y - 1) + nyi * (z - 1)))];
+        if (logp_bool)              /* :624-627: temp3d = reshape(statevec(logp_start:logp_end,:)) */
+            for (int y = g->tdata_ystart; y <= g->tdata_yend; ++y)
+                for (int x = g->tdata_xstart; x <= g->tdata_xend; ++x) o[q++] = u[(s->logp_start - 1) + (x - 1) + nxi * (y - 1)];
+        if (precip_bool)            /* :641-647 */
+            for (int y = g->tdata_ystart; y <= g->tdata_yend; ++y)
+                for (int x = g->tdata_xstart; x <= g->tdata_xend; ++x) o[q++] = u[(s->precip_start - 1) + (x - 1) + nxi * (y - 1)];
+    }
+}
+
 static inline double stdz(double v, double mean, double std) { double t = v - mean; return t / std; }
 /* unstandardize_data_*: multiply, then add as two statements (src/mod_utilities.f90:667-831) */
 static inline double unstdz(double v, double mean, double std) { double t = v * std; return t + mean; }

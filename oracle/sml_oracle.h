@@ -103,6 +103,8 @@ void rd_tile_input(int num_regions, int region_num, int overlap, int num_vert_le
 void rd_tile_input2d(int num_regions, int region_num, int overlap, const double *grid2d, double *out); /* tileoverlapgrid2d */
 void rd_scatter_res(int num_regions, int num_vert_levels, int region_num, int vert_level, int precip_bool, int length,
                     const double *statevec, double *grid4d, double *grid2d, double *precip);  /* tile_full_grid_with_local_state_vec_res1d :791-826 */
+void rd_tile_target(const rd_grid *g, const rd_sizes *s, int local_predictvars, int logp_bool, int precip_bool,
+                    const double *statevec, int ld_in, int T, double *tiled, int ld_out);                  /* :602-689 */
 void rd_tile_res(int num_regions, int num_vert_levels, int region_num, int vert_level,
                  const double *grid4d, const double *grid2d, double *statevec);  /* tile_4d_and_logp_full_grid_to_local_res_vec :1022-1053 */
 void rd_standardize_input(const rd_grid *g, const rd_sizes *s, int local_predictvars, int logp_bool,

@@ -248,6 +248,33 @@ int sml_domain_in_map(int number_of_regions, int region_num, int overlap, int nu
     return q;
 }
 
+// tile_full_input_to_target_data (src/res_domain.f90:602-689): which entries of the region's INPUT vector u(t) form its TARGET
+// vector (the res patch inside the input patch: tdata_x/y/zstart..end), as 0-based positions: (var, x, y, z) var fastest, then
+// logp(x, y), then precip(x, y) when predicted.  Training targets are trainingdata(in_pos(:), columns).
+int sml_domain_target_map(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
+                          int vert_overlap, int precip_bool, int32_t *in_pos, int capacity)
+{
+    Patch p; Vert v;
+    SML_REQUIRE(in_pos, "sml_domain_target_map: null output");
+    SML_REQUIRE(patch(number_of_regions, region_num, overlap, p), "sml_domain_target_map: bad region");
+    SML_REQUIRE(vert(num_vert_levels, vert_level, vert_overlap, v), "sml_domain_target_map: bad level");
+    const int in2d = p.ixc * p.iyc, res2d = p.rxc * p.ryc;
+    const int count = NV * res2d * v.rzc + (v.bottom ? res2d * (1 + (precip_bool ? 1 : 0)) : 0);
+    SML_REQUIRE(capacity >= count, "sml_domain_target_map: capacity %d < %d", capacity, count);
+    int q = 0;
+    for (int z = v.tdzs; z <= v.tdze; ++z)
+        for (int y = p.tdys; y <= p.tdye; ++y)
+            for (int x = p.tdxs; x <= p.tdxe; ++x)
+                for (int var = 1; var <= NV; ++var) in_pos[q++] = (var - 1) + NV * ((x - 1) + p.ixc * ((y - 1) + p.iyc * (z - 1)));
+    if (v.bottom) {
+        const int logp0 = NV * in2d * v.izc;                       // logp_start - 1 (src/mod_reservoir.f90:1859-1885)
+        for (int plane = 0; plane < 1 + (precip_bool ? 1 : 0); ++plane)
+            for (int y = p.tdys; y <= p.tdye; ++y)
+                for (int x = p.tdxs; x <= p.tdxe; ++x) in_pos[q++] = logp0 + plane * in2d + (x - 1) + p.ixc * (y - 1);
+    }
+    return q;
+}
+
 // getsend_receive_size_{res,speedy,input,res_slab,input_slab} (src/mpires.f90:806-925): lengths of the per-region vectors
 // the reference ships between ranks; here they size the outvec / local_model / feedback slabs.
 int sml_domain_message_sizes(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,

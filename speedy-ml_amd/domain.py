@@ -55,6 +55,21 @@ def in_map(num_regions, region_num, overlap=1, num_vert_levels=1, vert_level=1, 
     return gi[:n].copy(), si[:n].copy()
 
 
+def target_map(num_regions, region_num, overlap=1, num_vert_levels=1, vert_level=1, vert_overlap=0, precip_bool=True):
+    """tile_full_input_to_target_data (src/res_domain.f90:602-689) as 0-based positions into the region's input vector:
+    targets = trainingdata[target_map, :]."""
+    cap = 8 * XGRID * YGRID * ZGRID
+    pos = np.zeros(cap, dtype=np.int32)
+    n = check(_lib.lib().sml_domain_target_map(int(num_regions), int(region_num), overlap, num_vert_levels, vert_level, vert_overlap,
+                                               int(precip_bool), ip(pos), cap))
+    return pos[:n].copy()
+
+
+def find_closest_divisor(target, number):
+    """find_closest_divisor (src/mod_utilities.f90:1598-1636)"""
+    return check(_lib.lib().sml_find_closest_divisor(int(target), int(number)))
+
+
 def calendar_date(hours_elapsed, startyear=1981):
     """get_current_time_delta_hour (src/mod_calendar.f90:24-91): (year, month, day, hour)."""
     out = np.zeros(4, dtype=np.int32)

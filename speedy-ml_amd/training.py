@@ -1,0 +1,105 @@
+"""train_reservoir (src/mod_reservoir.f90:214-320) for the reservoirs resident in a bank: the orchestration around the device kernels.
+
+    gen_res / W_in                         -> done by the caller (speedy_ml_amd.reservoir.gen_res, make_win) and loaded into the bank
+    initialize_chunk_training (:1561-1592) -> chunk_batch_size(): 20 batches, find_closest_divisor
+    do i = 1, timestep                     -> `timestep` interleaved passes over the columns i, i+timestep, ... of the hourly data
+      reservoir_layer_chunking_hybrid (:1067-1175)  -> ReservoirBank.train_pass (recurrence + MFMA Gram updates on the device)
+        gaussian_noise_1d_function[_precip] (src/mod_utilities.f90:1387-1462) -> add_input_noise() (the normal deviates are an input:
+                                              the reference's RANDOM_NUMBER stream cannot be reproduced)
+        chunking_matmul (:1645-1701): targets = tile_full_input_to_target_data(trainingdata) -> domain.target_map rows
+    fit_chunk_hybrid (:1235-1334)          -> train.fit_chunk_hybrid (LU on the device)
+    write_trained_res (:1703-1737)         -> weights.write_trained_res
+
+All reservoirs of the bank advance together (one launch per time column); passes and batches follow the reference's index
+arithmetic, so the accumulated matrices equal the reference's up to the order of the floating-point sums inside the GEMM."""
+import numpy as np
+
+from . import domain, train
+
+NUM_OF_BATCHES = 20          # src/mod_reservoir.f90:1570
+
+
+def chunk_batch_size(traininglength, discardlength, timestep):
+    """initialize_chunk_training (src/mod_reservoir.f90:1570-1576)"""
+    approx = (traininglength - discardlength) // (NUM_OF_BATCHES * timestep)
+    return domain.find_closest_divisor(approx, (traininglength - discardlength) // timestep)
+
+
+def make_win(n, numinputs, sigma, uniform):
+    """W_in as train_reservoir builds it (src/mod_reservoir.f90:262-283): q = n / numinputs nodes per input, column i holds
+    sigma * (-1 + 2 * rand) in rows (i-1) q + 1 .. i q.  uniform: (numinputs, q) U(0,1) numbers (row i = the i-th random_number call)."""
+    q = n // numinputs
+    uniform = np.asarray(uniform, dtype=np.float64)
+    assert uniform.shape == (numinputs, q)
+    win = np.zeros((n, numinputs), order="F")
+    for i in range(numinputs):
+        win[i * q:(i + 1) * q, i] = sigma * (-1.0 + 2.0 * uniform[i])
+    return win
+
+
+def add_input_noise(inputdata, gauss, noisemag, precip_slice=None, precip_mean=0.0, precip_std=1.0, precip_epsilon=0.001):
+    """gaussian_noise_1d_function (src/mod_utilities.f90:1387-1409): x + g * noisemag * x, column by column; with precip_slice =
+    (precip_start - 1, precip_end) the precipitation entries get their noise in physical space as gaussian_noise_1d_function_precip
+    does (:1411-1462): un-standardise, invert log(1 + p / eps), perturb, abs, transform back.  inputdata, gauss: (d, T)."""
+    x, g = np.asarray(inputdata, dtype=np.float64), np.asarray(gauss, dtype=np.float64)
+    out = x + g * noisemag * x
+    if precip_slice is not None:
+        a, b = precip_slice
+        t = x[a:b] * precip_std + precip_mean
+        t = precip_epsilon * (np.e ** t - 1.0)
+        t = t + g[a:b] * noisemag * t
+        t = np.abs(t)
+        t = np.log(1.0 + t / precip_epsilon)
+        t = t - precip_mean
+        out[a:b] = t / precip_std
+    return out
+
+
+def train_reservoirs(bank, specs, traininglength, discardlength, timestep, beta_res=0.001, beta_model=1.0, prior_val=0.0,
+                     using_prior=True, ml_only=False, stream=None):
+    """specs: one dict per slot to train (others None): n, n_model, n_out, trainingdata (d, traininglength) already noisy where the
+    reference adds noise (see add_input_noise; the clean copy provides the targets), clean (d, traininglength) or None (= same),
+    imperfect_model (n_model, traininglength) or None when ml_only, target_rows (0-based rows of the input vector: domain.target_map).
+    Runs the `timestep` interleaved passes, accumulates C and B on the device, solves for W_out, stores it in the bank and returns
+    {slot: dict(wout=(n_out, n_aug) Fortran-ordered host array, batch_size, batches)}."""
+    import torch
+    assert traininglength % timestep == 0 and discardlength % timestep == 0
+    batch = chunk_batch_size(traininglength, discardlength, timestep)
+    discard = discardlength // timestep
+    cols = traininglength // timestep
+    cap, maxd = bank.capacity, bank.max_d
+    cs, bs = [None] * cap, [None] * cap
+    for slot, sp in enumerate(specs):
+        if sp is None:
+            continue
+        n_aug = sp["n"] + (0 if ml_only else sp["n_model"])
+        cs[slot] = train.fortran_zeros(n_aug, n_aug)
+        bs[slot] = train.fortran_zeros(sp["n_out"], n_aug)
+    nb_total = 0
+    for i in range(timestep):                                    # trainingdata(:, i:traininglength:timestep)
+        noisy = np.zeros((cols, cap, maxd))
+        models, targets = [None] * cap, [None] * cap
+        for slot, sp in enumerate(specs):
+            if sp is None:
+                continue
+            td = np.asarray(sp["trainingdata"])[:, i::timestep]
+            clean = td if sp.get("clean") is None else np.asarray(sp["clean"])[:, i::timestep]
+            noisy[:, slot, :td.shape[0]] = td.T
+            # chunking_matmul: the targets of batch b are the clean columns discard + (b-1) m + 1 .. discard + b m, i.e. column for
+            # column the input that the state was driven TOWARDS; train_pass indexes them from the start of the pass
+            targets[slot] = torch.from_numpy(np.ascontiguousarray(clean[sp["target_rows"], :].T)).cuda()      # column-major (n_out, T)
+            if not ml_only:
+                models[slot] = torch.from_numpy(np.ascontiguousarray(np.asarray(sp["imperfect_model"])[:, i::timestep].T)).cuda()
+        nb = bank.train_pass(torch.from_numpy(noisy).cuda(), discard, batch, models, targets, cs, bs, stream=stream, ml_variant=ml_only)
+        nb_total += nb
+    out = {}
+    for slot, sp in enumerate(specs):
+        if sp is None:
+            continue
+        wout = train.fit_chunk_hybrid(cs[slot], bs[slot], sp["n"], 0 if ml_only else sp["n_model"], sp["n_out"], beta_res, beta_model,
+                                      prior_val, using_prior, stream=stream)
+        torch.cuda.synchronize()
+        host = np.asfortranarray(wout.cpu().numpy().T)          # device buffer is column-major (n_out, n_aug) = torch [n_aug, n_out]
+        bank.set_wout(slot, host)
+        out[slot] = dict(wout=host, batch_size=batch, batches=nb_total // timestep)
+    return out

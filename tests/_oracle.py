@@ -30,10 +30,12 @@ TABLES = {  # which -> (name, shape in Fortran order)
 
 
 def _p(a):
+    assert a.dtype == np.float64 and (a.flags.c_contiguous or a.flags.f_contiguous), "oracle call with a strided or non-float64 array"
     return a.ctypes.data_as(_dp)
 
 
 def _pi(a):
+    assert a.dtype == np.int32 and (a.flags.c_contiguous or a.flags.f_contiguous), "oracle call with a strided or non-int32 array"
     return a.ctypes.data_as(_ip)
 
 
@@ -197,6 +199,13 @@ class Oracle:
     def scatter_res(self, num_regions, region, statevec, grid4d, grid2d, precip, nvl=1, vl=1, precip_bool=1):
         sv = np.ascontiguousarray(statevec, dtype=np.float64)
         self.lib.rd_scatter_res(num_regions, nvl, region, vl, precip_bool, sv.size, _p(sv), _p(grid4d), _p(grid2d), _p(precip))
+
+    def tile_target(self, g, s, statevec, nout, local_predictvars=4, logp=1, precip=1):
+        """tile_full_input_to_target_data2d: statevec (numinputs, T) -> (chunk_size_prediction, T)"""
+        sv = np.asfortranarray(statevec, dtype=np.float64)
+        out = np.zeros((nout, sv.shape[1]), order="F")
+        self.lib.rd_tile_target(C.byref(g), C.byref(s), local_predictvars, logp, precip, _p(sv), sv.shape[0], sv.shape[1], _p(out), nout)
+        return out
 
     def tile_res(self, num_regions, region, grid4d, grid2d, nout, nvl=1, vl=1):
         out = np.zeros(nout)

@@ -147,3 +147,27 @@ def test_slab_sizes_match_survey():
     assert (s.atmo3d_start, s.atmo3d_end, s.logp_start, s.logp_end, s.sst_start, s.sst_end, s.tisr_start, s.tisr_end) == (1, 64, 65, 80, 81, 96, 97, 112)
     p = slab_sizes(domain.initializedomain(1152, 0))          # polar region: 4 x 3 input patch
     assert (p.reservoir_numinputs, p.nodes_per_input, p.n, p.chunk_size_prediction) == (96, 42, 4032, 8)
+
+
+@pytest.mark.parametrize("region", [0, 1, 23, 24, 954, 1127, 1151])
+def test_target_map_matches_oracle_tiler(oracle, region):
+    """tile_full_input_to_target_data (src/res_domain.f90:602-689): the product's index map applied to an index-tagged input vector
+    gives what the oracle's restatement of the reshape/slice/reshape gives; polar, x-periodic and interior regions."""
+    g = oracle.initializedomain(1152, region)
+    s = oracle.allocate_sizes(g)
+    rng = np.random.default_rng(region)
+    u = np.asfortranarray(np.arange(s.reservoir_numinputs * 3, dtype=np.float64).reshape(3, -1).T + rng.random((s.reservoir_numinputs, 3)))
+    want = oracle.tile_target(g, s, u, s.chunk_size_prediction)
+    rows = domain.target_map(1152, region)
+    assert rows.size == s.chunk_size_prediction == 136
+    assert np.array_equal(u[rows, :], want)
+    assert len(set(rows.tolist())) == rows.size and rows.max() < s.precip_end
+    if region == 0:
+        # SURVEY Appendix A (run of the reference): region 0 trains on tdata x 2-3, y 1-2 of its 4 x 3 input patch
+        nx = g.inputxchunk
+        first_level = rows[:16].reshape(2, 2, 4)           # (y, x, var)
+        xs = (first_level[..., 0] // 4) % nx + 1
+        ys = (first_level[..., 0] // 4) // nx % g.inputychunk + 1
+        assert sorted(set(xs.ravel().tolist())) == [2, 3] and sorted(set(ys.ravel().tolist())) == [1, 2]
+    # without precipitation the target vector stops after logp
+    assert domain.target_map(1152, region, precip_bool=False).size == 132
