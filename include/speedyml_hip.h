@@ -371,6 +371,9 @@ int sml_dyn_window(sml_dyn *dyn, double *state_dev, int start, int nsteps, doubl
  * sml_dyn_step / sml_dyn_grtend calls and a window's stepone use (the module variable lradsw, src/mod_lflags.f90:22). */
 int sml_dyn_attach_physics(sml_dyn *dyn, sml_phys *phys, int nstrad);
 int sml_dyn_set_lradsw(sml_dyn *dyn, int lradsw);
+/* how a time step runs grtend's grid-point part with physics attached: 1 = one fused launch (default), 0 = the grid-point
+ * dynamics and sml_phys_tendencies_sfcwind as two launches (same arithmetic; kept so that tests can compare the two) */
+int sml_dyn_select_physics_form(int fused);
 /* how sml_dyn_window runs a time step: 0 = four launches over whole fields (default), 1 = two kernels (zonal-wavenumber
  * space <-> latitude space; bit-identical results, measured slower on MI355X, see csrc/dynamics.hip), -1 = default /
  * environment SML_DYN_TWO_KERNEL */

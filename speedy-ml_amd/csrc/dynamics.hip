@@ -349,89 +349,119 @@ __global__ __launch_bounds__(64) void k_gridtend(DevHoriz H, LevelTables L, cons
     }
 }
 
-// k_gridtend_physics: k_gridtend followed, in the same thread, by the column physics (dyn_grtend.f90:222-225: phypar adds its
-// tendencies to utend, vtend, ttend, trtend before the forward transforms).  Both are one-thread-per-column kernels of 72
-// workgroups, so fusing them costs nothing in parallelism and saves one launch (>= 4.7 us on this part) and the round trip of
-// ttend, qtend, utend(kx), vtend(kx) through memory: the dynamical tendencies go straight into the physics' accumulators.
+// k_gridtend_physics: grtend's grid-point part (dyn_grtend.f90:80-216) and phypar (:222-225, phy_phypar.f90:80-230) in ONE launch
+// of 72 workgroups x 2 wavefronts for 64 columns each:
+//   wave 0: the dynamical tendencies (k_gridtend's body; ttend, qtend, utend(kx), vtend(kx) go straight into the physics'
+//           accumulators, no trip through memory), convection and condensation, vertical diffusion, the final sums and stores;
+//   wave 1: clouds, short- and long-wave radiation, surface fluxes.
+// The two chains meet once, through the LDS park (smlphys::P_*): the final sums need the heating rates and surface fluxes of wave 1
+// (one barrier).  On short-wave steps cloud() needs the precipitation and the convection top, which wave 1 re-derives.  Every
+// sum keeps the reference's order (see physics_dev.h), so the result equals the one-wave sequence bit for bit
+// (sml_dyn_select_physics_form(0) runs that for comparison).  One wave for both chains took 19.9 us per launch.
 // PG: the grids of time level 1 the parametrisations read (smlphys::PhysIn).
-__global__ __launch_bounds__(64) void k_gridtend_physics(DevHoriz H, LevelTables L, const double *__restrict__ G, double *__restrict__ O,
-                                                          smlphys::PhysLev PL, smlphys::PhysDev PD, smlphys::PhysIn PG, int lradsw, int want_diag)
+__global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTables L, const double *__restrict__ G, double *__restrict__ O,
+                                                           smlphys::PhysLev PL, smlphys::PhysDev PD, smlphys::PhysIn PG, int lradsw, int want_diag)
 {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= GR) return;
-    const int j = p / IX;
     __shared__ double park[smlphys::PARK_DOUBLES];
-    smlphys::LA tt{park + threadIdx.x}, qt{park + smlphys::NLP * 64 + threadIdx.x};      // 1-based level arrays of the physics
-    double ug[KX], vg[KX], tg[KX], vorg[KX], divg[KX], trg[KX], puv[KX], sigdt[KXP], sigm[KXP];
-    const double cor = H.coriol[j];
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        vorg[k] = G[(size_t)(F_VOR + k) * GR + p] + cor;
-        divg[k] = G[(size_t)(F_DIV + k) * GR + p];
-        tg[k] = G[(size_t)(F_T + k) * GR + p];
-        trg[k] = G[(size_t)(F_TR + k) * GR + p];
-        ug[k] = G[(size_t)(32 + k) * GR + p];
-        vg[k] = G[(size_t)(40 + k) * GR + p];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // uniform: the two chains are scalar branches
+    const int p = blockIdx.x * 64 + lane;                                     // the grid is exactly GR / 64 workgroups
+    if (wave == 0) {
+        const int j = p / IX;
+        smlphys::LA tt = smlphys::park_array(park, smlphys::P_TT, lane), qt = smlphys::park_array(park, smlphys::P_QT, lane);   // 1-based levels
+        double ug[KX], vg[KX], tg[KX], vorg[KX], divg[KX], trg[KX], puv[KX], sigdt[KXP], sigm[KXP];
+        const double cor = H.coriol[j];
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            vorg[k] = G[(size_t)(F_VOR + k) * GR + p] + cor;
+            divg[k] = G[(size_t)(F_DIV + k) * GR + p];
+            tg[k] = G[(size_t)(F_T + k) * GR + p];
+            trg[k] = G[(size_t)(F_TR + k) * GR + p];
+            ug[k] = G[(size_t)(32 + k) * GR + p];
+            vg[k] = G[(size_t)(40 + k) * GR + p];
+        }
+        double px = G[(size_t)48 * GR + p], py = G[(size_t)49 * GR + p];
+        double umean = 0.0, vmean = 0.0, dmean = 0.0;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            umean = umean + ug[k] * L.dhs[k];
+            vmean = vmean + vg[k] * L.dhs[k];
+            dmean = dmean + divg[k] * L.dhs[k];
+        }
+        O[(size_t)72 * GR + p] = -umean * px - vmean * py;
+        sigdt[0] = 0.0; sigm[0] = 0.0;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {          // the reference's loop runs to kx and so overwrites the zero it put at kxp
+            sigdt[k + 1] = sigdt[k] - L.dhs[k] * (puv[k] + divg[k] - dmean);
+            sigm[k + 1] = sigm[k] - L.dhs[k] * puv[k];
+        }
+        double tgg[KX];
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - L.tref[k];
+        px = RGAS * px;
+        py = RGAS * py;
+        double tmp[KXP];
+        tmp[0] = 0.0; tmp[KX] = 0.0;
+        // zonal wind
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX - 1; ++k) O[(size_t)k * GR + p] = vg[k] * vorg[k] - tgg[k] * px - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        const double u_dyn = vg[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * px - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
+        // meridional wind
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX - 1; ++k) O[(size_t)(8 + k) * GR + p] = -ug[k] * vorg[k] - tgg[k] * py - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        const double v_dyn = -ug[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * py - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
+        // temperature
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (L.tref[k] - L.tref[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX; ++k)
+            tt[k + 1] = tgg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k] + L.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k])
+                                           + L.tref3[k] * (sigm[k + 1] + sigm[k]) + L.akap * (tg[k] * puv[k] - tgg[k] * dmean);
+        // tracer (specific humidity): no vertical advection across the two uppermost interfaces (:196-203)
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
+        tmp[1] = 0.; tmp[2] = 0.;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) qt[k + 1] = trg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        // flux products (:241-246, :262-267)
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            O[(size_t)(48 + k) * GR + p] = 0.5 * (ug[k] * ug[k] + vg[k] * vg[k]);
+            O[(size_t)(16 + k) * GR + p] = -ug[k] * tgg[k];
+            O[(size_t)(24 + k) * GR + p] = -vg[k] * tgg[k];
+            O[(size_t)(32 + k) * GR + p] = -ug[k] * trg[k];
+            O[(size_t)(40 + k) * GR + p] = -vg[k] * trg[k];
+        }
+            smlphys::Column c;
+        smlphys::column_state(PL, PG, p, c);
+        int iptop, icnv;
+        double precnv, precls;
+        smlphys::chain_moist(PL, PD, c, p, want_diag, park, lane, iptop, icnv, precnv, precls);
+        double pt[smlphys::NLP], pq[smlphys::NLP];
+        smlphys::vdifsc(PL, c, icnv, pt, pq);
+        __syncthreads();                                                      // the radiation chain has left its results in the park
+        smlphys::chain_pbl_and_store(PL, c, p, icnv, park, lane, O, 0, 8, 56, 64, u_dyn, v_dyn, pt, pq);
+    } else {
+        smlphys::Column c;
+        smlphys::column_state(PL, PG, p, c);
+        double precnv = 0., precls = 0.;
+        int iptop = 0;
+        if (lradsw) {
+            // cloud() needs the precipitation and the convection top: this wave evaluates convmf / lscond for itself (same inputs,
+            // same code, same bits) instead of waiting 7 us for wave 0 to get there behind the grid-point dynamics
+            double cbmf, s1[smlphys::NLP], s2[smlphys::NLP];
+            smlphys::convmf(PL, c, iptop, cbmf, precnv, s1, s2);
+            smlphys::lscond(PL, c, iptop, precls, s1, s2);
+        }
+        smlphys::chain_radiation(PL, PD, c, p, lradsw, want_diag, park, lane, precnv, precls, iptop);
+        __syncthreads();
     }
-    double px = G[(size_t)48 * GR + p], py = G[(size_t)49 * GR + p];
-    double umean = 0.0, vmean = 0.0, dmean = 0.0;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        umean = umean + ug[k] * L.dhs[k];
-        vmean = vmean + vg[k] * L.dhs[k];
-        dmean = dmean + divg[k] * L.dhs[k];
-    }
-    O[(size_t)72 * GR + p] = -umean * px - vmean * py;
-    sigdt[0] = 0.0; sigm[0] = 0.0;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {          // the reference's loop runs to kx and so overwrites the zero it put at kxp
-        sigdt[k + 1] = sigdt[k] - L.dhs[k] * (puv[k] + divg[k] - dmean);
-        sigm[k + 1] = sigm[k] - L.dhs[k] * puv[k];
-    }
-    double tgg[KX];
-#pragma unroll
-    for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - L.tref[k];
-    px = RGAS * px;
-    py = RGAS * py;
-    double tmp[KXP];
-    tmp[0] = 0.0; tmp[KX] = 0.0;
-    // zonal wind
-#pragma unroll
-    for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
-#pragma unroll
-    for (int k = 0; k < KX - 1; ++k) O[(size_t)k * GR + p] = vg[k] * vorg[k] - tgg[k] * px - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-    const double u_dyn = vg[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * px - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
-    // meridional wind
-#pragma unroll
-    for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
-#pragma unroll
-    for (int k = 0; k < KX - 1; ++k) O[(size_t)(8 + k) * GR + p] = -ug[k] * vorg[k] - tgg[k] * py - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-    const double v_dyn = -ug[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * py - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
-    // temperature
-#pragma unroll
-    for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (L.tref[k] - L.tref[k - 1]);
-#pragma unroll
-    for (int k = 0; k < KX; ++k)
-        tt[k + 1] = tgg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k] + L.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k])
-                                       + L.tref3[k] * (sigm[k + 1] + sigm[k]) + L.akap * (tg[k] * puv[k] - tgg[k] * dmean);
-    // tracer (specific humidity): no vertical advection across the two uppermost interfaces (:196-203)
-#pragma unroll
-    for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
-    tmp[1] = 0.; tmp[2] = 0.;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) qt[k + 1] = trg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-    // flux products (:241-246, :262-267)
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        O[(size_t)(48 + k) * GR + p] = 0.5 * (ug[k] * ug[k] + vg[k] * vg[k]);
-        O[(size_t)(16 + k) * GR + p] = -ug[k] * tgg[k];
-        O[(size_t)(24 + k) * GR + p] = -vg[k] * tgg[k];
-        O[(size_t)(32 + k) * GR + p] = -ug[k] * trg[k];
-        O[(size_t)(40 + k) * GR + p] = -vg[k] * trg[k];
-    }
-    smlphys::physics_column(PL, PD, PG, O, lradsw, 0, 8, 56, 64, want_diag, p, park, u_dyn, v_dyn);
 }
 
 struct StepArgs {
@@ -1120,6 +1150,8 @@ int fetch_table(sml_dyn *d, int which, const double **dst, std::vector<double> &
     return dst ? upload(d, dst, tmp.data(), n) : SML_OK;
 }
 
+int g_physics_fused = 1;     // sml_dyn_select_physics_form
+
 int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend, double *tend_out, hipStream_t st, int lradsw = 1)
 {
     const double *sj2 = state + (size_t)(a.j2 - 1) * NSTATE * SP;
@@ -1129,15 +1161,19 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
     int rc = d->phys ? sml_spectral_grid_derived_aux(d->sp, state, d->desc_phys + (size_t)(a.j2 - 1) * NB_ALL * 4, d->aux, d->batch_grid, NB_ALL, st)
                      : sml_spectral_grid_derived(d->sp, sj2, d->desc, d->batch_grid, NB_SPEC, st);
     if (rc) return rc;
-    if (d->phys) {      // dyn_grtend.f90:80-225 in one launch: grid-point tendencies + phypar
+    if (d->phys && g_physics_fused) {      // dyn_grtend.f90:80-225 in one launch: grid-point tendencies + phypar
         const double *pg = d->batch_grid + (size_t)NB_SPEC * GR;
         smlphys::PhysIn in{pg, pg + (size_t)GR, pg + (size_t)2 * GR, pg + (size_t)10 * GR, pg + (size_t)18 * GR, pg + (size_t)26 * GR};
-        hipLaunchKernelGGL(k_gridtend_physics, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
+        hipLaunchKernelGGL(k_gridtend_physics, dim3(GR / 64), dim3(128), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
                            d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag);
     } else {
         hipLaunchKernelGGL(k_gridtend, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid);
     }
     SML_HIP(hipGetLastError());
+    if (d->phys && !g_physics_fused) {     // the same as two launches (sml_dyn_select_physics_form(0)): tests compare the two forms
+        rc = sml_phys_tendencies_sfcwind(d->phys, d->batch_grid + (size_t)NB_SPEC * GR, lradsw, d->tend_grid, 0, 8, 56, 64, 1, d->phys_diag, st);
+        if (rc) return rc;
+    }
     rc = sml_spectral_spec_mixed(d->sp, d->tend_grid, d->tend_spec, NB_GRID, d->scale, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_spectral<true>, dim3(SP / 8), dim3(64), 0, st, d->d, d->cur->lv, a, d->tend_spec, (const double *)nullptr,
@@ -1458,6 +1494,12 @@ int sml_dyn_set_lradsw(sml_dyn *d, int lradsw)
 {
     SML_REQUIRE(d, "sml_dyn_set_lradsw: null handle");
     d->lradsw = lradsw ? 1 : 0;
+    return SML_OK;
+}
+
+int sml_dyn_select_physics_form(int fused)
+{
+    g_physics_fused = fused ? 1 : 0;
     return SML_OK;
 }
 

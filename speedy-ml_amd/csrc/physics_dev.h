@@ -657,18 +657,23 @@ struct PhysIn { const double *usfc, *vsfc, *t, *q, *phi, *ps; };
 // utenvd = vtenvd = 0; only the surface stress acts), so with accumulate the upper 7 levels of utend, vtend are not touched.
 // want_diag == 0 skips the 2-D diagnostics.
 //
-// physics_column is the body for column p; the caller has put the dynamical ttend, qtend (or zeros) of the column into the LDS
-// park (PARK_DOUBLES doubles per workgroup of 64 columns: element k of the thread's tt at park[k * 64 + lane], qt NLP * 64
-// further) and passes the dynamical utend(kx), vtend(kx).  Two callers: k_physics below and the fused k_gridtend_physics of
-// dynamics.hip, which hands the tendencies over without a trip through memory.
-constexpr int PARK_DOUBLES = (3 * NLP + 5 * NLP) * 64;
-__device__ __forceinline__ void physics_column(const PhysLev &L, const PhysDev &D, const PhysIn &in, double *__restrict__ tend, int lradsw,
-                                               int off_u, int off_v, int off_t, int off_q, int want_diag, int p, double *park,
-                                               double u_dyn, double v_dyn)
+// The sequence is cut into pieces that two wavefronts can run side by side for the same 64 columns (dynamics.hip,
+// k_gridtend_physics: wave 0 = grid-point dynamics, convection, condensation, vertical diffusion; wave 1 = radiation and surface
+// fluxes) or one wavefront runs back to back (physics_column / k_physics).  The pieces talk through the workgroup's LDS park,
+// lane-interleaved slots of 64 doubles (element k of a column's array at park[(slot + k) * 64 + lane]):
+//   P_TT, P_QT  ttend, qtend accumulators, filled by the caller with the dynamical tendencies (or zeros)
+//   P_RSW       short-wave heating (tendency) of this or the last short-wave step        P_RLW  long-wave heating (tendency)
+//   P_FB        long-wave band fractions of the level temperatures [level][band]
+//   P_XB        radiation chain -> finish: ustr, vstr, shf, evap of the surface (fmask-weighted)
+// The sums keep the reference's order whatever runs where: ttend = ((dyn + cnv) + lsc), then (+ rsw) + rlw, then + pbl.
+constexpr int P_TT = 0, P_QT = NLP, P_RSW = 2 * NLP, P_FB = 3 * NLP, P_RLW = 8 * NLP, P_XB = 9 * NLP, P_SLOTS = 9 * NLP + 4;
+constexpr int PARK_DOUBLES = P_SLOTS * 64;
+
+__device__ __forceinline__ LA park_array(double *park, int slot, int lane) { return LA{park + slot * 64 + lane}; }
+
+// phypar 1.1-1.2 (:54-100): the column's grid-point state of time level 1 and its thermodynamic variables
+__device__ __forceinline__ void column_state(const PhysLev &L, const PhysIn &in, int p, Column &c)
 {
-    const int jlat = p / IX;
-    PSTAMP(0);
-    Column c;
     // every global load the column needs, issued in one batch
     for (int k = 1; k <= KX; ++k) {
         c.tg[k] = in.t[(size_t)(k - 1) * GR + p];
@@ -678,19 +683,6 @@ __device__ __forceinline__ void physics_column(const PhysLev &L, const PhysDev &
     c.usfc = in.usfc[p];
     c.vsfc = in.vsfc[p];
     const double pslg = in.ps[p];
-    LA tt{park + threadIdx.x}, qt{park + NLP * 64 + threadIdx.x}, tt_rsw{park + 2 * NLP * 64 + threadIdx.x};
-    const double s_fmask = D.fmask[p], s_phis0 = D.phis0[p], s_tland = D.tland[p], s_tsea = D.tsea[p], s_swav = D.swav[p];
-    const double s_alb_l = D.alb_l[p], s_alb_s = D.alb_s[p], s_snowc = D.snowc[p], s_forog = D.forog[p], s_albsfc = D.albsfc[p];
-    double tau2[NLP][5], stratc[3], ssrd;
-    if (!lradsw) {      // the short-wave step's leftovers: long-wave transmissivities, stratospheric corrections, heating, surface flux
-        for (int k = 1; k <= KX; ++k) {
-            for (int b = 1; b <= 4; ++b) tau2[k][b] = D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p];
-            tt_rsw[k] = D.tt_rsw[(size_t)(k - 1) * GR + p];
-        }
-        stratc[1] = D.stratc[p];
-        stratc[2] = D.stratc[GR + p];
-        ssrd = D.ssrd[p];
-    }
     c.psg = exp(pslg);
     c.rps = 1. / c.psg;
     for (int k = 1; k <= KX; ++k) {
@@ -699,29 +691,54 @@ __device__ __forceinline__ void physics_column(const PhysLev &L, const PhysDev &
         c.qsat[k] = qsat_of(c.tg[k], L.sig[k] * c.psg);
         c.rh[k] = c.qg[k] / c.qsat[k];
     }
-    // 2. precipitation
-    int iptop;
-    double cbmf, precnv, precls, a1[NLP], a2[NLP], b1[NLP], b2[NLP];
-    PSTAMP(1);
+}
+
+// phypar 2 (:102-118): convection and large-scale condensation; ttend = ttend + tt_cnv + tt_lsc (same for q)
+__device__ __forceinline__ void chain_moist(const PhysLev &L, const PhysDev &D, const Column &c, int p, int want_diag, double *park, int lane,
+                                            int &iptop, int &icnv, double &precnv, double &precls)
+{
+    LA tt = park_array(park, P_TT, lane), qt = park_array(park, P_QT, lane);
+    double cbmf, a1[NLP], a2[NLP], b1[NLP], b2[NLP];
     convmf(L, c, iptop, cbmf, precnv, a1, a2);
-    PSTAMP(2);
     for (int k = 2; k <= KX; ++k) { a1[k] = a1[k] * c.rps * L.grdscp[k]; a2[k] = a2[k] * c.rps * L.grdsig[k]; }
-    const int icnv = KX - iptop;
+    icnv = KX - iptop;
     lscond(L, c, iptop, precls, b1, b2);
-    for (int k = 1; k <= KX; ++k) { tt[k] = tt[k] + a1[k] + b1[k]; qt[k] = qt[k] + a2[k] + b2[k]; }     // ttend = ttend + tt_cnv + tt_lsc
-    PSTAMP(3);
-    // 3. radiation and surface fluxes
-    double ssr = 0., tsr = 0., cloudc = 0., clstr = 0.;
-    int icltop = 0;
-    if (lradsw) {
+    for (int k = 1; k <= KX; ++k) { tt[k] = tt[k] + a1[k] + b1[k]; qt[k] = qt[k] + a2[k] + b2[k]; }
+    if (want_diag) {
+        D.diag[(size_t)D_PRECNV * GR + p] = precnv; D.diag[(size_t)D_PRECLS * GR + p] = precls; D.diag[(size_t)D_CBMF * GR + p] = cbmf;
+        D.diag[(size_t)D_IPTOP * GR + p] = iptop;
+    }
+}
+
+// phypar 3 (:120-176): clouds and short-wave radiation on short-wave steps (else what the last one left), long-wave radiation
+// down, surface fluxes, long-wave radiation up.  Leaves the two heating tendencies and the surface fluxes in the park.
+__device__ __forceinline__ void chain_radiation(const PhysLev &L, const PhysDev &D, const Column &c, int p, int lradsw, int want_diag,
+                                                double *park, int lane, double precnv, double precls, int iptop)
+{
+    const int jlat = p / IX;
+    LA tt_rsw = park_array(park, P_RSW, lane), tt_rlw = park_array(park, P_RLW, lane), xb = park_array(park, P_XB, lane);
+    const double s_fmask = D.fmask[p], s_phis0 = D.phis0[p], s_tland = D.tland[p], s_tsea = D.tsea[p], s_swav = D.swav[p];
+    const double s_alb_l = D.alb_l[p], s_alb_s = D.alb_s[p], s_snowc = D.snowc[p], s_forog = D.forog[p], s_albsfc = D.albsfc[p];
+    double tau2[NLP][5], stratc[3], ssrd, a1[NLP];
+    if (!lradsw) {      // the short-wave step's leftovers: long-wave transmissivities, stratospheric corrections, heating, surface flux
+        for (int k = 1; k <= KX; ++k) {
+            for (int b = 1; b <= 4; ++b) tau2[k][b] = D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p];
+            tt_rsw[k] = D.tt_rsw[(size_t)(k - 1) * GR + p];
+        }
+        stratc[1] = D.stratc[p];
+        stratc[2] = D.stratc[GR + p];
+        ssrd = D.ssrd[p];
+    } else {
+        double ssr = 0., tsr = 0., cloudc = 0., clstr = 0., qcloud;
+        int icltop = 0;
         const double gse = (c.se[KX - 1] - c.se[KX]) / (c.phig[KX - 1] - c.phig[KX]);
-        double qcloud;
         cloud(c, precnv, precls, iptop, gse, s_fmask, icltop, cloudc, clstr, qcloud);
         radsw(L, c, icltop, cloudc, clstr, qcloud, D.fsol[jlat], D.ozone[jlat], D.ozupp[jlat], D.zenit[jlat], D.stratz[jlat], s_albsfc,
               tau2, stratc, ssrd, ssr, tsr, a1);
         for (int k = 1; k <= KX; ++k) {
-            tt_rsw[k] = a1[k] * c.rps * L.grdscp[k];
-            D.tt_rsw[(size_t)(k - 1) * GR + p] = tt_rsw[k];
+            const double h = a1[k] * c.rps * L.grdscp[k];
+            tt_rsw[k] = h;
+            D.tt_rsw[(size_t)(k - 1) * GR + p] = h;
             for (int b = 1; b <= 4; ++b) D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p] = tau2[k][b];
         }
         D.stratc[p] = stratc[1];
@@ -733,42 +750,66 @@ __device__ __forceinline__ void physics_column(const PhysLev &L, const PhysDev &
         }
     }
     LwState lw;
-    lw.fb = LA2<5>{park + 3 * NLP * 64 + threadIdx.x};
-    double slrd, slr, olr;
-    PSTAMP(4);
-    radlw_down(L, c, D.fband, tau2, lw, slrd, a2);      // a2 = dfabs of the long-wave scheme from here to radlw_up
-    PSTAMP(5);
+    lw.fb = LA2<5>{park + P_FB * 64 + lane};
+    double slrd, slr, olr, dfabs[NLP];
+    radlw_down(L, c, D.fband, tau2, lw, slrd, dfabs);
     Surface sf;
     suflux(L, c, s_phis0, s_fmask, s_tland, s_tsea, s_swav, ssrd, slrd, s_alb_l, s_alb_s, s_snowc, s_forog, D.sqclat[jlat], sf);
-    PSTAMP(6);
-    radlw_up(L, c, D.fband, tau2, stratc, lw, sf.tsfc, slrd, sf.slru[3], slr, olr, a2);
-    PSTAMP(7);
-    for (int k = 1; k <= KX; ++k) {
-        const double tt_rlw = a2[k] * c.rps * L.grdscp[k];
-        tt[k] = tt[k] + tt_rsw[k] + tt_rlw;
-    }
-    // 4. PBL
-    vdifsc(L, c, icnv, a1, a2);
-    PSTAMP(8);
-    const double ut = 0.0 + sf.ustr[3] * c.rps * L.grdsig[KX];        // ut_pbl(:,kx) = utenvd (0) + stress term (:187-190)
-    const double vt = 0.0 + sf.vstr[3] * c.rps * L.grdsig[KX];
-    a1[KX] = a1[KX] + sf.shf[3] * c.rps * L.grdscp[KX];
-    a2[KX] = a2[KX] + sf.evap[3] * c.rps * L.grdsig[KX];
-    tend[(size_t)(off_u + KX - 1) * GR + p] = u_dyn + ut;
-    tend[(size_t)(off_v + KX - 1) * GR + p] = v_dyn + vt;
-    for (int k = 1; k <= KX; ++k) {
-        tend[(size_t)(off_t + k - 1) * GR + p] = tt[k] + a1[k];
-        tend[(size_t)(off_q + k - 1) * GR + p] = qt[k] + a2[k];
-    }
+    radlw_up(L, c, D.fband, tau2, stratc, lw, sf.tsfc, slrd, sf.slru[3], slr, olr, dfabs);
+    for (int k = 1; k <= KX; ++k) tt_rlw[k] = dfabs[k] * c.rps * L.grdscp[k];
+    xb[0] = sf.ustr[3]; xb[1] = sf.vstr[3]; xb[2] = sf.shf[3]; xb[3] = sf.evap[3];
     if (want_diag) {
         double *dg = D.diag;
-        dg[(size_t)D_PRECNV * GR + p] = precnv; dg[(size_t)D_PRECLS * GR + p] = precls; dg[(size_t)D_CBMF * GR + p] = cbmf;
         dg[(size_t)D_TS * GR + p] = sf.tsfc; dg[(size_t)D_TSKIN * GR + p] = sf.tskin; dg[(size_t)D_SSRD * GR + p] = ssrd;
         dg[(size_t)D_SLRD * GR + p] = slrd; dg[(size_t)D_OLR * GR + p] = olr; dg[(size_t)D_SHF * GR + p] = sf.shf[3];
         dg[(size_t)D_EVAP * GR + p] = sf.evap[3]; dg[(size_t)D_USTR * GR + p] = sf.ustr[3]; dg[(size_t)D_VSTR * GR + p] = sf.vstr[3];
         dg[(size_t)D_SLR * GR + p] = slr; dg[(size_t)D_HFLUXN1 * GR + p] = sf.hfluxn[1]; dg[(size_t)D_HFLUXN2 * GR + p] = sf.hfluxn[2];
-        dg[(size_t)D_T0 * GR + p] = sf.t0; dg[(size_t)D_Q0 * GR + p] = sf.q0; dg[(size_t)D_IPTOP * GR + p] = iptop;
+        dg[(size_t)D_T0 * GR + p] = sf.t0; dg[(size_t)D_Q0 * GR + p] = sf.q0;
     }
+}
+
+// phypar 3.x sums and 4 (:172-196): ttend = ttend + tt_rsw + tt_rlw; vertical diffusion / shallow convection and the surface
+// fluxes as tendencies of the lowest level; the final tendencies go to `tend`.
+__device__ __forceinline__ void chain_pbl_and_store(const PhysLev &L, const Column &c, int p, int icnv, double *park, int lane,
+                                                    double *__restrict__ tend, int off_u, int off_v, int off_t, int off_q, double u_dyn,
+                                                    double v_dyn, const double (&pt)[NLP], const double (&pq)[NLP])
+{
+    LA tt = park_array(park, P_TT, lane), qt = park_array(park, P_QT, lane), tt_rsw = park_array(park, P_RSW, lane);
+    LA tt_rlw = park_array(park, P_RLW, lane), xb = park_array(park, P_XB, lane);
+    const double ut = 0.0 + xb[0] * c.rps * L.grdsig[KX];        // ut_pbl(:,kx) = utenvd (0) + stress term (:187-190)
+    const double vt = 0.0 + xb[1] * c.rps * L.grdsig[KX];
+    tend[(size_t)(off_u + KX - 1) * GR + p] = u_dyn + ut;
+    tend[(size_t)(off_v + KX - 1) * GR + p] = v_dyn + vt;
+    for (int k = 1; k <= KX; ++k) {
+        double t_pbl = pt[k], q_pbl = pq[k];
+        if (k == KX) { t_pbl = t_pbl + xb[2] * c.rps * L.grdscp[KX]; q_pbl = q_pbl + xb[3] * c.rps * L.grdsig[KX]; }
+        const double t_rad = tt[k] + tt_rsw[k] + tt_rlw[k];
+        tend[(size_t)(off_t + k - 1) * GR + p] = t_rad + t_pbl;
+        tend[(size_t)(off_q + k - 1) * GR + p] = qt[k] + q_pbl;
+    }
+}
+
+// physics_column: the whole sequence for column p in one wavefront.  The caller has put the dynamical ttend, qtend (or zeros) of
+// the column into the park (P_TT, P_QT) and passes the dynamical utend(kx), vtend(kx).
+__device__ __forceinline__ void physics_column(const PhysLev &L, const PhysDev &D, const PhysIn &in, double *__restrict__ tend, int lradsw,
+                                               int off_u, int off_v, int off_t, int off_q, int want_diag, int p, double *park,
+                                               double u_dyn, double v_dyn)
+{
+    const int lane = threadIdx.x & 63;
+    PSTAMP(0);
+    Column c;
+    column_state(L, in, p, c);
+    PSTAMP(1);
+    int iptop, icnv;
+    double precnv, precls;
+    chain_moist(L, D, c, p, want_diag, park, lane, iptop, icnv, precnv, precls);
+    PSTAMP(3);
+    chain_radiation(L, D, c, p, lradsw, want_diag, park, lane, precnv, precls, iptop);
+    PSTAMP(7);
+    double pt[NLP], pq[NLP];
+    vdifsc(L, c, icnv, pt, pq);
+    PSTAMP(8);
+    chain_pbl_and_store(L, c, p, icnv, park, lane, tend, off_u, off_v, off_t, off_q, u_dyn, v_dyn, pt, pq);
     PSTAMP(9);
 }
 

@@ -66,6 +66,11 @@ class Dynamics:
         self._physics = physics          # keeps the handle alive
         check(_lib.lib().sml_dyn_attach_physics(self._h, physics._h if physics is not None else None, int(nstrad)))
 
+    @staticmethod
+    def select_physics_form(fused):
+        """True (default): grtend's grid-point part and the physics as one two-wave launch; False: two launches (same bits)"""
+        check(_lib.lib().sml_dyn_select_physics_form(1 if fused else 0))
+
     def set_lradsw(self, flag):
         """the module flag lradsw (src/mod_lflags.f90:22) seen by step()/grtend() and by the stepone part of the next window"""
         check(_lib.lib().sml_dyn_set_lradsw(self._h, 1 if flag else 0))

@@ -201,6 +201,29 @@ def device_window(st, phis, surf, nsteps):
     return out, dyn, ph
 
 
+def test_fused_two_wave_step_equals_two_launch_form():
+    """k_gridtend_physics (wave 0: dynamics + moist + diffusion chain, wave 1: radiation + surface chain) against k_gridtend followed
+    by the one-wave k_physics: identical bits after stepone + 7 steps (short-wave and non-short-wave steps), and repeatable."""
+    from make_physics_golden import coupled_inputs
+    from speedy_ml_amd.dynamics import Dynamics
+    _, st, phis, surf = coupled_inputs(seed=4)
+    try:
+        Dynamics.select_physics_form(False)
+        two, _, ph_two = device_window(st, phis, surf, 7)
+        diag_two = {k: ph_two.diag(k).copy() for k in ("olr", "precnv", "iptop", "ssrd", "shf")}
+        Dynamics.select_physics_form(True)
+        one, _, ph_one = device_window(st, phis, surf, 7)
+        again, _, _ = device_window(st, phis, surf, 7)
+    finally:
+        Dynamics.select_physics_form(True)
+    for k in ("vor", "div", "t", "tr", "ps"):
+        assert np.all(np.isfinite(one[k]))
+        assert np.array_equal(one[k], two[k]), k
+        assert np.array_equal(one[k], again[k]), k
+    for k, v in diag_two.items():
+        assert np.array_equal(ph_one.diag(k), v), k
+
+
 def test_window_with_physics_matches_reference_fixture():
     from make_physics_golden import WINDOW_KEEP, WINDOW_STEPS, coupled_inputs
     gold = np.load(GOLD)
