@@ -143,7 +143,6 @@ void build_tables(HostTables &t, double a)
 }
 
 // ------------------------------------------------ kernels ------------------------------------------------
-constexpr int TT = 256;
 
 // A single 96x48 transform is far too small to fill the chip, and even a whole transform set (<= 91 fields) gives
 // only 91 workgroups for 256 CUs.  Each field is therefore split over several workgroups along the dimension that
@@ -156,8 +155,12 @@ constexpr int TT = 256;
 #endif
 constexpr int LATG = SML_LATG;          // latitude pairs per workgroup (inverse)
 constexpr int NLG = IY / LATG;          // 6 workgroups per field
-constexpr int MG = 4;                   // zonal wavenumbers per workgroup (forward)
-constexpr int NMG = (MX + MG - 1) / MG; // 8 workgroups per field
+#ifndef SML_MG
+#define SML_MG 8
+#endif
+constexpr int MG = SML_MG;              // zonal wavenumbers per workgroup (forward)
+constexpr int NMG = (MX + MG - 1) / MG; // workgroups per field
+constexpr int TT = 64 * MG;             // threads: 2 MG coefficient columns x 32 total wavenumbers in the Legendre analysis
 
 // inverse transform: vorm[32][62] -> vorg[48][96]; workgroup = (field, group of LATG latitude pairs)
 // (i g z): (re,im) -> (-g im, g re)
@@ -204,43 +207,62 @@ __device__ __forceinline__ double derived_coeff(const DevTables &T, int type, co
 
 constexpr int TG = 512;     // phase ablation: staging+launch floor 6.7 us, Legendre 2.6 us, Fourier 6.5 us at 256 threads (two
                             // rounds of the 392 Fourier items); 512 threads do them in one round
+#ifndef SML_FPW
+#define SML_FPW 1
+#endif
+constexpr int FPW = SML_FPW;            // fields per workgroup: each gets TG threads of its own, the Legendre slab is staged once
+constexpr size_t GRID_LDS = sizeof(double) * ((size_t)FPW * SPEC_N + (size_t)LATG * NX * MX + (size_t)FPW * 2 * LATG * MX2 + 2 * IX) + sizeof(int) * NX;
 // desc (optional): int32 [nf][4] = (type, src0, src1, kcos) per output field; type 0 = field src0 of vorm as it is,
 // 1..4 = derived_coeff of fields src0 (P) and src1 (Q); 7 = geopotential of level src1 from the temperature levels at src0 (needs aux)
-__global__ __launch_bounds__(TG) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos_all,
-                                              const int *__restrict__ kcos_of_field, const int *__restrict__ desc,
-                                              const double *__restrict__ aux)
+// A workgroup can serve FPW fields of one latitude group (the Legendre slab is then staged once for both).  Measured on the 77-field
+// set of a time step with physics (462 one-field workgroups, two on most CUs): FPW = 2 (231 workgroups of 1024 threads) is 1 us
+// SLOWER per launch, and the launch costs 14.2 us even when every field is a plain copy (the geopotential rows add 1.3 us) against
+// 10.8 us for 50 fields: the kernel's time follows the total LDS traffic of the Fourier phase, not the workgroup count.  FPW = 1.
+__global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__restrict__ vorm, double *__restrict__ vorg, int kcos_all,
+                                                    const int *__restrict__ kcos_of_field, const int *__restrict__ desc,
+                                                    const double *__restrict__ aux, int nf)
 {
-    __shared__ double sv[SPEC_N];              // spectral coefficients
-    __shared__ double sp[LATG][NX][MX];        // this workgroup's slab of the Legendre table (31 KB), staged with sv
-    __shared__ double sf[2 * LATG][MX2];       // Fourier coefficients of the 2*LATG latitude rows of this workgroup
-    __shared__ double stc[IX], sts[IX];
-    __shared__ int snsh[NX];
-    const int f = blockIdx.x / NLG, lg = blockIdx.x % NLG;
-    int kcos = kcos_of_field ? kcos_of_field[f] : kcos_all, type = 0, src0 = f, src1 = f;
-    if (desc) { type = desc[4 * f]; src0 = desc[4 * f + 1]; src1 = desc[4 * f + 2]; kcos = desc[4 * f + 3]; }
+    extern __shared__ __attribute__((aligned(16))) double grid_lds[];
+    double *sv_all = grid_lds;                                            // [FPW][SPEC_N] spectral coefficients
+    double (*sp)[NX][MX] = reinterpret_cast<double (*)[NX][MX]>(sv_all + FPW * SPEC_N);      // [LATG]: this latitude group's slab of the Legendre table (31 KB)
+    double *sf_all = &sp[0][0][0] + LATG * NX * MX;                       // [FPW][2 * LATG][MX2] Fourier coefficients
+    double *stc = sf_all + FPW * 2 * LATG * MX2, *sts = stc + IX;
+    int *snsh = reinterpret_cast<int *>(sts + IX);
+    const int sub = threadIdx.x / TG, tid = threadIdx.x % TG;             // sub is uniform per wavefront
+    const int f = (blockIdx.x / NLG) * FPW + sub, lg = blockIdx.x % NLG;
+    const bool active = f < nf;
+    double *sv = sv_all + sub * SPEC_N;
+    double (*sf)[MX2] = reinterpret_cast<double (*)[MX2]>(sf_all + sub * 2 * LATG * MX2);
+    int kcos = kcos_all, type = 0, src0 = f, src1 = f;
+    if (active) {
+        if (kcos_of_field) kcos = kcos_of_field[f];
+        if (desc) { type = desc[4 * f]; src0 = desc[4 * f + 1]; src1 = desc[4 * f + 2]; kcos = desc[4 * f + 3]; }
+    }
     const double *v = vorm + (size_t)src0 * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
     // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
-    if (type == 0) {
-        for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = v[i];
-    } else if (type == 7) {
-        for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, 7, v, v, i / MX2, i % MX2, src1, aux);
-    } else {
-        const double *q = vorm + (size_t)src1 * SPEC_N;
-        for (int i = threadIdx.x; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, type, v, q, i / MX2, i % MX2);
+    if (active) {
+        if (type == 0) {
+            for (int i = tid; i < SPEC_N; i += TG) sv[i] = v[i];
+        } else if (type == 7) {
+            for (int i = tid; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, 7, v, v, i / MX2, i % MX2, src1, aux);
+        } else {
+            const double *q = vorm + (size_t)src1 * SPEC_N;
+            for (int i = tid; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, type, v, q, i / MX2, i % MX2);
+        }
     }
     {
         const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
         double *pl = &sp[0][0][0];
-        for (int i = threadIdx.x; i < LATG * NX * MX; i += TG) pl[i] = pg[i];
+        for (int i = threadIdx.x; i < LATG * NX * MX; i += TG * FPW) pl[i] = pg[i];
     }
-    for (int i = threadIdx.x; i < IX; i += TG) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
+    for (int i = threadIdx.x; i < IX; i += TG * FPW) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
     if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
     __syncthreads();
     // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O.
     // Summation order is the reference's, so without FMA contraction this is bit-identical to gridy.
-    if (threadIdx.x < LATG * MX2) {
-        const int c = threadIdx.x % MX2, jj = threadIdx.x / MX2, m = c >> 1;
+    if (active && tid < LATG * MX2) {
+        const int c = tid % MX2, jj = tid / MX2, m = c >> 1;
         double e = 0.0, o = 0.0;
 #pragma unroll 4
         for (int n = 0; n < NX; n += 2) {
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(TG) void k_grid(DevTables T, const double *__restri
     __syncthreads();
     // Fourier synthesis (gridx) of the 31 retained modes, two longitudes per work item: with A = sum_k Re_k cos(k i t)
     // and B = sum_k Im_k sin(k i t),  x_i = a0 + 2(A - B)  and  x_{96-i} = a0 + 2(A + B)   (i = 0..48).
-    for (int w = threadIdx.x; w < 2 * LATG * (IX / 2 + 1); w += TG) {
+    for (int w = active ? tid : 2 * LATG * (IX / 2 + 1); w < 2 * LATG * (IX / 2 + 1); w += TG) {
         const int i = w % (IX / 2 + 1), r = w / (IX / 2 + 1);
         const int j = lg * LATG + (r >> 1);
         const int row = (r & 1) ? IL - 1 - j : j;
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     // accumulation over latitude in the reference's order -> bit-identical to specy for identical Fourier input.
     // The 24 table loads of a thread are independent and issued together (full unroll).
     {
-        const int cc = threadIdx.x % (2 * MG), n = threadIdx.x / (2 * MG);     // 8 x 32 = 256 threads
+        const int cc = threadIdx.x % (2 * MG), n = threadIdx.x / (2 * MG);     // 2 MG x 32 = TT threads
         const int c = 2 * k0 + cc, m = c >> 1;
         if (cc < 2 * nk) {
             double acc = 0.0;
@@ -496,6 +518,8 @@ int sml_spectral_create(double a, sml_spectral **out)
     UP(uvdx, &h.uvdx[0][0], NX * MX); UP(uvdym, &h.uvdym[0][0], NX * MX); UP(uvdyp, &h.uvdyp[0][0], NX * MX);
     UP(vddym, &h.vddym[0][0], NX * MX); UP(vddyp, &h.vddyp[0][0], NX * MX);
 #undef UP
+    if (!rc && hipFuncSetAttribute((const void *)k_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS) != hipSuccess)
+        rc = sml::fail(SML_ERR_HIP, "sml_spectral_create: cannot reserve %zu bytes of LDS for k_grid", GRID_LDS);
     if (rc) { sml_spectral_destroy(sp); return rc; }
     *out = sp;
     return SML_OK;
@@ -561,8 +585,8 @@ int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf
 {
     SML_REQUIRE(sp && nf >= 0 && (kcos == 1 || kcos == 2) && (nf == 0 || (vorm && vorg)), "sml_spectral_grid: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, kcos, (const int *)nullptr, (const int *)nullptr,
-                       (const double *)nullptr);
+    hipLaunchKernelGGL(k_grid, dim3((nf + FPW - 1) / FPW * NLG), dim3(TG * FPW), GRID_LDS, sml::as_stream(stream), sp->d, vorm, vorg, kcos,
+                       (const int *)nullptr, (const int *)nullptr, (const double *)nullptr, nf);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
@@ -578,8 +602,8 @@ int sml_spectral_grid_mixed(sml_spectral *sp, const double *vorm, double *vorg, 
 {
     SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (vorm && vorg && kcos_dev)), "sml_spectral_grid_mixed: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, vorm, vorg, 1, (const int *)kcos_dev, (const int *)nullptr,
-                       (const double *)nullptr);
+    hipLaunchKernelGGL(k_grid, dim3((nf + FPW - 1) / FPW * NLG), dim3(TG * FPW), GRID_LDS, sml::as_stream(stream), sp->d, vorm, vorg, 1,
+                       (const int *)kcos_dev, (const int *)nullptr, (const double *)nullptr, nf);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
@@ -589,8 +613,8 @@ int sml_spectral_grid_derived_aux(sml_spectral *sp, const double *spec_base, con
 {
     SML_REQUIRE(sp && nf >= 0 && (nf == 0 || (spec_base && desc_dev && vorg)), "sml_spectral_grid_derived: bad arguments");
     if (!nf) return SML_OK;
-    hipLaunchKernelGGL(k_grid, dim3(nf * NLG), dim3(TG), 0, sml::as_stream(stream), sp->d, spec_base, vorg, 1, (const int *)nullptr,
-                       (const int *)desc_dev, aux_dev);
+    hipLaunchKernelGGL(k_grid, dim3((nf + FPW - 1) / FPW * NLG), dim3(TG * FPW), GRID_LDS, sml::as_stream(stream), sp->d, spec_base, vorg, 1,
+                       (const int *)nullptr, (const int *)desc_dev, aux_dev, nf);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
