@@ -523,6 +523,17 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
         psdt = tend_in[(size_t)F_PS * SP + e];
     }
     double *s1 = state, *s2 = state + (size_t)NSTATE * SP;
+    // Everything the diffusion and the leapfrog update need from memory is fetched HERE, in the same batch as the tendencies: the
+    // kernel is a chain of exposed round trips (10.6 us per launch for 0.1 ms of arithmetic), and loads issued after the LDS
+    // phases below each cost another one.
+    const size_t ov = (size_t)(F_VOR + k) * SP + e, od = (size_t)(F_DIV + k) * SP + e, ot = (size_t)(F_T + k) * SP + e,
+                 oq = (size_t)(F_TR + k) * SP + e, op = (size_t)F_PS * SP + e;
+    const bool two = a.j1 != 1;
+    const double v1 = s1[ov], d1 = s1[od], t1 = s1[ot], q1 = s1[oq], p1 = s1[op];
+    const double v2 = two ? s2[ov] : 0., d2 = two ? s2[od] : 0., t2 = two ? s2[ot] : 0., q2 = two ? s2[oq] : 0., p2 = two ? s2[op] : 0.;
+    const double dmp = H.dmp[hm], dmpd = H.dmpd[hm], dmps = H.dmps[hm];
+    const double dmp1 = imp_h[hm], dmp1d = imp_h[NX * MX + hm], dmp1s = imp_h[2 * NX * MX + hm];
+    const double tch = tcorh[e], qch = qcorh[e], tf = H.trfilt[hm];
     if (!stop_after_grtend) {
         // ---- sptend (src/dyn_sptend.f90) on time level j4
         const double *s4 = a.j4 == 1 ? s1 : s2;
@@ -586,11 +597,8 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
             for (int k1 = 0; k1 < KX; ++k1) tdt = tdt + xdc[1][k1 * KX + k] * dvs[k1][ci];
         }
         // ---- horizontal diffusion (src/dyn_step.f90:60-104, hordif :130-150), always on time level 1
-        const double dmp = H.dmp[hm], dmpd = H.dmpd[hm], dmps = H.dmps[hm];
-        const double dmp1 = imp_h[hm], dmp1d = imp_h[NX * MX + hm], dmp1s = imp_h[2 * NX * MX + hm];
-        const double v1 = s1[(size_t)(F_VOR + k) * SP + e], d1 = s1[(size_t)(F_DIV + k) * SP + e];
-        const double ct = s1[(size_t)(F_T + k) * SP + e] + tcorh[e] * lv[LV_TCORV][k];
-        const double cq = s1[(size_t)(F_TR + k) * SP + e] + qcorh[e] * lv[LV_QCORV][k];
+        const double ct = t1 + tch * lv[LV_TCORV][k];
+        const double cq = q1 + qch * lv[LV_QCORV][k];
         vordt = (vordt - dmp * v1) * dmp1;
         divdt = (divdt - dmpd * d1) * dmp1d;
         tdt = (tdt - dmp * ct) * dmp1;
@@ -611,25 +619,21 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
     }
     if (stop_after_grtend || !a.integrate) return;
     // ---- timint (src/dyn_step.f90:152-190): truncation, leapfrog, Robert-Asselin-Williams filter, both levels in place
-    const double tf = H.trfilt[hm];
-    auto timint = [&](int f, double fdt) {
+    auto timint = [&](size_t o, double f1, double f2, double fdt) {
         fdt = fdt * tf;
-        const size_t o = (size_t)f * SP + e;
-        const double f1 = s1[o];
-        const double fj = a.j1 == 1 ? f1 : s2[o];
+        const double fj = two ? f2 : f1;
         const double fnew = f1 + a.dt * fdt;
         const double n1 = fj + a.wil * a.eps * (f1 - 2 * fj + fnew);
-        const double fj_after = a.j1 == 1 ? n1 : fj;          // field(.,1) is overwritten before field(.,2) is formed
+        const double fj_after = two ? fj : n1;                // field(.,1) is overwritten before field(.,2) is formed
         s1[o] = n1;
         s2[o] = fnew - (1 - a.wil) * a.eps * (n1 - 2 * fj_after + fnew);
     };
-    // every level-thread of a coefficient has read its time-level-1 diffusion operands above; a column's ps is only
-    // touched by its k == 0 thread
-    timint(F_VOR + k, vordt);
-    timint(F_DIV + k, divdt);
-    timint(F_T + k, tdt);
-    timint(F_TR + k, trdt);
-    if (k == 0) timint(F_PS, psdt);
+    // a column's ps is only touched by its k == 0 thread
+    timint(ov, v1, v2, vordt);
+    timint(od, d1, d2, divdt);
+    timint(ot, t1, t2, tdt);
+    timint(oq, q1, q2, trdt);
+    if (k == 0) timint(op, p1, p2, psdt);
 }
 
 
