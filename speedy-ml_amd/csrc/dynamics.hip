@@ -367,6 +367,8 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // uniform: the two chains are scalar branches
     const int p = blockIdx.x * 64 + lane;                                     // the grid is exactly GR / 64 workgroups
     if (wave == 0) {
+        smlphys::Column c;
+        smlphys::column_load(PG, p, c);                  // issued with the loads of the dynamics below: one exposed round trip
         const int j = p / IX;
         smlphys::LA tt = smlphys::park_array(park, smlphys::P_TT, lane), qt = smlphys::park_array(park, smlphys::P_QT, lane);   // 1-based levels
         double ug[KX], vg[KX], tg[KX], vorg[KX], divg[KX], trg[KX], puv[KX], sigdt[KXP], sigm[KXP];
@@ -438,8 +440,7 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
             O[(size_t)(32 + k) * GR + p] = -ug[k] * trg[k];
             O[(size_t)(40 + k) * GR + p] = -vg[k] * trg[k];
         }
-            smlphys::Column c;
-        smlphys::column_state(PL, PG, p, c);
+            smlphys::column_thermo(PL, c);
         int iptop, icnv;
         double precnv, precls;
         smlphys::chain_moist(PL, PD, c, p, want_diag, park, lane, iptop, icnv, precnv, precls);
@@ -449,7 +450,10 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
         smlphys::chain_pbl_and_store(PL, c, p, icnv, park, lane, O, 0, 8, 56, 64, u_dyn, v_dyn, pt, pq);
     } else {
         smlphys::Column c;
-        smlphys::column_state(PL, PG, p, c);
+        smlphys::RadIn r;
+        smlphys::column_load(PG, p, c);                  // everything this chain reads, in one batch
+        smlphys::radiation_load(PD, p, lradsw, park, lane, r);
+        smlphys::column_thermo(PL, c);
         double precnv = 0., precls = 0.;
         int iptop = 0;
         if (lradsw) {
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
             smlphys::convmf(PL, c, iptop, cbmf, precnv, s1, s2);
             smlphys::lscond(PL, c, iptop, precls, s1, s2);
         }
-        smlphys::chain_radiation(PL, PD, c, p, lradsw, want_diag, park, lane, precnv, precls, iptop);
+        smlphys::chain_radiation(PL, PD, c, r, p, lradsw, want_diag, park, lane, precnv, precls, iptop);
         __syncthreads();
     }
 }

@@ -671,10 +671,10 @@ constexpr int PARK_DOUBLES = P_SLOTS * 64;
 
 __device__ __forceinline__ LA park_array(double *park, int slot, int lane) { return LA{park + slot * 64 + lane}; }
 
-// phypar 1.1-1.2 (:54-100): the column's grid-point state of time level 1 and its thermodynamic variables
-__device__ __forceinline__ void column_state(const PhysLev &L, const PhysIn &in, int p, Column &c)
+// phypar 1.1-1.2 (:54-100): the column's grid-point state of time level 1 (column_load: the loads only, so that a caller can issue
+// them together with its other loads) and its thermodynamic variables (column_thermo)
+__device__ __forceinline__ void column_load(const PhysIn &in, int p, Column &c)
 {
-    // every global load the column needs, issued in one batch
     for (int k = 1; k <= KX; ++k) {
         c.tg[k] = in.t[(size_t)(k - 1) * GR + p];
         c.qg[k] = in.q[(size_t)(k - 1) * GR + p];
@@ -682,7 +682,12 @@ __device__ __forceinline__ void column_state(const PhysLev &L, const PhysIn &in,
     }
     c.usfc = in.usfc[p];
     c.vsfc = in.vsfc[p];
-    const double pslg = in.ps[p];
+    c.psg = in.ps[p];               // log(ps) until column_thermo
+}
+
+__device__ __forceinline__ void column_thermo(const PhysLev &L, Column &c)
+{
+    const double pslg = c.psg;
     c.psg = exp(pslg);
     c.rps = 1. / c.psg;
     for (int k = 1; k <= KX; ++k) {
@@ -690,6 +695,39 @@ __device__ __forceinline__ void column_state(const PhysLev &L, const PhysIn &in,
         c.se[k] = CP * c.tg[k] + c.phig[k];
         c.qsat[k] = qsat_of(c.tg[k], L.sig[k] * c.psg);
         c.rh[k] = c.qg[k] / c.qsat[k];
+    }
+}
+
+__device__ __forceinline__ void column_state(const PhysLev &L, const PhysIn &in, int p, Column &c)
+{
+    column_load(in, p, c);
+    column_thermo(L, c);
+}
+
+// what the radiation / surface chain reads from memory: boundary fields of the column, zonal fields of its latitude and, when this
+// is not a short-wave step, what the last one left (the short-wave heating goes straight into the park)
+struct RadIn {
+    double fmask, phis0, tland, tsea, swav, alb_l, alb_s, snowc, forog, albsfc, fsol, ozone, ozupp, zenit, stratz, sqclat;
+    double tau2[NLP][5], stratc[3], ssrd;
+};
+
+__device__ __forceinline__ void radiation_load(const PhysDev &D, int p, int lradsw, double *park, int lane, RadIn &r)
+{
+    const int jlat = p / IX;
+    r.fmask = D.fmask[p]; r.phis0 = D.phis0[p]; r.tland = D.tland[p]; r.tsea = D.tsea[p]; r.swav = D.swav[p];
+    r.alb_l = D.alb_l[p]; r.alb_s = D.alb_s[p]; r.snowc = D.snowc[p]; r.forog = D.forog[p]; r.albsfc = D.albsfc[p];
+    r.sqclat = D.sqclat[jlat];
+    if (lradsw) {
+        r.fsol = D.fsol[jlat]; r.ozone = D.ozone[jlat]; r.ozupp = D.ozupp[jlat]; r.zenit = D.zenit[jlat]; r.stratz = D.stratz[jlat];
+    } else {
+        LA tt_rsw = park_array(park, P_RSW, lane);
+        for (int k = 1; k <= KX; ++k) {
+            for (int b = 1; b <= 4; ++b) r.tau2[k][b] = D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p];
+            tt_rsw[k] = D.tt_rsw[(size_t)(k - 1) * GR + p];
+        }
+        r.stratc[1] = D.stratc[p];
+        r.stratc[2] = D.stratc[GR + p];
+        r.ssrd = D.ssrd[p];
     }
 }
 
@@ -712,29 +750,19 @@ __device__ __forceinline__ void chain_moist(const PhysLev &L, const PhysDev &D, 
 
 // phypar 3 (:120-176): clouds and short-wave radiation on short-wave steps (else what the last one left), long-wave radiation
 // down, surface fluxes, long-wave radiation up.  Leaves the two heating tendencies and the surface fluxes in the park.
-__device__ __forceinline__ void chain_radiation(const PhysLev &L, const PhysDev &D, const Column &c, int p, int lradsw, int want_diag,
+__device__ __forceinline__ void chain_radiation(const PhysLev &L, const PhysDev &D, const Column &c, RadIn &r, int p, int lradsw, int want_diag,
                                                 double *park, int lane, double precnv, double precls, int iptop)
 {
-    const int jlat = p / IX;
     LA tt_rsw = park_array(park, P_RSW, lane), tt_rlw = park_array(park, P_RLW, lane), xb = park_array(park, P_XB, lane);
-    const double s_fmask = D.fmask[p], s_phis0 = D.phis0[p], s_tland = D.tland[p], s_tsea = D.tsea[p], s_swav = D.swav[p];
-    const double s_alb_l = D.alb_l[p], s_alb_s = D.alb_s[p], s_snowc = D.snowc[p], s_forog = D.forog[p], s_albsfc = D.albsfc[p];
-    double tau2[NLP][5], stratc[3], ssrd, a1[NLP];
-    if (!lradsw) {      // the short-wave step's leftovers: long-wave transmissivities, stratospheric corrections, heating, surface flux
-        for (int k = 1; k <= KX; ++k) {
-            for (int b = 1; b <= 4; ++b) tau2[k][b] = D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p];
-            tt_rsw[k] = D.tt_rsw[(size_t)(k - 1) * GR + p];
-        }
-        stratc[1] = D.stratc[p];
-        stratc[2] = D.stratc[GR + p];
-        ssrd = D.ssrd[p];
-    } else {
-        double ssr = 0., tsr = 0., cloudc = 0., clstr = 0., qcloud;
+    double (&tau2)[NLP][5] = r.tau2;
+    double (&stratc)[3] = r.stratc;
+    double &ssrd = r.ssrd;
+    if (lradsw) {
+        double ssr = 0., tsr = 0., cloudc = 0., clstr = 0., qcloud, a1[NLP];
         int icltop = 0;
         const double gse = (c.se[KX - 1] - c.se[KX]) / (c.phig[KX - 1] - c.phig[KX]);
-        cloud(c, precnv, precls, iptop, gse, s_fmask, icltop, cloudc, clstr, qcloud);
-        radsw(L, c, icltop, cloudc, clstr, qcloud, D.fsol[jlat], D.ozone[jlat], D.ozupp[jlat], D.zenit[jlat], D.stratz[jlat], s_albsfc,
-              tau2, stratc, ssrd, ssr, tsr, a1);
+        cloud(c, precnv, precls, iptop, gse, r.fmask, icltop, cloudc, clstr, qcloud);
+        radsw(L, c, icltop, cloudc, clstr, qcloud, r.fsol, r.ozone, r.ozupp, r.zenit, r.stratz, r.albsfc, tau2, stratc, ssrd, ssr, tsr, a1);
         for (int k = 1; k <= KX; ++k) {
             const double h = a1[k] * c.rps * L.grdscp[k];
             tt_rsw[k] = h;
@@ -754,7 +782,7 @@ __device__ __forceinline__ void chain_radiation(const PhysLev &L, const PhysDev 
     double slrd, slr, olr, dfabs[NLP];
     radlw_down(L, c, D.fband, tau2, lw, slrd, dfabs);
     Surface sf;
-    suflux(L, c, s_phis0, s_fmask, s_tland, s_tsea, s_swav, ssrd, slrd, s_alb_l, s_alb_s, s_snowc, s_forog, D.sqclat[jlat], sf);
+    suflux(L, c, r.phis0, r.fmask, r.tland, r.tsea, r.swav, ssrd, slrd, r.alb_l, r.alb_s, r.snowc, r.forog, r.sqclat, sf);
     radlw_up(L, c, D.fband, tau2, stratc, lw, sf.tsfc, slrd, sf.slru[3], slr, olr, dfabs);
     for (int k = 1; k <= KX; ++k) tt_rlw[k] = dfabs[k] * c.rps * L.grdscp[k];
     xb[0] = sf.ustr[3]; xb[1] = sf.vstr[3]; xb[2] = sf.shf[3]; xb[3] = sf.evap[3];
@@ -798,13 +826,16 @@ __device__ __forceinline__ void physics_column(const PhysLev &L, const PhysDev &
     const int lane = threadIdx.x & 63;
     PSTAMP(0);
     Column c;
-    column_state(L, in, p, c);
+    RadIn r;
+    column_load(in, p, c);                              // one batch of loads for everything the sequence reads
+    radiation_load(D, p, lradsw, park, lane, r);
+    column_thermo(L, c);
     PSTAMP(1);
     int iptop, icnv;
     double precnv, precls;
     chain_moist(L, D, c, p, want_diag, park, lane, iptop, icnv, precnv, precls);
     PSTAMP(3);
-    chain_radiation(L, D, c, p, lradsw, want_diag, park, lane, precnv, precls, iptop);
+    chain_radiation(L, D, c, r, p, lradsw, want_diag, park, lane, precnv, precls, iptop);
     PSTAMP(7);
     double pt[NLP], pq[NLP];
     vdifsc(L, c, icnv, pt, pq);
