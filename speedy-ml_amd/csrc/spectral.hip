@@ -205,6 +205,14 @@ __device__ __forceinline__ double derived_coeff(const DevTables &T, int type, co
     return -T.gradym[n * MX + m] * P[row - MX2 + c] + T.gradyp[n * MX + m] * P[row + MX2 + c];
 }
 
+// phase time stamps of one workgroup (profiles/micro/grid_phase_stamps.py); compiled in with -DSML_GRID_STAMPS only
+__device__ unsigned long long g_grid_dbg[16];
+#ifdef SML_GRID_STAMPS
+#define GSTAMP(slot) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == SML_GRID_STAMPS && threadIdx.x == 0) g_grid_dbg[slot] = wall_clock64(); } while (0)
+#else
+#define GSTAMP(slot) do { } while (0)
+#endif
+__device__ __host__ constexpr int nsh2_of(int n) { return 2 * (NX - n) < MX2 ? 2 * (NX - n) : MX2; }
 constexpr int TG = 512;     // phase ablation: staging+launch floor 6.7 us, Legendre 2.6 us, Fourier 6.5 us at 256 threads (two
                             // rounds of the 392 Fourier items); 512 threads do them in one round
 #ifndef SML_FPW
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
                                                     const int *__restrict__ kcos_of_field, const int *__restrict__ desc,
                                                     const double *__restrict__ aux, int nf)
 {
+    GSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) double grid_lds[];
     double *sv_all = grid_lds;                                            // [FPW][SPEC_N] spectral coefficients
     double (*sp)[NX][MX] = reinterpret_cast<double (*)[NX][MX]>(sv_all + FPW * SPEC_N);      // [LATG]: this latitude group's slab of the Legendre table (31 KB)
@@ -241,38 +250,51 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     const double *v = vorm + (size_t)src0 * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
     // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
-    if (active) {
-        if (type == 0) {
-            for (int i = tid; i < SPEC_N; i += TG) sv[i] = v[i];
-        } else if (type == 7) {
-            for (int i = tid; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, 7, v, v, i / MX2, i % MX2, src1, aux);
-        } else {
-            const double *q = vorm + (size_t)src1 * SPEC_N;
-            for (int i = tid; i < SPEC_N; i += TG) sv[i] = derived_coeff(T, type, v, q, i / MX2, i % MX2);
-        }
-    }
+    // Only the coefficients inside the triangular truncation are ever read below (c < nsh2(n), i.e. m < nsh2(n) / 2): staging
+    // just those is 45 % fewer bytes, and the staging phase is where all 462 workgroups of a launch hit L2 at the same moment
+    // (phase stamps: 3.0 of a workgroup's 9 us).  nsh2(n) = min(62, 2 (32 - n)) (parmtr, src/spe_spectral.f90:99-125).
+    // The Legendre slab does not depend on the field's descriptor: its loads go out first and fly under the descriptor round trip.
     {
         const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
         double *pl = &sp[0][0][0];
-        for (int i = threadIdx.x; i < LATG * NX * MX; i += TG * FPW) pl[i] = pg[i];
+        const int m = threadIdx.x & 31;                                  // two (latitude, n) rows of 31 zonal wavenumbers per wavefront
+        for (int row = (threadIdx.x >> 5); row < LATG * NX; row += TG * FPW / 32) {
+            if (m < MX && 2 * m < nsh2_of(row % NX)) pl[row * MX + m] = pg[row * MX + m];
+        }
+    }
+    // (a wavefront stages whole rows: lane = coefficient within total wavenumber n, no index division per element)
+    const int wv = tid >> 6, ln = tid & 63;
+    if (active) {
+        if (type == 0) {
+            for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = v[n * MX2 + ln]; }
+        } else if (type == 7) {
+            for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = derived_coeff(T, 7, v, v, n, ln, src1, aux); }
+        } else {
+            const double *q = vorm + (size_t)src1 * SPEC_N;
+            for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = derived_coeff(T, type, v, q, n, ln); }
+        }
     }
     for (int i = threadIdx.x; i < IX; i += TG * FPW) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
     if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
+    GSTAMP(1);
     __syncthreads();
+    GSTAMP(2);
     // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O.
     // Summation order is the reference's, so without FMA contraction this is bit-identical to gridy.
     if (active && tid < LATG * MX2) {
         const int c = tid % MX2, jj = tid / MX2, m = c >> 1;
         double e = 0.0, o = 0.0;
-#pragma unroll 4
+#pragma unroll
         for (int n = 0; n < NX; n += 2) {
-            if (c < snsh[n]) e = e + sv[n * MX2 + c] * sp[jj][n][m];
-            if (c < snsh[n + 1]) o = o + sv[(n + 1) * MX2 + c] * sp[jj][n + 1][m];
+            if (c < nsh2_of(n)) e = e + sv[n * MX2 + c] * sp[jj][n][m];
+            if (c < nsh2_of(n + 1)) o = o + sv[(n + 1) * MX2 + c] * sp[jj][n + 1][m];
         }
         sf[2 * jj + 1][c] = e + o;       // northern row il+1-j
         sf[2 * jj][c] = e - o;           // southern row j
     }
+    GSTAMP(3);
     __syncthreads();
+    GSTAMP(4);
     // Fourier synthesis (gridx) of the 31 retained modes, two longitudes per work item: with A = sum_k Re_k cos(k i t)
     // and B = sum_k Im_k sin(k i t),  x_i = a0 + 2(A - B)  and  x_{96-i} = a0 + 2(A + B)   (i = 0..48).
     for (int w = active ? tid : 2 * LATG * (IX / 2 + 1); w < 2 * LATG * (IX / 2 + 1); w += TG) {
@@ -294,6 +316,7 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
         g[row * IX + i] = x0;
         if (i != 0 && i != IX / 2) g[row * IX + IX - i] = x1;
     }
+    GSTAMP(5);
 }
 
 // forward transform: vorg[48][96] -> vorm[32][62]; workgroup = (field, group of MG zonal wavenumbers)
@@ -518,6 +541,8 @@ int sml_spectral_create(double a, sml_spectral **out)
     UP(uvdx, &h.uvdx[0][0], NX * MX); UP(uvdym, &h.uvdym[0][0], NX * MX); UP(uvdyp, &h.uvdyp[0][0], NX * MX);
     UP(vddym, &h.vddym[0][0], NX * MX); UP(vddyp, &h.vddyp[0][0], NX * MX);
 #undef UP
+    for (int n = 0; n < NX && !rc; ++n)
+        if (h.nsh2[n] != nsh2_of(n)) rc = sml::fail(SML_ERR_ARG, "sml_spectral_create: nsh2(%d) = %d, the kernels assume %d", n + 1, h.nsh2[n], nsh2_of(n));
     if (!rc && hipFuncSetAttribute((const void *)k_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS) != hipSuccess)
         rc = sml::fail(SML_ERR_HIP, "sml_spectral_create: cannot reserve %zu bytes of LDS for k_grid", GRID_LDS);
     if (rc) { sml_spectral_destroy(sp); return rc; }
@@ -579,6 +604,13 @@ int sml_spectral_get_table(sml_spectral *sp, int which, double *out, int capacit
     SML_REQUIRE(capacity >= n, "sml_spectral_get_table: capacity %d < %d", capacity, n);
     memcpy(out, src, sizeof(double) * n);
     return n;
+}
+
+int sml_spectral_debug_stamps(unsigned long long *out)      // not part of the C-ABI (no declaration in include/): phase profiling aid
+{
+    SML_HIP(hipDeviceSynchronize());
+    SML_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grid_dbg), sizeof(unsigned long long) * 16));
+    return SML_OK;
 }
 
 int sml_spectral_grid(sml_spectral *sp, const double *vorm, double *vorg, int nf, int kcos, void *stream)
