@@ -197,7 +197,9 @@ def main():
     # "Software pipeline"): measured +6 % only, because the latency-bound SPEEDY kernels slow down 2x next to an
     # HBM-saturating stream; the default is the reference's sequential order.
     model = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode=args.mode,
-                              pipeline=os.environ.get("SML_PIPELINE", "0") == "1", slab=args.slab, physics=not args.no_physics)
+                              pipeline=os.environ.get("SML_PIPELINE", "0") == "1", slab=args.slab, physics=not args.no_physics,
+                              speedy_cus=int(os.environ.get("SML_SPEEDY_CUS", "0")),
+                              persistent_readout=os.environ.get("SML_PERSISTENT_READOUT", "1") == "1")
     if rank == 0:
         print(f"[bench] rank0 loaded {len(regions)} reservoirs in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
 

@@ -38,6 +38,11 @@ int sml_set_device(int ordinal);
 /* device memory for hosts without a HIP binding of their own (the Fortran drop-ins of speedy-ml_amd/fortran/): hipMalloc,
  * hipFree, hipMemset(0), synchronous hipMemcpy in either direction */
 int sml_dev_alloc(uint64_t bytes, void **out_dev);
+/* A HIP stream whose kernels run on a subset of the compute units (hipExtStreamCreateWithCUMask): mask bit i = CU i, nwords
+ * 32-bit words (8 words cover the 256 CUs).  Used by the pipelined hybrid step to keep the HBM-streaming reservoir readout and the
+ * latency-bound SPEEDY window off each other's CUs.  sml_stream_destroy is for streams made here only. */
+int sml_stream_create_cu_mask(const uint32_t *mask, int nwords, void **stream_out);
+int sml_stream_destroy(void *stream);
 int sml_dev_free(void *dev);
 int sml_dev_zero(void *dev, uint64_t bytes);
 int sml_dev_upload(void *dst_dev, const void *src_host, uint64_t bytes);

@@ -47,7 +47,7 @@ class ResSizes(C.Structure):
 # every symbol include/speedyml_hip.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
     "sml_last_error", "sml_version", "sml_device_count", "sml_set_device",
-    "sml_dev_alloc", "sml_dev_free", "sml_dev_zero", "sml_dev_upload", "sml_dev_download",
+    "sml_stream_create_cu_mask", "sml_stream_destroy", "sml_dev_alloc", "sml_dev_free", "sml_dev_zero", "sml_dev_upload", "sml_dev_download",
     "sml_domain_decompose", "sml_domain_region", "sml_domain_sizes", "sml_domain_out_map", "sml_domain_in_map", "sml_domain_message_sizes", "sml_domain_target_map", "sml_find_closest_divisor", "sml_calendar_date", "sml_hours_into_year", "sml_tisr_index",
     "sml_bank_create", "sml_bank_destroy", "sml_bank_load", "sml_bank_load_sparse_win", "sml_bank_set_wout",
     "sml_bank_set_state", "sml_bank_get_state", "sml_bank_set_feedback", "sml_bank_set_local_model",

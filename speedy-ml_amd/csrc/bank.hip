@@ -649,6 +649,21 @@ int sml_set_device(int ordinal)
 }
 
 // device memory for hosts that have no HIP binding of their own (the Fortran drop-ins): plain hipMalloc / hipMemcpy
+int sml_stream_create_cu_mask(const uint32_t *mask, int nwords, void **stream_out)
+{
+    SML_REQUIRE(mask && nwords > 0 && stream_out, "sml_stream_create_cu_mask: bad arguments");
+    hipStream_t st = nullptr;
+    SML_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask));
+    *stream_out = (void *)st;
+    return SML_OK;
+}
+
+int sml_stream_destroy(void *stream)
+{
+    if (stream) SML_HIP(hipStreamDestroy((hipStream_t)stream));
+    return SML_OK;
+}
+
 int sml_dev_alloc(uint64_t bytes, void **out_dev)
 {
     SML_REQUIRE(out_dev, "sml_dev_alloc: null pointer");

@@ -120,7 +120,7 @@ class HybridRank:
 
     def __init__(self, regions, classes, world=1, rank=0, sea_mask=None, mode="hybrid", seed=20240000, n_override=None,
                  leapfrog_steps=LEAPFROG_PER_WINDOW, physical=True, pipeline=False, persistent_readout=True, drain_readout=True,
-                 start_hours=12000 + 24 * 14, slab=False, physics=True):
+                 start_hours=12000 + 24 * 14, slab=False, physics=True, speedy_cus=0):
         import torch
         self.torch = torch
         self.regions, self.classes, self.world, self.rank, self.mode = list(regions), classes, world, rank, mode
@@ -198,7 +198,26 @@ class HybridRank:
             if self.pipeline:
                 # Software pipeline (see step()): the reservoir advance and the state block of the readout of step t+1 run on a
                 # side stream under the SPEEDY window of step t.  Prologue: advance + state block of the first step.
-                self.side = torch.cuda.Stream()
+                self.side, self.main = torch.cuda.Stream(), None
+                if speedy_cus:
+                    # CU partition: the SPEEDY window (and the small exchange kernels) on the first `speedy_cus` compute units, the
+                    # reservoir advance + readout on the rest, so that the HBM-streaming readout never shares a CU with the
+                    # latency-bound window (sml_stream_create_cu_mask)
+                    import ctypes as C
+                    from ._lib import check, lib
+                    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+                    assert 0 < speedy_cus < ncu
+                    words = (ncu + 31) // 32
+
+                    def masked(lo, hi):
+                        m = (C.c_uint32 * words)()
+                        for cu in range(lo, hi):
+                            m[cu // 32] |= 1 << (cu % 32)
+                        h = C.c_void_p()
+                        check(lib().sml_stream_create_cu_mask(m, words, C.byref(h)))
+                        return torch.cuda.ExternalStream(h.value), h
+                    self.main, self._main_h = masked(0, speedy_cus)
+                    self.side, self._side_h = masked(speedy_cus, ncu)
                 self.ev_feedback, self.ev_partial = torch.cuda.Event(), torch.cuda.Event()
                 self.bank.advance(stream=torch.cuda.current_stream())
                 self.bank.readout_part(1, stream=torch.cuda.current_stream())
@@ -385,6 +404,16 @@ class HybridRank:
                 self.slab.update_inputs(self.t, stream=stream)
             return
         assert self.slab is None, "the pipelined schedule does not carry the slab-ocean coupling"
+        if self.main is not None:                               # CU-partitioned form: the whole main leg runs on the masked stream
+            caller = stream
+            self.main.wait_stream(caller)
+            with self.torch.cuda.stream(self.main):
+                self._pipelined_body(self.main)
+            caller.wait_stream(self.main)
+            return
+        self._pipelined_body(stream)
+
+    def _pipelined_body(self, stream):
         stream.wait_event(self.ev_partial)                      # state block of this step's readout (side stream)
         self.bank.readout_part(2, stream=stream)                # + physics-model block -> outvec(t)
         allv = self.exchange_outvec(stream)
