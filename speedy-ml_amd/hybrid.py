@@ -126,6 +126,7 @@ class HybridRank:
         self.regions, self.classes, self.world, self.rank, self.mode = list(regions), classes, world, rank, mode
         self.leapfrog_steps = leapfrog_steps
         self.pipeline = pipeline and mode == "hybrid"
+        self._region_index = None
         self.persistent_readout, self.drain_readout = persistent_readout, drain_readout
         self.bank, self.sizes = build_bank(self.regions, classes, seed=seed, n_override=n_override, physical=physical)
         cap = self.bank.capacity
@@ -336,7 +337,14 @@ class HybridRank:
         """All ranks end up with every region's outvec in region order (the MPI gather-to-root of
         src/mpires.f90:347-454 becomes one RCCL all-gather of the contiguous outvec slab)."""
         if self.world == 1:
-            return self.outvec
+            if len(self.regions) == NREG:
+                return self.outvec
+            # a single rank holding a subset of the regions (development runs: what one rank of an N-GPU job computes): the rows
+            # of the absent regions stay zero instead of being read past the end of the resident slab
+            if self._region_index is None:
+                self._region_index = self.torch.as_tensor(self.regions, dtype=self.torch.long, device=self.outvec.device)
+            self.all_out.index_copy_(0, self._region_index, self.outvec[:len(self.regions)])
+            return self.all_out
         return gather_outvec_slab(self.outvec, self.regions, self.all_out, self.even_split)
 
     def handoff_in(self, stream):
