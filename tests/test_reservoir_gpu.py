@@ -224,3 +224,31 @@ def test_weights_file_roundtrip_to_device(oracle, tmp_path):
     assert np.max(np.abs(bank.get_outvec(0) - out)) <= OUT_TOL * np.max(np.abs(out))
     with pytest.raises(ValueError):
         weights.load_trained_res(bank, 0, path, r.n_model + 1, stat)          # wout columns must be n + n_model
+
+
+def test_prediction_start_sequence(oracle):
+    """initialize_prediction + start_prediction (src/mod_reservoir.f90:791-961) on the device for two reservoirs of one bank: the
+    un-noisy sync from a zero state, the sync of the prediction window continuing from it, then the first feedback / local_model;
+    against the oracle's synchronize and predict on the same columns."""
+    from speedy_ml_amd import prediction
+    rs = [make_reservoir(n=384, d=24, n_model=6, n_out=8, seed=41), make_reservoir(n=200, d=20, n_model=4, n_out=5, seed=42)]
+    bank = ReservoirBank(3, max_d=24, max_n_model=6, max_n_out=8)
+    for i, r in enumerate(rs):
+        load(bank, i + 1, r)                                   # slot 0 stays empty
+        bank.set_state(i + 1, np.full(r.n, 0.3))               # must be reset by initialize_prediction
+    rng = np.random.default_rng(6)
+    timestep, un_noisy, synclength = 6, 360, 84                 # 59 and 13 columns
+    pd1 = [None] + [rng.standard_normal((r.d, un_noisy // timestep)) for r in rs]
+    pd2 = [None] + [rng.standard_normal((r.d, synclength // timestep + 2)) for r in rs]
+    ims = [None] + [rng.standard_normal((r.n_model, synclength // timestep + 2)) for r in rs]
+    assert prediction.initialize_prediction(bank, pd1, timestep, un_noisy_sync=un_noisy) == 59
+    assert prediction.start_prediction(bank, pd2, ims, synclength, timestep) == 13
+    bank.predict(raw=True)
+    torch.cuda.synchronize()
+    for i, r in enumerate(rs):
+        x = oracle.synchronize(r.n, r.d, r.rows, r.cols, r.vals, r.win, 1.0, pd1[i + 1][:, :59], np.zeros(r.n))
+        x = oracle.synchronize(r.n, r.d, r.rows, r.cols, r.vals, r.win, 1.0, pd2[i + 1][:, :13], x)
+        x1, out = oracle.predict_raw(r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, 1.0,
+                                     np.ascontiguousarray(pd2[i + 1][:, 13]), np.ascontiguousarray(ims[i + 1][:, 14]), x)
+        assert np.max(np.abs(bank.get_state(i + 1) - x1)) <= 1e-12
+        assert np.max(np.abs(bank.get_outvec(i + 1) - out)) <= OUT_TOL * np.max(np.abs(out))
