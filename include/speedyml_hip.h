@@ -376,6 +376,10 @@ int sml_dyn_window(sml_dyn *dyn, double *state_dev, int start, int nsteps, doubl
  * sml_dyn_step / sml_dyn_grtend calls and a window's stepone use (the module variable lradsw, src/mod_lflags.f90:22). */
 int sml_dyn_attach_physics(sml_dyn *dyn, sml_phys *phys, int nstrad);
 int sml_dyn_set_lradsw(sml_dyn *dyn, int lradsw);
+/* iogrid(30)'s physical-range guard (src/ppo_iogrid.f90:563-577) without an inverse set of its own: a window that starts with
+ * stepone (start != 0) checks the grids of its first time step -- T, q, u, v of the state just handed over -- and clears
+ * *safe_dev (int32 on the device, set to 1 by the caller) when a value is outside the range or NaN.  NULL switches it off. */
+int sml_dyn_set_range_guard(sml_dyn *dyn, int32_t *safe_dev);
 /* how a time step runs grtend's grid-point part with physics attached: 1 = one fused launch (default), 0 = the grid-point
  * dynamics and sml_phys_tendencies_sfcwind as two launches (same arithmetic; kept so that tests can compare the two) */
 int sml_dyn_select_physics_form(int fused);
@@ -401,6 +405,9 @@ int sml_phys_set_surface(sml_phys *phys, const double *fmask, const double *phis
                          const double *swav, const double *alb_l, const double *alb_s, const double *albsfc, const double *snowc);
 /* the hybrid model's SST grid (G's SST segment, device) becomes sst_am */
 int sml_phys_set_sst_dev(sml_phys *phys, const double *tsea_dev, void *stream);
+/* ... or read in place: later launches take the sea temperature straight from tsea_dev ([48][96] doubles on the device, e.g. the
+ * SST segment of the hybrid state), no copy per step.  NULL returns to the handle's own copy. */
+int sml_phys_bind_sst_dev(sml_phys *phys, const double *tsea_dev);
 /* sol_oz(tyear) (src/phy_radiat.f90:1-83): zonal solar / ozone fields for the day, tyear = fraction of the year */
 int sml_phys_sol_oz(sml_phys *phys, double tyear);
 /* host copies for tests: zonal [6][48] = fsol ozone ozupp zenit stratz sqrt(clat); fband [301][4]; levels [9][9] = sig sigl

@@ -468,6 +468,23 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
     }
 }
 
+// iogrid(30)'s physical-range guard (src/ppo_iogrid.f90:563-577: |u| <= 150, |v| <= 120, 160 <= T <= 330, -6 <= q <= 30 on the
+// grid fields obtained from the truncated spectral state) evaluated on the inverse set of the window's FIRST time step, which holds
+// exactly those fields (T, q, u, v of time level 1): the hand-off then needs no 33-field inverse set of its own.  NaN trips it.
+__global__ void k_range_guard(const double *__restrict__ G, int32_t *__restrict__ safe)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 32 * GR) return;
+    const int var = (t / GR) >> 3;                            // 0 T, 1 q, 2 u, 3 v: fields 16..47 of the dynamics batch
+    const double v = G[(size_t)16 * GR + t];
+    bool bad;
+    if (var == 0) bad = v < 160.0 || v > 330.0;
+    else if (var == 1) bad = v < -6.0 || v > 30.0;
+    else if (var == 2) bad = v < -150.0 || v > 150.0;
+    else bad = v < -120.0 || v > 120.0;
+    if (bad || v != v) *safe = 0;
+}
+
 struct StepArgs {
     int j1, j2, j4, implicit, integrate;
     double dt, eps, wil;
@@ -1128,6 +1145,7 @@ struct sml_dyn {
     double *batch_grid = nullptr;      // [50 + 41][GR]: grtend's inverse set | phypar's inverse set (time level 1)
     sml_phys *phys = nullptr;          // column physics added to the grid-point tendencies (sml_dyn_attach_physics), not owned
     int phys_diag = 1;                 // keep the physics' 2-D diagnostics up to date (sml_phys_diag) during time steps
+    int32_t *guard = nullptr;          // sml_dyn_set_range_guard: flag cleared when the first step's grids leave the physical range
     int nstrad = 3, lradsw = 1;        // short-wave radiation every nstrad-th step; flag of the next sml_dyn_step (mod_lflags.f90:22)
     int32_t *desc_phys = nullptr;      // inverse-batch descriptors with physics: [2 (j2)][91][4], fields relative to the whole state
     double *aux = nullptr;             // xgeop1 | xgeop2 | corf | phis: geopotential operands of the type-7 rows
@@ -1498,6 +1516,13 @@ int sml_dyn_attach_physics(sml_dyn *d, sml_phys *phys, int nstrad)
     return SML_OK;
 }
 
+int sml_dyn_set_range_guard(sml_dyn *d, int32_t *safe_dev)
+{
+    SML_REQUIRE(d, "sml_dyn_set_range_guard: null handle");
+    d->guard = safe_dev;
+    return SML_OK;
+}
+
 int sml_dyn_set_lradsw(sml_dyn *d, int lradsw)
 {
     SML_REQUIRE(d, "sml_dyn_set_lradsw: null handle");
@@ -1542,6 +1567,10 @@ int sml_dyn_window(sml_dyn *d, double *state_dev, int start, int nsteps, double 
         for (size_t i = 0; i < sched.size() && !rc; ++i) {
             rc = sml_dyn_impint(d, sched[i].dt_imp, alph);
             if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st, sched[i].lradsw);
+            if (!rc && i == 0 && start && d->guard) {       // the first step's inverse set is still in batch_grid
+                hipLaunchKernelGGL(k_range_guard, dim3((32 * GR + 255) / 256), dim3(256), 0, st, (const double *)d->batch_grid, d->guard);
+                SML_HIP(hipGetLastError());
+            }
         }
         if (nsteps > 0) d->lradsw = sched.back().lradsw;
         if (!rc) rc = sml_dyn_impint(d, 2 * delt, alph);

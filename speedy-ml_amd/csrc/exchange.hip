@@ -80,6 +80,26 @@ __global__ void k_gather(const ResDesc *__restrict__ descs, const double *__rest
     dst[(size_t)slot * dst_stride + j] = v;
 }
 
+// both gathers of a step (feedback from G, local_model from F) in one launch: blockIdx.z picks the pair of maps
+struct GatherArgs { const double *src; const int32_t *map, *stat; double *dst; int stride; };
+__global__ void k_gather2(const ResDesc *__restrict__ descs, GatherArgs a0, GatherArgs a1, int nslots)
+{
+    const GatherArgs &a = blockIdx.z == 0 ? a0 : a1;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.y;
+    if (j >= a.stride || slot >= nslots) return;
+    const int gi = a.map[(size_t)slot * a.stride + j];
+    if (gi < 0) return;
+    const ResDesc &D = descs[slot];
+    double v = a.src[gi];
+    const int si = a.stat[(size_t)slot * a.stride + j];
+    if (si >= 0) {
+        v = __dsub_rn(v, D.mean[si]);
+        v = v / D.stdv[si];
+    }
+    a.dst[(size_t)slot * a.stride + j] = v;
+}
+
 __global__ void k_pack(const double *__restrict__ slab, int stride, const int32_t *__restrict__ region_of_slot, int nslots,
                        double *__restrict__ all_out)
 {
@@ -249,6 +269,14 @@ int sml_exchange_gather(sml_exchange *ex, const double *g_dev, const double *f_d
     int rc = sml::bank_sync_descs(ex->bank);
     if (rc) return rc;
     hipStream_t st = sml::as_stream(stream);
+    if (g_dev && f_dev) {       // the usual case: one launch for both
+        GatherArgs a0{g_dev, ex->d_in_map, ex->d_in_stat, ex->bank->d_feedback, ex->in_stride};
+        GatherArgs a1{f_dev, ex->d_lm_map, ex->d_lm_stat, ex->bank->d_local_model, ex->lm_stride};
+        dim3 grid((std::max(ex->in_stride, ex->lm_stride) + 127) / 128, ex->nslots, 2);
+        hipLaunchKernelGGL(k_gather2, grid, dim3(128), 0, st, ex->bank->d_descs, a0, a1, ex->nslots);
+        SML_HIP(hipGetLastError());
+        return SML_OK;
+    }
     if (g_dev) {
         dim3 gin((ex->in_stride + 127) / 128, ex->nslots);
         hipLaunchKernelGGL(k_gather, gin, dim3(128), 0, st, ex->bank->d_descs, g_dev, ex->d_in_map, ex->d_in_stat, ex->in_stride, ex->nslots,

@@ -110,6 +110,13 @@ int sml_phys_set_sst_dev(sml_phys *ph, const double *tsea_dev, void *stream)
     return SML_OK;
 }
 
+int sml_phys_bind_sst_dev(sml_phys *ph, const double *tsea_dev)
+{   // sst_am read in place: the kernel takes the sea temperature from the caller's device array (NULL: back to the handle's copy)
+    SML_REQUIRE(ph, "sml_phys_bind_sst_dev: null handle");
+    ph->dev.tsea = tsea_dev ? tsea_dev : ph->surf + 3 * (size_t)smlphys::GR;
+    return SML_OK;
+}
+
 int sml_phys_sol_oz(sml_phys *ph, double tyear)
 {
     SML_REQUIRE(ph, "sml_phys_sol_oz: null handle");

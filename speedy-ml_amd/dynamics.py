@@ -71,6 +71,12 @@ class Dynamics:
         """True (default): grtend's grid-point part and the physics as one two-wave launch; False: two launches (same bits)"""
         check(_lib.lib().sml_dyn_select_physics_form(1 if fused else 0))
 
+    def set_range_guard(self, safe):
+        """iogrid(30)'s range guard on the first time step's grids of every window that starts with stepone; safe: int32 device
+        tensor holding 1 (cleared on violation), or None"""
+        self._guard = safe
+        check(_lib.lib().sml_dyn_set_range_guard(self._h, _lib.ip(safe.data_ptr()) if safe is not None else None))
+
     def set_lradsw(self, flag):
         """the module flag lradsw (src/mod_lflags.f90:22) seen by step()/grtend() and by the stepone part of the next window"""
         check(_lib.lib().sml_dyn_set_lradsw(self._h, 1 if flag else 0))

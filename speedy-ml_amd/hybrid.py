@@ -186,6 +186,7 @@ class HybridRank:
             self.sp.trunct(bc)
             self.phis, self.tcorh, self.qcorh = bc[0].contiguous(), bc[1].contiguous(), torch.zeros((NX, MX2), dtype=f64, device=dev)
             self.dyn.set_boundary(self.phis, self.tcorh, self.qcorh)
+            self.dyn.set_range_guard(self.safe)
             self.phys = None
             if physics:
                 self.init_physics(sea_mask, g4)
@@ -246,6 +247,7 @@ class HybridRank:
         self.surface = dict(fmask=fmask, phis0=phis0, tland=tland, tsea=self.base_sst.cpu().numpy().reshape(IL, IX), swav=np.full((IL, IX), 0.5),
                             alb_l=alb_l, alb_s=alb_s, albsfc=alb_s + fmask * (alb_l - alb_s), snowc=np.zeros((IL, IX)))
         self.phys.set_surface(*[self.surface[k] for k in ("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc")])
+        self.phys.bind_sst(self.G[domain.GS_OFF:domain.GT_OFF])      # sst_am = the hybrid state's SST grid, read in place
         self.phys_day = None
         self.update_forcing()
         self.dyn.attach_physics(self.phys, NSTRAD)
@@ -354,8 +356,10 @@ class HybridRank:
         handoff_to_fields(self.G, self.fields, stream)
         sp.spec_mixed(self.fields, self.in_scale, out=self.raw_spec, stream=stream)
         sp.spec_post(self.raw_spec, self.in_desc, S, stream=stream)
-        self.to_grid(stream)
-        handoff_check(self.fields_out, self.safe, stream)
+        if self.leapfrog_steps is None:                 # no window follows: the guard needs its own inverse set
+            self.to_grid(stream)
+            handoff_check(self.fields_out, self.safe, stream)
+        # else: the window's first time step transforms exactly these fields; the guard reads them there (Dynamics.set_range_guard)
 
     def to_grid(self, stream):
         """uvspec -> grid(.,2) for u,v ; grid(.,1) for t, q, ps  (src/ppo_iogrid.f90:549-561 and 582-593)"""
@@ -370,7 +374,6 @@ class HybridRank:
         self.handoff_in(stream)
         if self.phys is not None:
             self.update_forcing()
-            self.phys.set_sst(self.G[domain.GS_OFF:domain.GT_OFF], stream=stream)
         if self.leapfrog_steps is not None:
             # agcm_init -> stepone, then stloop's first 6-hour window (src/dyn_stloop.f90:24-95 with onehr_hybrid)
             self.dyn.window(self.state, self.leapfrog_steps, start=True, delt=DELT, stream=stream)

@@ -40,6 +40,13 @@ class Physics:
         assert tsea_dev.is_cuda and tsea_dev.numel() == 4608 and tsea_dev.is_contiguous()
         check(_lib.lib().sml_phys_set_sst_dev(self._h, dp(tsea_dev.data_ptr()), vp(stream)))
 
+    def bind_sst(self, tsea_dev):
+        """read the sea temperature in place from a persistent device tensor (None: back to the handle's copy)"""
+        if tsea_dev is not None:
+            assert tsea_dev.is_cuda and tsea_dev.numel() == 4608 and tsea_dev.is_contiguous() and tsea_dev.element_size() == 8
+            self._sst_keep = tsea_dev
+        check(_lib.lib().sml_phys_bind_sst_dev(self._h, dp(tsea_dev.data_ptr()) if tsea_dev is not None else None))
+
     def sol_oz(self, tyear):
         check(_lib.lib().sml_phys_sol_oz(self._h, C.c_double(tyear)))
 

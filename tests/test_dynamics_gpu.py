@@ -244,3 +244,33 @@ def test_window_equals_step_by_step(dyn, oracle, two_kernel, monkeypatch):
         dyn.step(b, 2, 2, 2 * DELT)
     assert torch.equal(a, b)
     check(_lib.lib().sml_dyn_select_window_form(-1))
+
+
+def test_range_guard_on_the_first_steps_grids(dyn, oracle):
+    """sml_dyn_set_range_guard: iogrid(30)'s physical-range check (src/ppo_iogrid.f90:563-577) evaluated on the inverse set of the
+    window's first time step.  A physical state leaves the flag at 1; a 400 K or a 200 m/s patch, or a NaN, clears it; windows
+    that do not start with stepone do not look."""
+    from _oracle import oracle_iogrid30
+    from speedy_ml_amd import synth
+    z = torch.zeros((32, 62), dtype=torch.float64, device="cuda")
+    dyn.set_boundary(z, z, z)
+    safe = torch.ones(1, dtype=torch.int32, device="cuda")
+    dyn.set_range_guard(safe)
+    try:
+        for case, expect in (("ok", 1), ("hot", 0), ("wind", 0), ("nan", 0), ("hot_no_stepone", 1)):
+            g4, logp, _, _ = synth.synthetic_state(3)
+            if case.startswith("hot"):
+                g4[5, 20:24, 30:36, 0] = 400.0
+            if case == "wind":
+                g4[2, 10:14, 50:56, 1] = 200.0
+            lvl = oracle_iogrid30(oracle, g4, logp)
+            st = {k: np.stack([lvl[k], lvl[k]], axis=-1) for k in KEYS}
+            s = to_state(st)
+            if case == "nan":
+                s[0, F_T + 3, 4, 6] = float("nan")
+            safe.fill_(1)
+            dyn.window(s, 1 if case == "hot_no_stepone" else 0, start=(case != "hot_no_stepone"))
+            torch.cuda.synchronize()
+            assert int(safe.item()) == expect, case
+    finally:
+        dyn.set_range_guard(None)
