@@ -180,3 +180,44 @@ def test_pipelined_step_equals_sequential_step():
     torch.cuda.synchronize()
     for s in (0, 17, 1151):
         assert np.max(np.abs(seq.bank.get_state(s) - pip.bank.get_state(s))) <= 1e-11
+
+
+def test_single_gather_launch_equals_the_two_halves(model):
+    """sml_exchange_gather with both sources (one launch) against the feedback-only and the local_model-only calls"""
+    m = model
+    rng = np.random.default_rng(8)
+    G = torch.from_numpy(rng.standard_normal(domain.G_SIZE)).cuda()
+    F = torch.from_numpy(rng.standard_normal(domain.G_SIZE)).cuda()
+    m.ex.gather(G, F)
+    torch.cuda.synchronize()
+    fb, lm = m.feedback.clone(), m.local_model.clone()
+    m.feedback.zero_(); m.local_model.zero_()
+    m.ex.gather(G, None)
+    m.ex.gather(None, F)
+    torch.cuda.synchronize()
+    assert torch.equal(fb, m.feedback) and torch.equal(lm, m.local_model)
+    assert float(fb.abs().max()) > 0 and float(lm.abs().max()) > 0
+
+
+def test_cu_masked_stream_runs_the_bank():
+    """sml_stream_create_cu_mask: a stream restricted to the first 64 compute units computes the same predict as the default stream"""
+    import ctypes as C
+    from speedy_ml_amd import _lib
+    from speedy_ml_amd.reservoir import ReservoirBank
+    r = synth.make_reservoir(n=640, d=64, n_model=12, n_out=16, seed=5)
+    bank = ReservoirBank(1, max_d=64, max_n_model=12, max_n_out=16)
+    bank.load(0, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
+    x0 = np.random.default_rng(1).standard_normal(r.n) * 0.2
+    words = (C.c_uint32 * 8)(0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().sml_stream_create_cu_mask(words, 8, C.byref(h)))
+    try:
+        outs = []
+        for stream in (None, torch.cuda.ExternalStream(h.value)):
+            bank.set_state(0, x0); bank.set_feedback(0, r.feedback); bank.set_local_model(0, r.local_model)
+            bank.predict(stream=stream)
+            torch.cuda.synchronize()
+            outs.append((bank.get_state(0).copy(), bank.get_outvec(0).copy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    finally:
+        _lib.check(_lib.lib().sml_stream_destroy(h))
