@@ -469,6 +469,7 @@ class HybridRank:
             wl += ("; + slab-ocean coupling (config 5): SST assembly from the slab reservoirs, 27-step input averaging ring, "
                    "predict_slab_ml of the SST-predicting regions every 28th step")
         return {"workload": wl, "regions_total": NREG, "regions_this_rank": len(self.regions),
-                "transforms_per_step": (99 + (150 if self.phys is not None else 123) * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
+                "transforms_per_step": ((99 if self.leapfrog_steps is None else 66) + (150 if self.phys is not None else 123)
+                                        * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
                 "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s); "
                                + ("one all-gather of the outvec slab per step" if self.world > 1 else "no collective")}
