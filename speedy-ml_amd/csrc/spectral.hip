@@ -330,6 +330,7 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     __shared__ double sd[IL][IX / 2 + 2];
     __shared__ double twc[MG][IX / 2 + 3], tws[MG][IX / 2 + 3];
     __shared__ double sf[IL][2 * MG];          // this workgroup's Fourier coefficients [lat][re/im of its wavenumbers]
+    GSTAMP(8);
     const int f = blockIdx.x / NMG, mg = blockIdx.x % NMG;
     const int scale = scale_of_field ? scale_of_field[f] : scale_all;
     const int k0 = mg * MG, nk = min(MG, MX - k0);
@@ -349,21 +350,37 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
         twc[kk][i] = T.twc[ph];
         tws[kk][i] = T.tws[ph];
     }
+    GSTAMP(9);
     __syncthreads();
+    GSTAMP(10);
     // forward DFT (specx): a0 = sum x / 96 ; Re_k = sum x cos / 96 ; Im_k = - sum x sin / 96 ; Im of k=0 is set to 0
-    if (threadIdx.x < nk * IL) {
-        const int j = threadIdx.x % IL, kk = threadIdx.x / IL;
-        const double *xs = ss[j], *xd = sd[j], *cc = twc[kk], *sn = tws[kk];
-        double re = 0.0, im = 0.0;
-#pragma unroll 7
-        for (int i = 0; i <= IX / 2; ++i) {
-            re += xs[i] * cc[i];
-            im -= xd[i] * sn[i];          // sd[.][0] = x_0 and sd[.][48] = x_48 meet sin = 0
+    if constexpr (TT == 64 * MG) {
+        // One wavefront per zonal wavenumber, lanes 0..47 = latitudes.  The wavenumber's 49 twiddle pairs are wave-uniform: lane l
+        // keeps pair l and v_readlane broadcasts pair i into scalar registers, so an iteration reads only the two folded data values
+        // from LDS (98 ds_read per thread instead of 196: phase stamps put this phase at 2.7 of a workgroup's 8 us, bound by the
+        // LDS pipe).  Same products in the same order.
+        const int kk = threadIdx.x >> 6, j = threadIdx.x & 63;
+        if (kk < nk) {
+            const double cmine = j <= IX / 2 ? twc[kk][j] : 0.0, smine = j <= IX / 2 ? tws[kk][j] : 0.0;
+            const int clo = __double2loint(cmine), chi = __double2hiint(cmine), slo = __double2loint(smine), shi = __double2hiint(smine);
+            const int jj = j < IL ? j : 0;
+            const double *xs = ss[jj], *xd = sd[jj];
+            double re = 0.0, im = 0.0;
+#pragma unroll
+            for (int i = 0; i <= IX / 2; ++i) {
+                const double ci = __hiloint2double(__builtin_amdgcn_readlane(chi, i), __builtin_amdgcn_readlane(clo, i));
+                const double si = __hiloint2double(__builtin_amdgcn_readlane(shi, i), __builtin_amdgcn_readlane(slo, i));
+                re += xs[i] * ci;
+                im -= xd[i] * si;          // sd[.][0] = x_0 and sd[.][48] = x_48 meet sin = 0
+            }
+            if (j < IL) {
+                const double sc = 1. / (double)IX;
+                sf[j][2 * kk] = re * sc;
+                sf[j][2 * kk + 1] = (k0 + kk == 0) ? 0.0 : im * sc;
+            }
         }
-        const double sc = 1. / (double)IX;
-        sf[j][2 * kk] = re * sc;
-        sf[j][2 * kk + 1] = (k0 + kk == 0) ? 0.0 : im * sc;
     }
+    GSTAMP(11);
     __syncthreads();
     // symmetric / antisymmetric parts times the Gaussian weight, in place (specy :511-517)
     if (threadIdx.x < IY * 2 * MG) {
@@ -373,6 +390,7 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
         sf[j1][cc] = (n_ - s_) * wj;      // dvarm
     }
     __syncthreads();
+    GSTAMP(12);
     // Legendre analysis (specy :519-537): odd n (1-based) use svarm, even n use dvarm, n <= ntrun1, c < nsh2(n);
     // accumulation over latitude in the reference's order -> bit-identical to specy for identical Fourier input.
     // The 24 table loads of a thread are independent and issued together (full unroll).
@@ -381,7 +399,9 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
         const int c = 2 * k0 + cc, m = c >> 1;
         if (cc < 2 * nk) {
             double acc = 0.0;
-            if (n < NTRUN1 && c < T.nsh2[n]) {
+            if (n < NTRUN1 && c < nsh2_of(n)) {
+                // (fetching these 24 table values ahead of the DFT was measured twice: the quadrature and Legendre phases shrink by
+                // 1.4 us per workgroup, the staging and DFT phases grow by as much -- the launch's loads all compete at its start)
                 const double *p = T.pol + (size_t)n * MX + m;
                 double pj[IY];
 #pragma unroll
@@ -397,6 +417,7 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
             v[n * MX2 + c] = acc;
         }
     }
+    GSTAMP(13);
 }
 
 // pointwise / 3-point-in-n spectral operators; one thread per real element [nf][32][62]
