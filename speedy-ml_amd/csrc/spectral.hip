@@ -330,6 +330,7 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     __shared__ double sd[IL][IX / 2 + 2];
     __shared__ double twc[MG][IX / 2 + 3], tws[MG][IX / 2 + 3];
     __shared__ double sf[IL][2 * MG];          // this workgroup's Fourier coefficients [lat][re/im of its wavenumbers]
+    __shared__ double swt[IY];                 // Gaussian weights, staged with the field (a load after the DFT costs a round trip)
     GSTAMP(8);
     const int f = blockIdx.x / NMG, mg = blockIdx.x % NMG;
     const int scale = scale_of_field ? scale_of_field[f] : scale_all;
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
         twc[kk][i] = T.twc[ph];
         tws[kk][i] = T.tws[ph];
     }
+    if (threadIdx.x < IY) swt[threadIdx.x] = T.wt[threadIdx.x];
     GSTAMP(9);
     __syncthreads();
     GSTAMP(10);
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     // symmetric / antisymmetric parts times the Gaussian weight, in place (specy :511-517)
     if (threadIdx.x < IY * 2 * MG) {
         const int cc = threadIdx.x % (2 * MG), j = threadIdx.x / (2 * MG), j1 = IL - 1 - j;
-        const double n_ = sf[j1][cc], s_ = sf[j][cc], wj = T.wt[j];
+        const double n_ = sf[j1][cc], s_ = sf[j][cc], wj = swt[j];
         sf[j][cc] = (n_ + s_) * wj;       // svarm
         sf[j1][cc] = (n_ - s_) * wj;      // dvarm
     }
