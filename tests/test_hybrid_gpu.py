@@ -23,18 +23,24 @@ def model(request):
     return m
 
 
-def oracle_speedy_leg(o, m, G):
+def oracle_speedy_leg(o, m, G, phys=None):
     """iogrid(30), stepone + 24 leapfrog steps, iogrid(31) with the oracle, from the device's hybrid state G.  With the column
-    physics attached, grtend's physics slot is filled with the compiled reference parametrisations (oracle/_ref/libref_phy.so)."""
+    physics attached, grtend's physics slot is filled with the compiled reference parametrisations (oracle/_ref/libref_phy.so);
+    `phys` continues a previous window's hook (short-wave flag and the short-wave scheme's leftovers carry over, as the reference's
+    module variables do).  Returns (F4, F2, phys)."""
     from _oracle import DynOracle, PhysHook, RefPhys, oracle_iogrid30, oracle_iogrid31, oracle_window
-    phys = None
     if m.phys is not None:
         if not RefPhys.available():
             pytest.skip("oracle/_ref/libref_phy.so not present")
-        from speedy_ml_amd.physics import HSG
-        sia = np.asarray(m.sp.table(1)).ravel()
-        surf = dict(m.surface, tsea=G[domain.GS_OFF:domain.GT_OFF])
-        phys = PhysHook(RefPhys(HSG, np.concatenate([-np.arcsin(sia), np.arcsin(sia)[::-1]])), surf, (m.phys_day - 0.5) / 365.0)
+        tyear = (m.phys_day - 0.5) / 365.0
+        if phys is None:
+            from speedy_ml_amd.physics import HSG
+            sia = np.asarray(m.sp.table(1)).ravel()
+            surf = dict(m.surface, tsea=G[domain.GS_OFF:domain.GT_OFF])
+            phys = PhysHook(RefPhys(HSG, np.concatenate([-np.arcsin(sia), np.arcsin(sia)[::-1]])), surf, tyear)
+        else:
+            phys.s["tsea"] = np.ascontiguousarray(G[domain.GS_OFF:domain.GT_OFF], dtype=np.float64)
+            phys.ref.sol_oz(tyear)                     # fordate's daily call (same value when the day has not changed)
     g4 = G[:domain.G2_OFF].reshape(8, 48, 96, 4)
     logp = G[domain.G2_OFF:domain.GP_OFF].reshape(48, 96)
     lvl = oracle_iogrid30(o, g4, logp)
@@ -43,7 +49,7 @@ def oracle_speedy_leg(o, m, G):
     F4, F2 = oracle_iogrid31(o, {k: cur[k][..., 0] for k in cur})
     qv = F4[..., 3]
     qv[qv < 0.000001] = 0.000001
-    return F4, F2
+    return F4, F2, phys
 
 
 def test_hybrid_step_stage_parity(model, oracle):
@@ -82,7 +88,7 @@ def test_hybrid_step_stage_parity(model, oracle):
 
     # ---- stage B: the SPEEDY leg (hand-off in, 26 adiabatic time steps, hand-off out), oracle fed with the device's G.
     # north_star tolerance: 1e-10 relative per field after the 6-hour window
-    F4w, F2w = oracle_speedy_leg(o, m, G)
+    F4w, F2w, hook = oracle_speedy_leg(o, m, G)
     F4g = F[:domain.G2_OFF].reshape(8, 48, 96, 4)
     for var in range(4):
         sc = np.max(np.abs(F4w[..., var]))
@@ -92,6 +98,7 @@ def test_hybrid_step_stage_parity(model, oracle):
     assert int(m.safe.item()) == 1
     assert np.max(np.abs(F4g[..., 1] - G[:domain.G2_OFF].reshape(8, 48, 96, 4)[..., 1])) > 0.5
 
+    m._hook_after_first_window = hook
     # ---- stage C: next inputs, oracle tilers fed with the device's G and F: bit-exact ----
     fb1 = m.feedback.cpu().numpy()
     lm1 = m.local_model.cpu().numpy()
@@ -120,6 +127,24 @@ def test_hybrid_step_stage_parity(model, oracle):
         assert np.array_equal(fb1[s, :b.d], u), s
         lm = o.standardize_res(g, mean, std, o.tile_res(NREG, s, Ff4, Ff2, 132))
         assert np.array_equal(lm1[s, :132], lm), s
+
+
+def test_second_window_carries_the_shortwave_state(model, oracle):
+    """The second hybrid step's SPEEDY leg: stepone now runs with the short-wave flag as the first window's last leapfrog step left
+    it (.false.: mod(24,3) /= 1) and with that window's last short-wave results (transmissivities, heating, surface flux) -- the
+    reference's module variables -- on both sides.  Must follow test_hybrid_step_stage_parity (module-scoped model)."""
+    m, o = model, oracle
+    if m.t != 1 or not hasattr(m, "_hook_after_first_window"):
+        pytest.skip("needs the state left by test_hybrid_step_stage_parity")
+    m.step(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    G, F = m.G.cpu().numpy(), m.F.cpu().numpy()
+    F4w, F2w, _ = oracle_speedy_leg(o, m, G, phys=m._hook_after_first_window)
+    F4g = F[:domain.G2_OFF].reshape(8, 48, 96, 4)
+    for var in range(4):
+        sc = np.max(np.abs(F4w[..., var]))
+        assert np.max(np.abs(F4g[..., var] - F4w[..., var])) <= 1e-10 * sc, (var, np.max(np.abs(F4g[..., var] - F4w[..., var])) / sc)
+    assert np.max(np.abs(F[domain.G2_OFF:domain.GP_OFF].reshape(48, 96) - F2w)) <= 1e-10 * np.max(np.abs(F2w))
 
 
 def test_safety_guard_trips(model):
