@@ -84,6 +84,26 @@ int main()
         CK(hipMemcpy(out.data(), buf + (size_t)((phases - 1) & 1) * nwg * n_per_wg, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
         good = true; for (double v : out) good = good && v == (double)phases;
         printf("launches  : %d phases %.1f us = %.2f us per phase  values %s\n", phases, ms * 1e3, ms * 1e3 / phases, good ? "ok" : "WRONG");
+        // the same launches captured once into a hipGraph and replayed
+        static hipGraphExec_t exec = nullptr;
+        static hipStream_t cs = nullptr;
+        if (!exec) {
+            hipGraph_t graph;
+            CK(hipStreamCreate(&cs));
+            CK(hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal));
+            for (int ph = 0; ph < phases; ++ph) hipLaunchKernelGGL(k_phase, dim3(nwg), dim3(512), 0, cs, buf, n_per_wg, ph);
+            CK(hipStreamEndCapture(cs, &graph));
+            CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        }
+        CK(hipMemset(buf, 0, sizeof(double) * 2 * nwg * n_per_wg));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, cs));
+        CK(hipGraphLaunch(exec, cs));
+        CK(hipEventRecord(e1, cs)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpy(out.data(), buf + (size_t)((phases - 1) & 1) * nwg * n_per_wg, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
+        good = true; for (double v : out) good = good && v == (double)phases;
+        printf("hipGraph  : %d phases %.1f us = %.2f us per phase  values %s\n", phases, ms * 1e3, ms * 1e3 / phases, good ? "ok" : "WRONG");
     }
     return 0;
 }
