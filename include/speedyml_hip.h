@@ -328,9 +328,9 @@ void invlap_(const double *vorm, double *strm);
 void trunct_(double *vor);
 
 /* ===================================================================================================
- * 4a. SPEEDY adiabatic time step on the device -- replaces, inside the hybrid window between iogrid(30) and
- *     iogrid(31), src/dyn_step.f90 (step, hordif, timint), src/dyn_grtend.f90 (without its phypar call: the column
- *     physics is out of scope), src/dyn_sptend.f90, src/dyn_geop.f90, src/dyn_implic.f90, and the set-up routines
+ * 4a. SPEEDY time step on the device -- replaces, inside the hybrid window between iogrid(30) and
+ *     iogrid(31), src/dyn_step.f90 (step, hordif, timint), src/dyn_grtend.f90 (its phypar call included once a physics
+ *     handle of section 4c is attached; the adiabatic core otherwise), src/dyn_sptend.f90, src/dyn_geop.f90, src/dyn_implic.f90, and the set-up routines
  *     src/ini_indyns.f90, src/ini_impint.f90 (+ src/spe_matinv.f90), src/ini_stepone.f90, src/dyn_stloop.f90:28-43.
  *     State (device, caller-owned): double state[2][33][32][62] = time level (mod_dynvar.f90's last index), then the
  *     fields vor(8) | div(8) | t(8) | tr(:,:,:,1)(8) | ps, each a Fortran complex (mx,nx) array.

@@ -9,10 +9,10 @@
     gather + standardise next inputs                src/mpires.f90:580-775
 
 Everything runs through libspeedyml_hip.so; torch is used only for device buffers, streams and
-torch.distributed (RCCL).  The SPEEDY leg is the adiabatic dynamical core on the device (speedy-ml_amd/csrc/dynamics.hip):
-every spectral transform, the grid-point tendencies, the semi-implicit spectral step and the leapfrog of the 26 time steps
-of a window.  SPEEDY's column physics (phypar, ~25 routines of parametrisations) is out of scope and
-is not called, so the forecast handed back to the reservoirs is the dry-dynamics forecast (DESIGN.md "What a bench step is").
+torch.distributed (RCCL).  The SPEEDY leg runs on the device (speedy-ml_amd/csrc/dynamics.hip, physics_dev.h): every spectral
+transform, the grid-point tendencies with phypar's column physics (convection, condensation, clouds, radiation, surface fluxes,
+vertical diffusion; physics=False gives the adiabatic core), the semi-implicit spectral step and the leapfrog of the 26 time
+steps of a window (DESIGN.md "What a bench step is").
 """
 import numpy as np
 
