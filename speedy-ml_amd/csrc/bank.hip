@@ -569,7 +569,9 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
     int variant = forced;
     if (variant < 0) {
         const int groups = nres8 * ((b->max_n_out_loaded + 16) / 17);       // workgroups of the one-wavefront form
-        variant = groups >= 4608 ? 7 : (groups >= 2304 ? 4 : (groups >= 1152 ? 13 : 1));
+        // (after the row stride was padded to whole lines: <8,64> matches <17,64> at 576-1152 reservoirs within the box-to-box noise
+        // and beats the column-split forms below that: 288 reservoirs 0.333 ms, 144 reservoirs 0.172-0.180 against 0.191 ms)
+        variant = groups >= 4608 ? 7 : 11;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = b->timing && !(flags & 4);       // the small physics-model block (part 2) is not the roofline kernel
@@ -622,6 +624,9 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
     case 11: RO_LAUNCH(8, 64, true) break;
     case 12: RO_LAUNCH(34, 64, true) break;
     case 13: RO_LAUNCH(17, 256, true) break;
+    case 14: RO_LAUNCH(4, 64, true) break;
+    case 15: RO_LAUNCH(8, 64, false) break;
+    case 16: RO_LAUNCH(6, 64, true) break;
     case 0: RO_LAUNCH(RO_ROWS, 256, true) break;
     default: RO_LAUNCH(RO_ROWS, 64, true) break;
     }
