@@ -5,8 +5,9 @@
 
 A "step" is one pass of the hot path over the 1152 local reservoirs of the T30L8 hybrid model (BASELINE.json
 config 3): batched predict of every resident reservoir, the region exchange (pack / all-gather over RCCL when
-N>1 / scatter + clamps), the SPEEDY hand-off and the 6-hour SPEEDY window on the device (26 time steps: spectral transforms,
-grid-point tendencies with the column physics, semi-implicit spectral step), and the gather + standardisation of the next inputs.  Regions are sharded over ranks exactly as processor_decomposition does
+N>1 / scatter + clamps), the SPEEDY hand-off and the 6-hour SPEEDY window on the device (26 time steps: spectral
+transforms, grid-point tendencies with the column physics, semi-implicit spectral step), and the gather + standardisation
+of the next inputs.  Regions are sharded over ranks exactly as processor_decomposition does
 (src/res_domain.f90:31-62); the only data-path collective is the all-gather of the outvec slab.  Inputs are
 synthetic (seeded, ERA5-shaped) and resident in HBM before the timed region starts.
 

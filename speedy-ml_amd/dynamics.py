@@ -1,4 +1,5 @@
-"""Host-side mirror of SPEEDY's time stepping (adiabatic core; with attach_physics the column physics of grtend as well) (src/dyn_step.f90, dyn_grtend.f90, dyn_sptend.f90, dyn_implic.f90,
+"""Host-side mirror of SPEEDY's time stepping: the adiabatic core and, with attach_physics, the column physics of grtend
+(src/dyn_step.f90, dyn_grtend.f90, dyn_sptend.f90, dyn_implic.f90,
 dyn_geop.f90, ini_indyns.f90, ini_impint.f90, ini_stepone.f90, dyn_stloop.f90) over the C-ABI.
 
 Same names and argument meaning as the Fortran subroutines (impint, step, stepone, grtend); the model state lives on the

@@ -393,7 +393,8 @@ class HybridRank:
 
         Sequential form (pipeline=False), the reference's order of program main's loop body:
             predict -> exchange -> scatter -> SPEEDY leg -> gather(feedback, local_model)
-        Pipelined form (pipeline=True; measured +6 % on MI355X, off by default): the reservoir state of step t+1 depends only on the feedback, i.e. on the hybrid state G(t),
+        Pipelined form (pipeline=True; measured +6 % on MI355X, off by default): the reservoir state of step t+1 depends only
+        on the feedback, i.e. on the hybrid state G(t),
         which is complete BEFORE the SPEEDY window of step t starts; only the 132 physics-model columns of W_out wait for the
         forecast.  So  advance(t+1) + W_out[:, state columns] x~(t+1)  (99 % of the step's HBM bytes) run on a side stream
         concurrently with the SPEEDY leg of step t (26 time steps of small latency-bound kernels), and the step closes with

@@ -17,7 +17,8 @@ class Physics:
     def __init__(self, rlat, hsg=HSG):
         """rlat: the 48 Gaussian latitudes in radians, south to north (radang of src/ini_indyns.f90:72-80)"""
         h = C.c_void_p()
-        check(_lib.lib().sml_phys_create(dp(np.ascontiguousarray(hsg, dtype=np.float64)), dp(np.ascontiguousarray(rlat, dtype=np.float64)), C.byref(h)))
+        hsg, rlat = np.ascontiguousarray(hsg, dtype=np.float64), np.ascontiguousarray(rlat, dtype=np.float64)
+        check(_lib.lib().sml_phys_create(dp(hsg), dp(rlat), C.byref(h)))
         self._h = h
 
     def close(self):
