@@ -380,6 +380,9 @@ int sml_dyn_set_lradsw(sml_dyn *dyn, int lradsw);
  * stepone (start != 0) checks the grids of its first time step -- T, q, u, v of the state just handed over -- and clears
  * *safe_dev (int32 on the device, set to 1 by the caller) when a value is outside the range or NaN.  NULL switches it off. */
 int sml_dyn_set_range_guard(sml_dyn *dyn, int32_t *safe_dev);
+/* whether time steps keep the physics' 2-D diagnostics (sml_phys_diag: precipitation, fluxes, cloud cover ...) up to date: on by
+ * default; a host that does not read them between windows can switch the 18 stores per column and step off */
+int sml_dyn_physics_diag(sml_dyn *dyn, int on);
 /* how a time step runs grtend's grid-point part with physics attached: 1 = one fused launch (default), 0 = the grid-point
  * dynamics and sml_phys_tendencies_sfcwind as two launches (same arithmetic; kept so that tests can compare the two) */
 int sml_dyn_select_physics_form(int fused);

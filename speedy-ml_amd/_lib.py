@@ -64,7 +64,7 @@ EXPORTS = [
     "parmtr_", "inifft_", "grid_", "spec_", "vdspec_", "uvspec_", "vds_", "grad_", "lap_", "invlap_", "trunct_",
     "sml_dyn_create", "sml_dyn_destroy", "sml_dyn_impint", "sml_dyn_get_table", "sml_dyn_set_boundary", "sml_dyn_state_dev",
     "sml_dyn_set_state_host", "sml_dyn_get_state_host", "sml_dyn_set_boundary_host", "sml_dyn_grtend",
-    "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_attach_physics", "sml_dyn_set_lradsw", "sml_dyn_set_range_guard", "sml_dyn_select_physics_form", "sml_dyn_select_window_form",
+    "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_attach_physics", "sml_dyn_set_lradsw", "sml_dyn_set_range_guard", "sml_dyn_physics_diag", "sml_dyn_select_physics_form", "sml_dyn_select_window_form",
     "sml_phys_create", "sml_phys_destroy", "sml_phys_set_surface", "sml_phys_set_sst_dev", "sml_phys_bind_sst_dev", "sml_phys_sol_oz", "sml_phys_get_tables",
     "sml_phys_tendencies", "sml_phys_tendencies_sfcwind", "sml_phys_diag",
     "sml_makesparse", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",

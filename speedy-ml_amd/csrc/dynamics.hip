@@ -1516,6 +1516,13 @@ int sml_dyn_attach_physics(sml_dyn *d, sml_phys *phys, int nstrad)
     return SML_OK;
 }
 
+int sml_dyn_physics_diag(sml_dyn *d, int on)
+{
+    SML_REQUIRE(d, "sml_dyn_physics_diag: null handle");
+    d->phys_diag = on ? 1 : 0;
+    return SML_OK;
+}
+
 int sml_dyn_set_range_guard(sml_dyn *d, int32_t *safe_dev)
 {
     SML_REQUIRE(d, "sml_dyn_set_range_guard: null handle");

@@ -72,6 +72,10 @@ class Dynamics:
         """True (default): grtend's grid-point part and the physics as one two-wave launch; False: two launches (same bits)"""
         check(_lib.lib().sml_dyn_select_physics_form(1 if fused else 0))
 
+    def physics_diag(self, on):
+        """keep (default) or skip the physics' 2-D diagnostics during time steps"""
+        check(_lib.lib().sml_dyn_physics_diag(self._h, 1 if on else 0))
+
     def set_range_guard(self, safe):
         """iogrid(30)'s range guard on the first time step's grids of every window that starts with stepone; safe: int32 device
         tensor holding 1 (cleared on violation), or None"""

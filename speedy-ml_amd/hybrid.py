@@ -250,7 +250,7 @@ class HybridRank:
         self.phys.bind_sst(self.G[domain.GS_OFF:domain.GT_OFF])      # sst_am = the hybrid state's SST grid, read in place
         self.phys_day = None
         self.update_forcing()
-        self.dyn.attach_physics(self.phys, NSTRAD)
+        self.dyn.attach_physics(self.phys, NSTRAD)       # diagnostics stay on: skipping their stores changes nothing measurable
 
     def update_forcing(self):
         """fordate's daily call of sol_oz(tyear), tyear = (day of the 365-day year - 0.5) / 365 (src/ini_fordate.f90:47-50 with
