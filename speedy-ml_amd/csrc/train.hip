@@ -357,10 +357,9 @@ __global__ __launch_bounds__(PT) void k_panel(double *__restrict__ w, int n, int
 constexpr int SW = 6, PBT = 512, RPT = 12;       // 96 doubles of the sub-panel per thread: needs the 256-VGPR budget of 8 waves per CU
 __global__ __launch_bounds__(PBT) void k_panel_blocked(double *__restrict__ w, int n, int k0, int nb, int *__restrict__ ipiv, int *__restrict__ info)
 {
-    __shared__ double sval[PBT / 64];
-    __shared__ int sidx[PBT / 64];
-    __shared__ int spiv;
-    __shared__ double rowP[SW], rowC[SW];       // the rows being interchanged (sub-panel columns); rowP is the pivot row afterwards
+    __shared__ double sval[2 * (PBT / 64)];     // per-wave maxima, double-buffered by column parity (one barrier per reduction)
+    __shared__ int sidx[2 * (PBT / 64)];
+    __shared__ double rowPC[2][2][SW];          // [column parity][pivot row | current row][sub-panel column]: the rows being interchanged
     __shared__ double l11[SW][SW];              // unit-lower factor of the sub-panel's diagonal block
     __shared__ double u12[SW][LU_NB];           // the sub-panel's rows of the panel's remaining columns, eliminated
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -393,18 +392,21 @@ __global__ __launch_bounds__(PBT) void k_panel_blocked(double *__restrict__ w, i
                     const int oi = __shfl_xor(bi, o, 64);
                     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
                 }
-                if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+                if (lane == 0) { sval[(j & 1) * (PBT / 64) + wave] = best; sidx[(j & 1) * (PBT / 64) + wave] = bi; }
                 __syncthreads();
+                // every thread finishes the reduction for itself (8 LDS broadcasts): no second barrier for a shared result
+                double b2 = sval[(j & 1) * (PBT / 64)]; int p = sidx[(j & 1) * (PBT / 64)];
+#pragma unroll
+                for (int q = 1; q < PBT / 64; ++q) {
+                    const double sv = sval[(j & 1) * (PBT / 64) + q];
+                    const int si = sidx[(j & 1) * (PBT / 64) + q];
+                    if (sv > b2 || (sv == b2 && si < p)) { b2 = sv; p = si; }
+                }
                 if (tid == 0) {
-                    double b2 = sval[0]; int i2 = sidx[0];
-                    for (int q = 1; q < PBT / 64; ++q)
-                        if (sval[q] > b2 || (sval[q] == b2 && sidx[q] < i2)) { b2 = sval[q]; i2 = sidx[q]; }
-                    spiv = i2;
-                    ipiv[col] = i2;
+                    ipiv[col] = p;
                     if (b2 == 0.0 && *info == 0) *info = col + 1;
                 }
-                __syncthreads();
-                const int p = spiv;
+                double *rowP = rowPC[j & 1][0], *rowC = rowPC[j & 1][1];
                 // interchange rows col <-> p: inside the sub-panel through LDS, in the panel's other columns in memory
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
@@ -418,12 +420,14 @@ __global__ __launch_bounds__(PBT) void k_panel_blocked(double *__restrict__ w, i
                         for (int jj = 0; jj < SW; ++jj) rowC[jj] = a[i][jj];
                     }
                 }
+                __syncthreads();
+                // (the panel's other columns: in memory, by one thread each; issued after the barrier so that its round trip
+                // runs under the elimination below instead of holding everybody at the barrier)
                 if (tid < nb && (tid < c0 || tid >= c0 + sw) && p != col) {
                     double *q = w + (long)(k0 + tid) * n;
                     const double x = q[col], y = q[p];
                     q[col] = y; q[p] = x;
                 }
-                __syncthreads();
                 if (p != col) {
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
@@ -452,7 +456,8 @@ __global__ __launch_bounds__(PBT) void k_panel_blocked(double *__restrict__ w, i
                         }
                     }
                 }
-                __syncthreads();                            // rowP / rowC are reused by the next column
+                // no barrier here: the next column uses the other halves of sval / sidx / rowPC, and its first barrier orders
+                // everything else
             }
         }
         // the sub-panel goes back to memory; its diagonal block's L part is shared for the elimination of the remaining columns
