@@ -30,8 +30,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="hybrid", choices=["hybrid", "sweep"],
-                    help="sweep = reservoir predict sweep only (development aid; the driver uses the default)")
+    ap.add_argument("--mode", default="hybrid", choices=["hybrid", "sweep", "ml_only"],
+                    help="sweep = reservoir predict sweep only; ml_only = the reference's ML-only forecast loop (predict_ml + exchange, no "
+                         "SPEEDY); development aids, the driver uses the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true", help="BASELINE config 5: add the 1152-region slab-ocean reservoirs and their coupling")
     ap.add_argument("--no-physics", action="store_true", help="adiabatic SPEEDY window (development aid: isolates the cost of the column physics)")

@@ -38,7 +38,7 @@ def region_classes(sea_mask):
     return out
 
 
-def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, physical=True):
+def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, physical=True, ml_only=False):
     """Load one synthetic trained reservoir per region into a ReservoirBank (slot i <-> regions[i]).
 
     One base reservoir is generated per size class and shared by the regions of the class (each slot still owns
@@ -56,8 +56,9 @@ def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, 
         n = s.n if n_override is None else n_override * d
         key = (n, d)
         if key not in base:
-            b = make_reservoir(n=n, d=d, n_model=s.chunk_size_speedy, n_out=s.chunk_size_prediction,
-                               seed=seed + len(base), dense_win=False, passthrough=physical)
+            # ml_only: chunk_size_speedy = 0 (predict_ml, src/mod_reservoir.f90:1491-1535): W_out acts on the reservoir state alone
+            b = make_reservoir(n=n, d=d, n_model=0 if ml_only else s.chunk_size_speedy, n_out=s.chunk_size_prediction,
+                               seed=seed + len(base), dense_win=False, passthrough=physical and not ml_only)
             b.win_rows = np.arange(1, n + 1, dtype=np.int32)
             b.win_cols = (np.arange(n, dtype=np.int32) // b.win_q + 1).astype(np.int32)
             base[key] = b
@@ -128,7 +129,8 @@ class HybridRank:
         self.pipeline = pipeline and mode == "hybrid"
         self._region_index = None
         self.persistent_readout, self.drain_readout = persistent_readout, drain_readout
-        self.bank, self.sizes = build_bank(self.regions, classes, seed=seed, n_override=n_override, physical=physical)
+        self.bank, self.sizes = build_bank(self.regions, classes, seed=seed, n_override=n_override, physical=physical,
+                                           ml_only=mode == "ml_only")
         cap = self.bank.capacity
         self.feedback = device_view(self.bank.feedback_ptr, (cap, self.bank.max_d))
         self.local_model = device_view(self.bank.local_model_ptr, (cap, self.bank.max_n_model))
@@ -156,7 +158,18 @@ class HybridRank:
         self.start_hours = start_hours
         self.timestep_hours = 6
         self.t = 0
-        if mode == "hybrid":
+        if mode == "ml_only":
+            # the reference's ml_only run (src/parallelmain.f90:229-231, src/mpires.f90:566,588): predict_ml, the same exchange,
+            # no SPEEDY window, no local_model
+            sst_flags = [int(classes[r][1]) for r in self.regions]
+            self.ex = Exchange(self.bank, NREG, self.regions, sst_flags)
+            self.all_out = torch.zeros((NREG, self.bank.max_n_out), dtype=f64, device=dev)
+            self.even_split = (NREG % world == 0)
+            self.slab = self.phys = None
+            self.leapfrog_steps = None
+            self.G[domain.GT_OFF:] = self.tisr_slice(0).reshape(-1)
+            self.ex.gather(self.G, None)
+        elif mode == "hybrid":
             sst_flags = [int(classes[r][1]) for r in self.regions]
             self.ex = Exchange(self.bank, NREG, self.regions, sst_flags)
             self.sp = Spectral()
@@ -403,6 +416,13 @@ class HybridRank:
         if self.mode == "sweep":
             self.bank.predict(stream=stream)
             return
+        if self.mode == "ml_only":
+            self.bank.predict(stream=stream)                     # predict_ml of every resident reservoir
+            allv = self.exchange_outvec(stream)
+            self.scatter_all(allv, stream)
+            self.next_tisr()
+            self.ex.gather(self.G, None, stream=stream)          # feedback only: there is no forecast to tile
+            return
         if not self.pipeline:
             self.bank.predict(stream=stream)
             if self.slab is not None and self.slab.due(self.t + 1):      # mod(t*timestep, timestep_slab) == 0, parallelmain.f90:238
@@ -458,6 +478,8 @@ class HybridRank:
     def describe(self):
         if self.mode == "sweep":
             wl = "config3 sweep-only: batched predict of the rank's resident reservoirs"
+        elif self.mode == "ml_only":
+            wl = "ML-only forecast loop: batched predict_ml of the rank's resident reservoirs + region exchange, no SPEEDY window"
         else:
             nst = 0 if self.leapfrog_steps is None else self.leapfrog_steps + 2
             wl = ("BASELINE config 3: 1152-reservoir batched predict + region exchange (scatter, clamps, gather, standardise) "

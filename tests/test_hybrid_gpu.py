@@ -246,3 +246,58 @@ def test_cu_masked_stream_runs_the_bank():
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     finally:
         _lib.check(_lib.lib().sml_stream_destroy(h))
+
+
+def test_ml_only_step_stage_parity(oracle):
+    """The reference's ml_only loop (src/parallelmain.f90:229-231, src/mpires.f90:566,588): predict_ml for every region, the same
+    scatter + clamps, no SPEEDY window, feedback gathered from the assembled state.  Two steps against the oracle."""
+    o = oracle
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    m = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="ml_only", n_override=1, physical=False)
+    stream = torch.cuda.current_stream()
+    for step in range(2):
+        torch.cuda.synchronize()
+        fb0 = m.feedback.cpu().numpy().copy()
+        x0 = [m.bank.get_state(s) for s in range(NREG)]
+        m.step(stream)
+        torch.cuda.synchronize()
+        G = m.G.cpu().numpy()
+        g4, g2, gp = np.zeros(147456), np.zeros(4608), np.zeros(4608)
+        for s in range(NREG):
+            b, mean, std, stat = m.bank.host_copies[s]
+            assert b.n_model == 0
+            win = np.zeros((b.n, b.d), order="F")
+            win[np.arange(b.n), b.win_cols - 1] = b.win_vals
+            xw, out = o.predict_raw(b.n, b.d, 0, b.n_out, b.rows, b.cols, b.vals, win, b.wout, 1.0, fb0[s, :b.d].copy(), None, x0[s])
+            g = o.initializedomain(NREG, s)
+            out = o.unstandardize_res(g, mean, std, out)
+            o.scatter_res(NREG, s, out, g4, g2, gp)
+            if s % 131 == 0:
+                assert np.max(np.abs(m.bank.get_state(s) - xw)) <= 1e-13
+        G4 = g4.reshape(8, 48, 96, 4)
+        G4[..., 3][G4[..., 3] < 0.000001] = 0.000001
+        gp[gp < 0.00001] = 0.0
+        sst = np.maximum(m.base_sst.cpu().numpy(), 272.0)
+        want = np.concatenate([g4, g2, gp, sst])
+        got = G[:domain.GT_OFF]
+        assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)) <= 1e-11, step
+        # next feedback: oracle tilers on the device's G, bit-exact
+        fb1 = m.feedback.cpu().numpy()
+        Gg4, Gg2 = np.ascontiguousarray(G[:domain.G2_OFF]), np.ascontiguousarray(G[domain.G2_OFF:domain.GP_OFF])
+        Ggp, Ggs = np.ascontiguousarray(G[domain.GP_OFF:domain.GS_OFF]), np.ascontiguousarray(G[domain.GS_OFF:domain.GT_OFF])
+        Ggt = np.ascontiguousarray(G[domain.GT_OFF:])
+        for s in range(0, NREG, 7):
+            b, mean, std, stat = m.bank.host_copies[s]
+            sst_in = classes[s][1]
+            g = o.initializedomain(NREG, s)
+            sz = o.allocate_sizes(g, sst_input=int(sst_in))
+            u = np.zeros(sz.reservoir_numinputs)
+            u[:sz.precip_end] = o.tile_input(NREG, s, Gg4, Gg2, Ggp, sz.precip_end)
+            in2d = g.inputxchunk * g.inputychunk
+            u = o.standardize_input(g, sz, mean, std, u)
+            u[sz.precip_start - 1:sz.precip_end] = (u[sz.precip_start - 1:sz.precip_end] - mean[34]) / std[34]
+            if sst_in:
+                u[sz.sst_start - 1:sz.sst_end] = (o.tile_input2d(NREG, s, Ggs, in2d) - mean[35]) / std[35]
+            u[sz.tisr_start - 1:sz.tisr_end] = (o.tile_input2d(NREG, s, Ggt, in2d) - mean[33]) / std[33]
+            assert np.array_equal(fb1[s, :b.d], u), (step, s)
