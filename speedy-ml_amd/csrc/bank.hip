@@ -43,11 +43,16 @@ __device__ __forceinline__ void decode_block(int id, int parts, int res_begin, i
     res = res_begin + (t / parts) * 8 + xcd;
 }
 
+struct TrainSlot { double *states; int n; };      // a slot's states(n, .) buffer of the training pass (NULL: slot not trained)
+
 // x_new = (1-leak) x + leak tanh([A|Win] [x;u])        (src/mod_reservoir.f90:1444-1448)
+// train_slots (optional): the training pass also wants the new state as column train_col of the slot's states buffer, in the
+// REFERENCE's row order with the even (1-based) rows squared (src/mod_reservoir.f90:1133) -- stored from here, one launch less
+// per time column than a separate copy kernel.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
                                                      int parts, const double *__restrict__ u_all, int u_stride, int cur, int square_input,
-                                                     int whole_blocks)
+                                                     int whole_blocks, const TrainSlot *__restrict__ train_slots, int train_col)
 {
     // Work split: the first whole_blocks workgroups take one reservoir each (x staged once per reservoir); the remaining
     // reservoirs -- the ragged last round of the chip's resident workgroups -- are cut into `parts` slice ranges so that the
@@ -118,14 +123,21 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
         }
         if (r < D.n) {
             const double xt = tanh(acc);
-            xn[r] = (1.0 - D.leak) * (square_input ? x[r] : xu[r]) + D.leak * xt;
+            const double v = (1.0 - D.leak) * (square_input ? x[r] : xu[r]) + D.leak * xt;
+            xn[r] = v;
+            if (train_slots) {
+                const TrainSlot t = train_slots[res];
+                if (t.states) {
+                    const int rr = D.perm[r];              // device position -> reference row (same parity)
+                    t.states[(size_t)train_col * D.n + rr] = (rr & 1) ? v * v : v;
+                }
+            }
         }
     }
 }
 
 // states(:, col) <- x with the even (1-based) rows squared, in the REFERENCE's row order (src/mod_reservoir.f90:1133):
 // the Gram matrices and W_out are defined over the reference's state indices.  One workgroup row per slot.
-struct TrainSlot { double *states; int n; };
 __global__ void k_store_state(const ResDesc *__restrict__ descs, const TrainSlot *__restrict__ ts, int nslots, int col, int cur)
 {
     const int slot = blockIdx.y;
@@ -506,7 +518,8 @@ int download_state(const HostRes &R, const double *src, double *x_host)
     return SML_OK;
 }
 
-int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st, int square_input = 0)
+int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st, int square_input = 0,
+                  const TrainSlot *train_slots = nullptr, int train_col = 0)
 {
     // 512-thread workgroups: three per CU (3 x 50.7 KB LDS, 24 waves).  A workgroup's life is latency-bound (29 us for a whole
     // reservoir on an idle chip: staging + ~11 dependent slice batches per wave) and staging [x ; u] costs 18 us per copy
@@ -547,11 +560,11 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
     if (threads == 1024)
-        hipLaunchKernelGGL(k_update<1024>, dim3(nblocks), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole);
+        hipLaunchKernelGGL(k_update<1024>, dim3(nblocks), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     else if (threads == 256)
-        hipLaunchKernelGGL(k_update<256>, dim3(nblocks), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole);
+        hipLaunchKernelGGL(k_update<256>, dim3(nblocks), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     else
-        hipLaunchKernelGGL(k_update<512>, dim3(nblocks), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole);
+        hipLaunchKernelGGL(k_update<512>, dim3(nblocks), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     SML_HIP(hipGetLastError());
     if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_update.emplace_back(e0, e1); }
     b->cur ^= 1;
@@ -970,9 +983,9 @@ int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int 
     for (int i = 1; i <= training_length - 1 && rc == SML_OK; ++i) {
         // the running (unsquared) state lives in the bank, so "restart from saved_state after a flush" (quirk Q6) is implicit;
         // the ML-only loop instead feeds the squared column into A x on the step after a flush (:1031-1044)
-        rc = launch_update(b, 0, b->capacity, noisy_inputs_dev + step * (discard + i - 1), st, ml_variant && i % batch == 0);
+        rc = launch_update(b, 0, b->capacity, noisy_inputs_dev + step * (discard + i - 1), st, ml_variant && i % batch == 0, d_ts,
+                           pending * batch + i % batch);                  // the new state goes into its states column from the same launch
         if (rc) break;
-        hipLaunchKernelGGL(k_store_state, sgrid, dim3(256), 0, st, b->d_descs, d_ts, b->capacity, pending * batch + i % batch, b->cur);
         if ((i + 1) % batch == 0) {
             ++flushed; ++pending;
             if (pending == group) flush();
