@@ -7,7 +7,7 @@
         gaussian_noise_1d_function[_precip] (src/mod_utilities.f90:1387-1462) -> add_input_noise() (the normal deviates are an input:
                                               the reference's RANDOM_NUMBER stream cannot be reproduced)
         chunking_matmul (:1645-1701): targets = tile_full_input_to_target_data(trainingdata) -> domain.target_map rows
-    fit_chunk_hybrid (:1235-1334)          -> train.fit_chunk_hybrid (LU on the device)
+    fit_chunk_hybrid (:1235-1334)          -> train.fit_chunk_hybrid_batched (LU on the device, size classes solved together)
     write_trained_res (:1703-1737)         -> weights.write_trained_res
 
 All reservoirs of the bank advance together (one launch per time column); passes and batches follow the reference's index
@@ -92,14 +92,18 @@ def train_reservoirs(bank, specs, traininglength, discardlength, timestep, beta_
                 models[slot] = torch.from_numpy(np.ascontiguousarray(np.asarray(sp["imperfect_model"])[:, i::timestep].T)).cuda()
         nb = bank.train_pass(torch.from_numpy(noisy).cuda(), discard, batch, models, targets, cs, bs, stream=stream, ml_variant=ml_only)
         nb_total += nb
-    out = {}
+    # fit_chunk_hybrid for all trained slots: reservoirs of one size class are solved together (up to 8 LU factorisations in
+    # flight: a single factorisation is latency-bound on its panel kernel)
+    out, classes = {}, {}
     for slot, sp in enumerate(specs):
-        if sp is None:
-            continue
-        wout = train.fit_chunk_hybrid(cs[slot], bs[slot], sp["n"], 0 if ml_only else sp["n_model"], sp["n_out"], beta_res, beta_model,
-                                      prior_val, using_prior, stream=stream)
+        if sp is not None:
+            classes.setdefault((sp["n"], 0 if ml_only else sp["n_model"], sp["n_out"]), []).append(slot)
+    for (n, n_model, n_out), slots in classes.items():
+        wouts = train.fit_chunk_hybrid_batched([cs[s] for s in slots], [bs[s] for s in slots], n, n_model, n_out, beta_res, beta_model,
+                                               prior_val, using_prior, stream=stream)
         torch.cuda.synchronize()
-        host = np.asfortranarray(wout.cpu().numpy().T)          # device buffer is column-major (n_out, n_aug) = torch [n_aug, n_out]
-        bank.set_wout(slot, host)
-        out[slot] = dict(wout=host, batch_size=batch, batches=nb_total // timestep)
+        for slot, wout in zip(slots, wouts):
+            host = np.asfortranarray(wout.cpu().numpy().T)      # device buffer is column-major (n_out, n_aug) = torch [n_aug, n_out]
+            bank.set_wout(slot, host)
+            out[slot] = dict(wout=host, batch_size=batch, batches=nb_total // timestep)
     return out
