@@ -171,3 +171,16 @@ def test_target_map_matches_oracle_tiler(oracle, region):
         assert sorted(set(xs.ravel().tolist())) == [2, 3] and sorted(set(ys.ravel().tolist())) == [1, 2]
     # without precipitation the target vector stops after logp
     assert domain.target_map(1152, region, precip_bool=False).size == 132
+
+
+def test_target_map_rejects_bad_arguments():
+    """errors are loud: bad region / level / capacity come back as SML_ERR_ARG with a message (no silent clamping)"""
+    from speedy_ml_amd import _lib
+    buf = np.zeros(16, dtype=np.int32)
+    for args in ((1152, 1152, 1, 1, 1, 0, 1), (1152, -1, 1, 1, 1, 0, 1), (1152, 0, 1, 8, 9, 0, 1)):
+        rc = _lib.lib().sml_domain_target_map(*args, _lib.ip(buf), 4608 * 8)
+        assert rc < 0
+    rc = _lib.lib().sml_domain_target_map(1152, 954, 1, 1, 1, 0, 1, _lib.ip(buf), 16)        # 136 entries do not fit 16
+    assert rc < 0
+    with pytest.raises(Exception):
+        domain.target_map(1152, 5000)
