@@ -268,7 +268,7 @@ def main():
                                        (upd_b / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0), "unit": "GB/s",
                                        "algorithmic_bytes_per_launch": upd_b, "avg_launch_ms": upd_ms}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU baseline is measured at N = 1 only (the other ranks would idle)
             line["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(line), flush=True)
     if world > 1:
