@@ -791,9 +791,14 @@ int sml_bank_set_wout(sml_bank *bank, int slot, const double *wout)
 {
     BANK_SLOT(bank, slot);
     SML_REQUIRE(wout, "sml_bank_set_wout: null wout");
+    // same re-layout as load_common: row-major, state columns in the device (SELL) order of the state vector
+    const std::vector<int> &order = bank->res[slot].order;
+    SML_REQUIRE((int)order.size() == D.n, "sml_bank_set_wout: slot %d has no state order", slot);
     std::vector<double> wrm((size_t)D.n_out * D.n_aug_pad, 0.0);
-    for (int j = 0; j < D.n_aug; ++j)
-        for (int i = 0; i < D.n_out; ++i) wrm[(size_t)i * D.n_aug_pad + j] = wout[(size_t)j * D.n_out + i];
+    for (int jd = 0; jd < D.n_aug; ++jd) {
+        const int j = jd < D.n_model ? jd : D.n_model + order[jd - D.n_model];       // device column jd holds reference column j
+        for (int i = 0; i < D.n_out; ++i) wrm[(size_t)i * D.n_aug_pad + jd] = wout[(size_t)j * D.n_out + i];
+    }
     SML_HIP(hipMemcpy(const_cast<double *>(D.wout), wrm.data(), wrm.size() * sizeof(double), hipMemcpyHostToDevice));
     return SML_OK;
 }

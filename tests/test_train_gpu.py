@@ -158,7 +158,19 @@ def test_device_training_pass_matches_oracle(oracle):
         assert np.max(np.abs(bg - bo)) <= 1e-12 * np.max(np.abs(bo))
     # end to end: fit W_out from the device-accumulated matrices and load it back into the bank
     wout = train.fit_chunk_hybrid(cs[0], bs[0], rs[0].n, rs[0].n_model, rs[0].n_out, 1e-3, 1.0, 0.0, True)
-    bank.set_wout(0, to_host(wout))
+    wh = to_host(wout)
+    bank.set_wout(0, wh)
+    r = rs[0]
+    x0 = rng.standard_normal(r.n) * 0.3
+    bank.set_state(0, x0)
+    bank.set_feedback(0, r.feedback)
+    bank.set_local_model(0, r.local_model)
+    bank.predict()
+    torch.cuda.synchronize()
+    xw, ow = oracle.predict_raw(r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, np.asfortranarray(wh), 1.0, r.feedback,
+                                r.local_model, x0)
+    assert np.max(np.abs(bank.get_state(0) - xw)) <= 1e-13
+    assert np.max(np.abs(bank.get_outvec(0) - ow)) <= 1e-11 * np.max(np.abs(ow))
 
 
 def test_device_training_pass_ml_variant(oracle):

@@ -86,6 +86,19 @@ def test_train_reservoir_end_to_end(oracle, tmp_path):
     lhs = wg @ (cs + np.diag(reg))
     assert np.max(np.abs(lhs - bo)) <= 1e-9 * np.max(np.abs(bo))
 
+    # ---- the trained slot itself predicts with the W_out the fit installed (src/mod_reservoir.f90:1312-1330: predict uses the
+    # fit's wout): sml_bank_set_wout must lay it out in the device's state order ----
+    xs = rng.standard_normal(n) * 0.2
+    us, ms = np.ascontiguousarray(truth[:, 11]), np.ascontiguousarray(model[:, 12])
+    bank.set_state(1, xs)
+    bank.set_feedback(1, us)
+    bank.set_local_model(1, ms)
+    bank.predict()
+    torch.cuda.synchronize()
+    xw, ow = oracle.predict_raw(n, d, n_model, n_out, r.rows, r.cols, r.vals, r.win, wg, 1.0, us, ms, xs)
+    assert np.max(np.abs(bank.get_state(1) - xw)) <= 1e-13
+    assert np.max(np.abs(bank.get_outvec(1) - ow)) <= 1e-11 * np.max(np.abs(ow)), np.max(np.abs(bank.get_outvec(1) - ow)) / np.max(np.abs(ow))
+
     # ---- what was learnt: on the training columns the hybrid readout beats the imperfect model it was given ----
     cl = truth[:, 0::TIMESTEP]
     md = model[:, 0::TIMESTEP]
