@@ -480,6 +480,9 @@ int sml_train_fit(double *c_dev, const double *b_dev, int n, int n_model, int n_
 int sml_train_fit_batched(int count, double *const *c_dev, const double *const *b_dev, int n, int n_model, int n_out,
                           double beta_res, double beta_model, double prior_val, int using_prior, double *const *wout_dev,
                           void *stream);
+/* sml_train_fit[_batched] keep their device scratch (the row-major system, panel buffers, streams: ~310 MB per factorisation in
+ * flight at n_aug = 5892) between calls; this frees it. */
+int sml_train_release_workspace(void);
 
 #ifdef __cplusplus
 }

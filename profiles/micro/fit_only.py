@@ -1,0 +1,21 @@
+"""One 5892 x 5892 (+136 right-hand sides) ridge solve, for rocprofv3 --kernel-trace --stats (config 4's fit_chunk_hybrid)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from __graft_entry__ import load_package
+load_package()
+from speedy_ml_amd import train
+n, n_model, n_out, m = 5760, 132, 136, 2920
+n_aug = n + n_model
+torch.manual_seed(1)
+states = torch.randn((m, n), dtype=torch.float64, device="cuda")
+model = torch.randn((m, n_model), dtype=torch.float64, device="cuda")
+y = torch.randn((m, n_out), dtype=torch.float64, device="cuda")
+c = train.fortran_zeros(n_aug, n_aug); b = train.fortran_zeros(n_out, n_aug)
+for _ in range(3): train.chunking_matmul(states, model, y, c, b)
+torch.cuda.synchronize()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for _ in range(reps):
+    t0 = time.perf_counter()
+    w = train.fit_chunk_hybrid(c, b, n, n_model, n_out)
+    torch.cuda.synchronize()
+    print(f"fit {1e3*(time.perf_counter()-t0):.2f} ms")

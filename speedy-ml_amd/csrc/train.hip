@@ -25,7 +25,6 @@ namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, KT = 16, LDS_LD = 144, GT = 256;
-constexpr int LU_NB = 32;      // LU panel width
 
 // ---- shared pieces of the two GEMM kernels ----
 // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction, 16 cycles, measured 75 TFLOP/s on this part
@@ -129,11 +128,14 @@ __device__ __forceinline__ void stage_write(const double (&v)[8], double (*dst)[
 
 // General kernel (any strides, any K, edge tiles): C[i + j*ldc] += alpha * sum_k A(i,k) * B(j,k).
 // lower_only: skip tiles strictly above the diagonal.
+struct GemmBatch { long sa, sb, sc; };          // element strides between the systems of a batch (blockIdx.z)
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(GT, 2) void k_gemm_acc(const double *__restrict__ A, long sai, long sak, const double *__restrict__ B,
                                                      long sbj, long sbk, double *__restrict__ C, long ldc, int M, int N, int K,
-                                                     double alpha, int lower_only)
+                                                     double alpha, int lower_only, GemmBatch gb)
 {
+    A += gb.sa * blockIdx.z; B += gb.sb * blockIdx.z; C += gb.sc * blockIdx.z;
     __shared__ double As[KT][LDS_LD];
     __shared__ double Bs[KT][LDS_LD];
     const int ti = blockIdx.x, tj = blockIdx.y;
@@ -193,8 +195,12 @@ __device__ __forceinline__ void tri_tile(int L, int &ti, int &tj)
 }
 
 __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
-                                                        double *__restrict__ C, long ldc, int M, int N, int K, double alpha, int mode)
+                                                        double *__restrict__ C, long ldc, int M, int N, int K, double alpha, int mode, int Mr, int Nr,
+                                                        GemmBatch gb)
 {
+    A += gb.sa * blockIdx.z; B += gb.sb * blockIdx.z; C += gb.sc * blockIdx.z;
+    // Mr, Nr: even numbers of READABLE operand rows (>= M, N: a padded operand may be read one row past an odd M or N; those
+    // products only reach rows of C that are never stored)
     __shared__ __attribute__((aligned(16))) double S[NBUF][2][DKT][LDS_LD];       // [ring slot][operand][k][row]  73.7 KB
     int ti, tj;
     if (mode == 0) { ti = blockIdx.x; tj = blockIdx.y; }
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict_
     const int i0 = ti * BM, j0 = tj * BN;
     const WavePos w = wave_pos();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ra = min(i0 + 2 * lane, (M - 2) & ~1), rb = min(j0 + 2 * lane, (N - 2) & ~1);
+    const int ra = min(i0 + 2 * lane, Mr - 2), rb = min(j0 + 2 * lane, Nr - 2);
     const double *pa = A + ra, *pb = B + rb;
     double acc[4][16];
 #pragma unroll
@@ -260,350 +266,675 @@ __global__ void k_symmetrize_diag(double *__restrict__ c, int n)
     }
 }
 
-// W = [ (C + reg)^T | (B + prior)^T ]   (fit_chunk_hybrid :1261-1309); C is symmetric at this point
-__global__ void k_build_system(const double *__restrict__ c, const double *__restrict__ b, double *__restrict__ w, int n_aug, int n_model,
-                               int n_out, double reg_model, double reg_res, double prior_diag)
+// ---------------------------------------------------------------------------------------------------------------------------
+// LU with partial pivoting (dgesv semantics: first maximum of |a| per column, row interchange, scale by the reciprocal pivot)
+// on the row-major system  W[n][ld] = [ (C + reg)^T | (B + prior)^T ]  (ld >= n + n_out).
+//
+// Layout.  A row interchange of a row-major matrix is a contiguous copy, and U12 / the trailing matrix stream along rows; the
+// panel being factorised, however, is searched and eliminated column by column, so the current outer panel (LU_NBO = 128 columns,
+// rows K0..n) lives in a column-major panel buffer P (two of them: the trailing update of panel k still reads its L21 from one
+// while panel k+1 is factorised in the other).  L is never written back: the right-hand sides ride along as extra columns of W, so
+// after the factorisation only U and the transformed right-hand sides are needed (back substitution).
+//
+// Schedule per outer panel (two streams; `P` = panel chain, `G` = everything else):
+//   P: 16 x [ k_lu_leaf   : ONE workgroup factorises 8 columns held entirely in registers (<= 7 rows x 8 columns per thread):
+//                           one global read and one global write of the leaf, two barriers per pivot.  The same workgroup
+//                           applies each interchange to the panel's other columns and finishes U (8 x 120) of the leaf's rows.
+//             k_lu_panel_update : rank-8 update of the panel's remaining columns, all CUs ]
+//   G: k_lu_panel_finish (U11 -> W, the composite permutation of the panel's 128 interchanges), k_lu_swap_gather (the <= 256
+//      affected rows of W's right-hand columns gathered into a scratch through that permutation: no dependent chain of 128 swaps),
+//      k_lu_trsm_scatter (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
+//      K = 128: FIRST the next panel's 128 columns (+ k_lu_strip_to_panel, which hands them to P), THEN the rest, which runs
+//      beside the next panel's leaf chain (look-ahead).
+// The previous form (32-wide panel in one workgroup that walked the panel through memory for every sub-panel, one dependent
+// chain of 32 row swaps per column, trailing updates at K = 32) spent 64 % of an 84 ms factorisation in the panel kernel.
+constexpr int LU_NBO = 128;    // outer panel width = K of the trailing update
+constexpr int LU_LEAF = 8;     // columns factorised in registers by one workgroup
+
+// W[i][j], i < n_aug: j < n_aug: a_trans(i,j) = C(j,i) (+ reg on the diagonal); n_aug <= j < ncols: b_trans(i,o) = B(o,i) + prior(o,i)
+// (fit_chunk_hybrid :1261-1309).  C is symmetric at this point, so C(j,i) = c[j + i*n_aug] is read contiguously along j.
+// The LU kernels factorise a BATCH of equally sized systems in lockstep: one grid dimension indexes the system, every scratch array
+// is a stack of per-system slabs (LuStride).  One chain of launches then serves all of them; eight separate chains on eight
+// stream pairs were multiplexed onto the runtime's four hardware queues and ran no faster than one after another (measured).
+struct LuStride { long w, p, tmp; int ipiv; };
+
+__global__ void k_build_system(const double *const *__restrict__ c_list, const double *const *__restrict__ b_list, double *__restrict__ w, long ld, int n_aug,
+                               int n_model, int n_out, double reg_model, double reg_res, double prior_diag, LuStride ls)
 {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)n_aug * (n_aug + n_out);
-    if (t >= total) return;
-    const int i = (int)(t % n_aug);
-    const int j = (int)(t / n_aug);
-    double v;
+    const double *__restrict__ c = c_list[blockIdx.z], *__restrict__ b = b_list[blockIdx.z];
+    w += ls.w * blockIdx.z;
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    double v = 0.0;
     if (j < n_aug) {
-        v = c[(long)i + (long)j * n_aug];                 // a_trans = transpose(C); C is symmetric here, read it contiguously
+        v = c[(long)j + (long)i * n_aug];
         if (i == j) v = v + (i < n_model ? reg_model : reg_res);
-    } else {
-        const int o = j - n_aug;                          // b_trans(i, o) = B(o, i) + prior(o, i)
+    } else if (j < n_aug + n_out) {
+        const int o = j - n_aug;
         v = b[(long)o + (long)i * n_out];
         if (o == i && o < n_model) v = v + prior_diag;
     }
-    w[t] = v;
+    w[(long)i * ld + j] = v;
 }
 
-__global__ void k_extract_wout(const double *__restrict__ w, double *__restrict__ wout, int n_aug, int n_out)
+// wout(o,i) = Z(i,o) = W[i][n_aug + o]; wout is the column-major (n_out, n_aug) array of the reference
+__global__ void k_extract_wout(const double *__restrict__ w, long ld, double *const *__restrict__ wout_list, int n_aug, int n_out, LuStride ls)
 {
+    double *__restrict__ wout = wout_list[blockIdx.y];
+    w += ls.w * blockIdx.y;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)n_aug * n_out) return;
     const int o = (int)(t % n_out), i = (int)(t / n_out);
-    wout[t] = w[(long)i + (long)(n_aug + o) * n_aug];     // wout(o,i) = Z(i,o)
+    wout[t] = w[(long)i * ld + n_aug + o];
 }
 
-// ---- LU panel: columns [k0, k0+nb) of W, rows [k0, n); one workgroup ----
-constexpr int PT = 1024;
-__global__ __launch_bounds__(PT) void k_panel(double *__restrict__ w, int n, int k0, int nb, int *__restrict__ ipiv, int *__restrict__ info)
+// P[q][r] = W[r][K0 + q] for K0 <= r < n, q < nbp: the next panel's columns, transposed through LDS (both sides contiguous)
+__global__ __launch_bounds__(256) void k_lu_strip_to_panel(const double *__restrict__ w, long ld, double *__restrict__ P, long np, int n, int K0, int nbp,
+                                                            LuStride ls)
 {
-    __shared__ double sval[PT / 64];
-    __shared__ int sidx[PT / 64];
-    __shared__ int spiv;
-    __shared__ double srow[LU_NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = 0; c < nb; ++c) {
-        const int col = k0 + c;
-        double *wc = w + (long)col * n;
-        // pivot search: first maximum of |a| (dgetf2 / idamax)
-        double best = -1.0; int bi = n;
-        for (int r = col + tid; r < n; r += PT) {
-            const double a = fabs(wc[r]);
-            if (a > best) { best = a; bi = r; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            double b2 = sval[0]; int i2 = sidx[0];
-            for (int q = 1; q < PT / 64; ++q)
-                if (sval[q] > b2 || (sval[q] == b2 && sidx[q] < i2)) { b2 = sval[q]; i2 = sidx[q]; }
-            spiv = i2;
-            ipiv[col] = i2;
-            if (b2 == 0.0 && *info == 0) *info = col + 1;
-        }
-        __syncthreads();
-        const int p = spiv;
-        // interchange rows col <-> p inside the panel and stage the pivot row
-        if (tid < nb) {
-            double *q = w + (long)(k0 + tid) * n;
-            const double a = q[col], b = q[p];
-            if (p != col) { q[col] = b; q[p] = a; }
-            srow[tid] = b;
-        }
-        __syncthreads();
-        const double piv = srow[c];
-        if (piv != 0.0) {
-            const double inv = 1.0 / piv;
-            for (int r = col + 1 + tid; r < n; r += PT) {
-                const double l = wc[r] * inv;
-                wc[r] = l;
-                for (int cc = c + 1; cc < nb; ++cc) {
-                    double *q = w + (long)(k0 + cc) * n;
-                    q[r] = q[r] - l * srow[cc];
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// The same factorisation of a panel, blocked: the panel's columns are taken SW at a time; a thread keeps its rows of those SW columns
-// in registers while their pivots are found and eliminated, and the panel's remaining columns are updated ONCE per sub-panel
-// (u = L11^-1 a12, then a22 -= l21 u, every subtraction in the order the column-by-column form does them, so the bits are the same)
-// instead of once per column.  k_panel walks all trailing panel columns through memory for every one of its 32 pivots: 0.5 ms per
-// panel, 93 of the 114 ms of a 5892 x 5892 factorisation.  Rows below the panel's first row: at most PBT * RPT.
-constexpr int SW = 6, PBT = 512, RPT = 12;       // 96 doubles of the sub-panel per thread: needs the 256-VGPR budget of 8 waves per CU
-__global__ __launch_bounds__(PBT) void k_panel_blocked(double *__restrict__ w, int n, int k0, int nb, int *__restrict__ ipiv, int *__restrict__ info)
-{
-    __shared__ double sval[2 * (PBT / 64)];     // per-wave maxima, double-buffered by column parity (one barrier per reduction)
-    __shared__ int sidx[2 * (PBT / 64)];
-    __shared__ double rowPC[2][2][SW];          // [column parity][pivot row | current row][sub-panel column]: the rows being interchanged
-    __shared__ double l11[SW][SW];              // unit-lower factor of the sub-panel's diagonal block
-    __shared__ double u12[SW][LU_NB];           // the sub-panel's rows of the panel's remaining columns, eliminated
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c0 = 0; c0 < nb; c0 += SW) {
-        const int sw = min(SW, nb - c0), top = k0 + c0;
-        double a[RPT][SW];
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = k0 + tid + i * PBT;
-#pragma unroll
-            for (int j = 0; j < SW; ++j) a[i][j] = (r < n && j < sw) ? w[(long)(top + j) * n + r] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < SW; ++j) {
-            if (j < sw) {                                   // uniform
-                const int col = top + j;
-                // pivot search: first maximum of |a| (dgetf2 / idamax)
-                double best = -1.0; int bi = n;
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = k0 + tid + i * PBT;
-                    if (r >= col && r < n) {
-                        const double v = fabs(a[i][j]);
-                        if (v > best) { best = v; bi = r; }
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double ob = __shfl_xor(best, o, 64);
-                    const int oi = __shfl_xor(bi, o, 64);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
-                if (lane == 0) { sval[(j & 1) * (PBT / 64) + wave] = best; sidx[(j & 1) * (PBT / 64) + wave] = bi; }
-                __syncthreads();
-                // every thread finishes the reduction for itself (8 LDS broadcasts): no second barrier for a shared result
-                double b2 = sval[(j & 1) * (PBT / 64)]; int p = sidx[(j & 1) * (PBT / 64)];
-#pragma unroll
-                for (int q = 1; q < PBT / 64; ++q) {
-                    const double sv = sval[(j & 1) * (PBT / 64) + q];
-                    const int si = sidx[(j & 1) * (PBT / 64) + q];
-                    if (sv > b2 || (sv == b2 && si < p)) { b2 = sv; p = si; }
-                }
-                if (tid == 0) {
-                    ipiv[col] = p;
-                    if (b2 == 0.0 && *info == 0) *info = col + 1;
-                }
-                double *rowP = rowPC[j & 1][0], *rowC = rowPC[j & 1][1];
-                // interchange rows col <-> p: inside the sub-panel through LDS, in the panel's other columns in memory
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = k0 + tid + i * PBT;
-                    if (r == p) {
-#pragma unroll
-                        for (int jj = 0; jj < SW; ++jj) rowP[jj] = a[i][jj];
-                    }
-                    if (r == col) {
-#pragma unroll
-                        for (int jj = 0; jj < SW; ++jj) rowC[jj] = a[i][jj];
-                    }
-                }
-                __syncthreads();
-                // (the panel's other columns: in memory, by one thread each; issued after the barrier so that its round trip
-                // runs under the elimination below instead of holding everybody at the barrier)
-                if (tid < nb && (tid < c0 || tid >= c0 + sw) && p != col) {
-                    double *q = w + (long)(k0 + tid) * n;
-                    const double x = q[col], y = q[p];
-                    q[col] = y; q[p] = x;
-                }
-                if (p != col) {
-#pragma unroll
-                    for (int i = 0; i < RPT; ++i) {
-                        const int r = k0 + tid + i * PBT;
-                        if (r == col) {
-#pragma unroll
-                            for (int jj = 0; jj < SW; ++jj) a[i][jj] = rowP[jj];
-                        } else if (r == p) {
-#pragma unroll
-                            for (int jj = 0; jj < SW; ++jj) a[i][jj] = rowC[jj];
-                        }
-                    }
-                }
-                const double piv = rowP[j];
-                if (piv != 0.0) {
-                    const double inv = 1.0 / piv;
-#pragma unroll
-                    for (int i = 0; i < RPT; ++i) {
-                        const int r = k0 + tid + i * PBT;
-                        if (r > col && r < n) {
-                            const double l = a[i][j] * inv;
-                            a[i][j] = l;
-#pragma unroll
-                            for (int jj = 0; jj < SW; ++jj)
-                                if (jj > j) a[i][jj] = a[i][jj] - l * rowP[jj];
-                        }
-                    }
-                }
-                // no barrier here: the next column uses the other halves of sval / sidx / rowPC, and its first barrier orders
-                // everything else
-            }
-        }
-        // the sub-panel goes back to memory; its diagonal block's L part is shared for the elimination of the remaining columns
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = k0 + tid + i * PBT;
-            if (r >= top && r < n) {
-#pragma unroll
-                for (int j = 0; j < SW; ++j)
-                    if (j < sw) w[(long)(top + j) * n + r] = a[i][j];
-                if (r < top + sw) {
-#pragma unroll
-                    for (int jj = 0; jj < SW; ++jj) l11[r - top][jj] = a[i][jj];
-                }
-            }
-        }
-        const int rem = nb - c0 - sw;                       // panel columns to the right of the sub-panel
-        if (rem > 0) {
-            __syncthreads();
-            if (tid < rem) {                                // u = L11^-1 a12, one thread per column, subtractions in elimination order
-                double *q = w + (long)(top + sw + tid) * n;
-                double u[SW];
-#pragma unroll
-                for (int j = 0; j < SW; ++j) {
-                    if (j < sw) {
-                        double v = q[top + j];
-#pragma unroll
-                        for (int jj = 0; jj < SW; ++jj)
-                            if (jj < j) v = v - l11[j][jj] * u[jj];
-                        u[j] = v;
-                        q[top + j] = v;
-                        u12[j][tid] = v;
-                    }
-                }
-            }
-            __syncthreads();
-            for (int cc = 0; cc < rem; ++cc) {              // a22 -= l21 u, row by row in registers' L
-                double *q = w + (long)(top + sw + cc) * n;
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = k0 + tid + i * PBT;
-                    if (r >= top + sw && r < n) {
-                        double v = q[r];
-#pragma unroll
-                        for (int j = 0; j < SW; ++j)
-                            if (j < sw) v = v - a[i][j] * u12[j][cc];
-                        q[r] = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();                                    // the next sub-panel reads what this one wrote
-    }
-}
-
-// apply the panel's interchanges to every column outside the panel (columns [0,k0) and [k0+nb, ncols))
-__global__ void k_swap(double *__restrict__ w, int n, int ncols, int k0, int nb, const int *__restrict__ ipiv)
-{
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols - nb) return;
-    if (col >= k0) col += nb;
-    double *q = w + (long)col * n;
-    for (int c = 0; c < nb; ++c) {
-        const int r = k0 + c, p = ipiv[r];
-        if (p != r) { const double a = q[r]; q[r] = q[p]; q[p] = a; }
-    }
-}
-
-// U12 = L11^-1 A12: one thread per column of A12 (columns [k0+nb, ncols)); unit-lower L11 and the thread's column
-// segment live in LDS (xs[r][thread] is conflict free), so nothing is indexed dynamically in registers.
-constexpr int TRSM_T = 64;
-__global__ __launch_bounds__(TRSM_T) void k_trsm_lower(double *__restrict__ w, int n, int ncols, int k0, int nb)
-{
-    __shared__ double L[LU_NB][LU_NB + 1];
-    __shared__ double xs[LU_NB][TRSM_T];
-    for (int e = threadIdx.x; e < nb * nb; e += TRSM_T) {
-        const int r = e % nb, c = e / nb;
-        L[r][c] = w[(long)(k0 + r) + (long)(k0 + c) * n];
+    w += ls.w * blockIdx.z; P += ls.p * blockIdx.z;
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = K0 + blockIdx.x * 32, q0 = blockIdx.y * 32;
+    for (int y = ty; y < 32; y += 8) {
+        const int r = r0 + y, q = q0 + tx;
+        t[y][tx] = (r < n && q < nbp) ? w[(long)r * ld + K0 + q] : 0.0;
     }
     __syncthreads();
-    const int col = k0 + nb + blockIdx.x * TRSM_T + threadIdx.x;
-    if (col >= ncols) return;
-    double *q = w + (long)col * n + k0;
-    for (int r = 0; r < nb; ++r) xs[r][threadIdx.x] = q[r];
-    for (int r = 1; r < nb; ++r) {
-        double s = xs[r][threadIdx.x];
-        for (int c = 0; c < r; ++c) s = s - L[r][c] * xs[c][threadIdx.x];
-        xs[r][threadIdx.x] = s;
+    for (int y = ty; y < 32; y += 8) {
+        const int q = q0 + y, r = r0 + tx;
+        if (r < n && q < nbp) P[(long)q * np + r] = t[tx][y];
     }
-    for (int r = 0; r < nb; ++r) q[r] = xs[r][threadIdx.x];
 }
 
-// back substitution block: X_kb = U_kk^-1 Y_kb for every right-hand side (columns [n, ncols))
-__global__ __launch_bounds__(TRSM_T) void k_trsm_upper(double *__restrict__ w, int n, int ncols, int k0, int nb)
+// ---- leaf: columns [c, c+lw) of the panel, rows [c, n), in registers; one workgroup of LEAF_T threads ----
+// Thread t owns rows c + t + LEAF_T i (i < R).  A pivot costs ONE barrier: before it every wavefront reduces its first-maximum
+// (DPP butterflies inside the 16-lane rows, v_readlane across them; the value first, then the smallest row among the lanes that
+// hold it) and parks value, row and -- from the one lane that owns it -- the candidate row's LW entries in LDS; the owner of the
+// diagonal row parks that row too.  After the barrier every thread finishes the reduction over the wavefront results itself and
+// reads the winning candidate row: no second barrier for the interchange.  The elimination is in the column-by-column order of
+// dgetf2 with fused multiply-adds.  The workgroup is VALU-issue bound (every wavefront repeats the ~290 instructions of a pivot's
+// reduction and bookkeeping), so fewer wavefronts with more rows each are faster -- as long as a thread stays within 256
+// registers (beyond v255 the vector ALU pays a copy each way).  Hence 4 wavefronts x <= 14 rows up to 3584 rows and 8 wavefronts
+// x <= 12 rows above (measured per leaf, in-kernel stamps: 256 threads 7.4 us at 256 rows .. 15.9 us at 3584 rows against
+// 9.7 .. 19.5 us with 512 threads; 3584 < rows <= 6144: 21 .. 27 us with 512 threads against 18 .. 47 us with 256; the first
+// version with 16 wavefronts x 7 rows took 3.3 us per pivot).
+// Threads LEAF_T-128 .. LEAF_T-1 also take one of the panel's OTHER columns each and apply all lw interchanges to it in one batch:
+// the leaf's rows of that column are fetched at the start, each pivot row as soon as it is known (consumed only at the end), the
+// composite permutation is applied through LDS and, to the right of the leaf, the leaf's rows become U (u = L11^-1 a).
+__device__ __forceinline__ double dpp_max_row16(double v)
+{   // all-reduce max inside each row of 16 lanes: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+#define DPP_STEP(CTRL)                                                   \
+    b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], CTRL, 0xf, 0xf, true);     \
+    b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, 0xf, 0xf, true);     \
+    a.d = fmax(a.d, b.d);
+    DPP_STEP(0xB1) DPP_STEP(0x4E) DPP_STEP(0x141) DPP_STEP(0x140)
+#undef DPP_STEP
+    return a.d;
+}
+
+__device__ __forceinline__ int dpp_min_row16(int v)
 {
-    __shared__ double U[LU_NB][LU_NB + 1];
-    __shared__ double xs[LU_NB][TRSM_T];
-    for (int e = threadIdx.x; e < nb * nb; e += TRSM_T) {
-        const int r = e % nb, c = e / nb;
-        U[r][c] = w[(long)(k0 + r) + (long)(k0 + c) * n];
+#define DPP_STEP(CTRL) v = min(v, __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true));
+    DPP_STEP(0xB1) DPP_STEP(0x4E) DPP_STEP(0x141) DPP_STEP(0x140)
+#undef DPP_STEP
+    return v;
+}
+
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+    union { double d; int i[2]; } a, r;
+    a.d = dpp_max_row16(v);
+    double m = -1.0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        r.i[0] = __builtin_amdgcn_readlane(a.i[0], 16 * row);
+        r.i[1] = __builtin_amdgcn_readlane(a.i[1], 16 * row);
+        m = fmax(m, r.d);
+    }
+    return m;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = dpp_min_row16(v);
+    int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) m = min(m, __builtin_amdgcn_readlane(v, 16 * row));
+    return m;
+}
+
+template <int LEAF_T, int R, int LW, bool FULL>
+__global__ __launch_bounds__(LEAF_T) void k_lu_leaf(double *__restrict__ P, long np, int n, int K0, int c, int lw_rt, int nbp, int *__restrict__ ipiv,
+                                                     int *__restrict__ info, long long *__restrict__ stamps, LuStride ls)
+{
+    P += ls.p * blockIdx.x; ipiv += ls.ipiv * blockIdx.x; info += blockIdx.x;
+    if (blockIdx.x) stamps = nullptr;
+    // stamps (diagnostic builds of a run only: SML_LU_STAMP=1): thread 0's cycle counter after the loads, after every pivot, after
+    // the stores were issued and at the end; nullptr otherwise
+#define LEAF_STAMP(K) if (stamps && threadIdx.x == 0) { stamps[K] = __builtin_readcyclecounter(); stamps[16 + (K)] = __builtin_amdgcn_s_memrealtime(); }
+    LEAF_STAMP(0)
+    constexpr int NW = LEAF_T / 64, LEAF_SH = LEAF_T == 512 ? 9 : 8;
+    static_assert(LEAF_T == 1 << LEAF_SH, "the leaf has 256 or 512 threads");
+    __shared__ __attribute__((aligned(16))) double sval[2][NW];
+    __shared__ __attribute__((aligned(16))) int sidx[2][NW];
+    __shared__ __attribute__((aligned(16))) double cand[2][NW][LU_LEAF];     // every wavefront's candidate pivot row
+    __shared__ __attribute__((aligned(16))) double rowC[2][LU_LEAF];         // the diagonal row
+    __shared__ double vt[2 * LU_LEAF][LU_NBO];                               // the affected rows of the panel's other columns
+    __shared__ double l11[LU_LEAF][LU_LEAF];
+    __shared__ int piv[LU_LEAF], srcidx[2 * LU_LEAF];
+    const int lw = FULL ? LW : lw_rt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = c - K0;
+    // slot i of this thread is row c + tid + LEAF_T i; slots beyond row n hold zeros throughout (0 * l = 0) and lose every tie
+    // in the pivot search (R is the next instantiated size >= ceil((n - c) / LEAF_T))
+    const int rows = n - c;
+    double *const base = P + (long)q0 * np + c + tid;
+    double a[R][LW];
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        const double *cp = base + (long)j * np;
+        const bool cok = FULL || j < lw;
+#pragma unroll
+        for (int i = 0; i < R; ++i) a[i][j] = (cok && tid + i * LEAF_T < rows) ? cp[i * LEAF_T] : 0.0;
+    }
+    const int q = tid - (LEAF_T - LU_NBO);
+    const bool other = q >= 0 && q < nbp && (q < q0 || q >= q0 + lw);
+    double *colq = P + (long)(other ? q : 0) * np;
+    double prow[LW];                                          // this column's entry in each pivot row
+    if (other) {
+#pragma unroll
+        for (int k = 0; k < LW; ++k)
+            if (FULL || k < lw) vt[k][q] = colq[c + k];
+    }
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        prow[j] = 0.0;
+        if (FULL || j < lw) {                                 // uniform
+            const int col = c + j, par = j & 1;
+            // first maximum of |a|: the value ...
+            double best = tid >= j ? fabs(a[0][j]) : -1.0;    // slot 0 is row c + tid: a candidate from the diagonal on
+#pragma unroll
+            for (int i = 1; i < R; ++i) best = fmax(best, fabs(a[i][j]));
+            const double mw = wave_max_f64(best);
+            if (j == 0) { LEAF_STAMP(1) }
+            // ... then the smallest row among the lanes that hold it
+            int rowc = 0x7fffffff;
+            if (best == mw) {
+#pragma unroll
+                for (int i = R - 1; i >= 1; --i)
+                    if (fabs(a[i][j]) == mw) rowc = c + tid + i * LEAF_T;
+                if (tid >= j && fabs(a[0][j]) == mw) rowc = c + tid;
+                if (rowc >= n) rowc = 0x7fffffff;
+            }
+            const int iw = wave_min_i32(rowc);
+            if (lane == 0) { sval[par][wave] = mw; sidx[par][wave] = iw; }
+            if (iw != 0x7fffffff && tid == ((iw - c) & (LEAF_T - 1))) {     // the candidate row's owner parks it
+                const int is = (iw - c) >> LEAF_SH;          // uniform; a chain of scalar compares (an indexed register array would
+                                                              // go to scratch, a switch made the compiler copy the whole array)
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                    if (i == is) {
+#pragma unroll
+                        for (int jj = 0; jj < LW; ++jj) cand[par][wave][jj] = a[i][jj];
+                    }
+            }
+            if (tid == j) {                                   // the diagonal row c + j is thread j's slot 0
+#pragma unroll
+                for (int jj = 0; jj < LW; ++jj) rowC[par][jj] = a[0][jj];
+            }
+            __syncthreads();
+            double sv[NW];
+            int si[NW];
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) { sv[w2] = sval[par][w2]; si[w2] = sidx[par][w2]; }
+            double b2 = sv[0];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) b2 = fmax(b2, sv[w2]);
+            int p = 0x7fffffff;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) p = min(p, sv[w2] == b2 ? si[w2] : 0x7fffffff);
+            if (p == 0x7fffffff) p = col;                     // (no finite candidate: NaN column)
+            const int wsel = ((p - c) & (LEAF_T - 1)) >> 6;
+            if (tid == 0) {
+                ipiv[col] = p;
+                piv[j] = p;
+                if (b2 == 0.0 && *info == 0) *info = col + 1;
+            }
+            if (other && p >= c + lw) prow[j] = colq[p];      // consumed after the pivot loop
+            double rp[LW];
+#pragma unroll
+            for (int jj = 0; jj < LW; ++jj) rp[jj] = cand[par][wsel][jj];
+            if (p != col) {
+                const int tp = (p - c) & (LEAF_T - 1), ip = (p - c) >> LEAF_SH;      // uniform
+                if (tid == tp) {                              // (before slot 0 is overwritten when tp == j)
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+                        if (i == ip) {
+#pragma unroll
+                            for (int jj = 0; jj < LW; ++jj) a[i][jj] = rowC[par][jj];
+                        }
+                }
+                if (tid == j) {
+#pragma unroll
+                    for (int jj = 0; jj < LW; ++jj) a[0][jj] = rp[jj];
+                }
+            }
+            const double pv = rp[j];
+            if (pv != 0.0) {
+                const double inv = 1.0 / pv;
+                {
+                    const bool el = tid > j;
+                    const double l = el ? a[0][j] * inv : 0.0;
+                    a[0][j] = el ? l : a[0][j];
+#pragma unroll
+                    for (int jj = 0; jj < LW; ++jj)
+                        if (jj > j) a[0][jj] = __builtin_fma(-l, rp[jj], a[0][jj]);
+                }
+#pragma unroll
+                for (int i = 1; i < R; ++i) {
+                    const double l = a[i][j] * inv;
+                    a[i][j] = l;
+#pragma unroll
+                    for (int jj = 0; jj < LW; ++jj)
+                        if (jj > j) a[i][jj] = __builtin_fma(-l, rp[jj], a[i][jj]);
+                }
+            }
+            // no barrier here: the next pivot uses the other halves of sval / sidx / cand / rowC
+            LEAF_STAMP(2 + j)
+        }
+    }
+    // ---- the panel's other columns: all lw interchanges in one batch ----
+    // positions: idx < 8 -> row c + idx, idx >= 8 -> row piv[idx - 8]; after the interchanges position x holds what was at
+    // s_0(s_1(...s_{lw-1}(x))), s_t = transposition (c + t, piv[t]); srcidx = index of that row in the position list
+    if (other) {
+#pragma unroll
+        for (int k = 0; k < LW; ++k)
+            if (FULL || k < lw) vt[LU_LEAF + k][q] = prow[k];  // (pivot rows inside the leaf's own rows are read through their idx < 8 slot)
+    }
+    __syncthreads();                                          // piv[] complete
+    if (tid < 2 * LU_LEAF) {
+        const int t2 = tid & (LU_LEAF - 1);
+        int x = t2 < lw ? (tid < LU_LEAF ? c + t2 : piv[t2]) : -1;
+        for (int t = lw - 1; t >= 0; --t) {
+            const int d = c + t, pp = piv[t];
+            x = (x == d) ? pp : (x == pp ? d : x);
+        }
+        int m = 0;                                            // x is c + m (m < lw) or one of the pivot rows
+        if (x >= c && x < c + lw) m = x - c;
+        else
+            for (int t = 0; t < lw; ++t)
+                if (piv[t] == x) { m = LU_LEAF + t; break; }
+        srcidx[tid] = m;
+    }
+    double *sbase = base;
+    asm volatile("" : "+v"(sbase));                           // (a fresh address chain: keeps the load-time addresses from living through the loop)
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        double *cp = sbase + (long)j * np;
+        if (FULL || j < lw) {
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                if (tid + i * LEAF_T < rows) cp[i * LEAF_T] = a[i][j];
+        }
+    }
+    LEAF_STAMP(10)
+    if (tid < LW) {
+#pragma unroll
+        for (int jj = 0; jj < LW; ++jj) l11[tid][jj] = a[0][jj];       // rows c .. c+7 belong to threads 0..7 (slot 0)
     }
     __syncthreads();
-    const int col = n + blockIdx.x * TRSM_T + threadIdx.x;
-    if (col >= ncols) return;
-    double *q = w + (long)col * n + k0;
-    for (int r = 0; r < nb; ++r) xs[r][threadIdx.x] = q[r];
-    for (int r = nb - 1; r >= 0; --r) {
-        double s = xs[r][threadIdx.x];
-        for (int c = r + 1; c < nb; ++c) s = s - U[r][c] * xs[c][threadIdx.x];
-        xs[r][threadIdx.x] = s / U[r][r];
+    if (other) {
+        const bool right = q >= q0 + lw;
+        double u[LW];
+#pragma unroll
+        for (int r = 0; r < LW; ++r) {
+            if (FULL || r < lw) {
+                double v = vt[srcidx[r]][q];
+                if (right) {
+#pragma unroll
+                    for (int k = 0; k < LW; ++k)
+                        if (k < r) v = __builtin_fma(-l11[r][k], u[k], v);
+                }
+                u[r] = v;
+                colq[c + r] = v;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < LW; ++t) {
+            if (FULL || t < lw) {
+                const int pr = piv[t];
+                if (pr >= c + lw) colq[pr] = vt[srcidx[LU_LEAF + t]][q];
+            }
+        }
     }
-    for (int r = 0; r < nb; ++r) q[r] = xs[r][threadIdx.x];
+    LEAF_STAMP(11)
+}
+#undef LEAF_STAMP
+
+// rank-lw update of the panel's columns to the right of a leaf: P[q][r] -= sum_k L(r,k) U(k,q), r >= c+lw, q >= q0+lw.
+// 256 rows x 16 columns per workgroup; the 16 x 8 U block goes through LDS, all loads are issued before the arithmetic.
+constexpr int PU_COLS = 16;
+__global__ __launch_bounds__(256) void k_lu_panel_update(double *__restrict__ P, long np, int n, int K0, int c, int lw, int nbp, LuStride ls)
+{
+    P += ls.p * blockIdx.z;
+    __shared__ double ub[PU_COLS][LU_LEAF];
+    const int q0 = c - K0;
+    const int r = c + lw + blockIdx.x * 256 + threadIdx.x;
+    const int qb = q0 + lw + blockIdx.y * PU_COLS;
+    if (threadIdx.x < PU_COLS * LU_LEAF) {
+        const int qq = threadIdx.x / LU_LEAF, k = threadIdx.x % LU_LEAF;
+        ub[qq][k] = (qb + qq < nbp && k < lw) ? P[(long)(qb + qq) * np + c + k] : 0.0;
+    }
+    const bool ok = r < n;
+    double l[LU_LEAF], av[PU_COLS];
+#pragma unroll
+    for (int k = 0; k < LU_LEAF; ++k) l[k] = (ok && k < lw) ? P[(long)(q0 + k) * np + r] : 0.0;
+#pragma unroll
+    for (int qq = 0; qq < PU_COLS; ++qq) av[qq] = (ok && qb + qq < nbp) ? P[(long)(qb + qq) * np + r] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < PU_COLS; ++qq) {
+        double v = av[qq];
+#pragma unroll
+        for (int k = 0; k < LU_LEAF; ++k) v = v - l[k] * ub[qq][k];
+        if (ok && qb + qq < nbp) P[(long)(qb + qq) * np + r] = v;
+    }
+}
+
+// U11 (upper triangle of the panel's top block) goes into W (needed by the back substitution only: off the critical path)
+__global__ __launch_bounds__(256) void k_lu_u11_to_w(const double *__restrict__ P, long np, double *__restrict__ w, long ld, int K0, int nbp, LuStride ls)
+{
+    P += ls.p * blockIdx.z; w += ls.w * blockIdx.z;
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
+    if (r0 > q0 + 31) return;                                  // tile strictly below the diagonal
+    for (int y = ty; y < 32; y += 8) {
+        const int qq = q0 + y, r = r0 + tx;                   // consecutive threads: consecutive rows of one panel column
+        t[y][tx] = (qq < nbp && r < nbp) ? P[(long)qq * np + K0 + r] : 0.0;
+    }
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) {
+        const int r = r0 + y, qq = q0 + tx;
+        if (r < nbp && qq < nbp && r <= qq) w[(long)(K0 + r) * ld + K0 + qq] = t[tx][y];
+    }
+}
+
+// tmp[idx][j] = W[src(idx)][j] for the columns j >= c0 to the right of the panel: the rows as they will read after the panel's
+// nbp interchanges.  Position idx < 128 is row K0 + idx, idx >= 128 is row ipiv[K0 + idx - 128]; after the interchanges position
+// x holds what was at src(x) = s_0(s_1(... s_{nbp-1}(x))), s_t = transposition (K0 + t, ipiv[K0 + t]) -- every workgroup works
+// that out for its own position (128 LDS broadcasts).  Nothing is written into W here, so no ordering between positions is
+// needed and no column walks a dependent chain of 128 swaps.
+__global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict__ w, long ld, int c0, int ncols, int K0, int nbp, const int *__restrict__ ipiv,
+                                                         double *__restrict__ tmp, LuStride ls)
+{
+    w += ls.w * blockIdx.z; ipiv += ls.ipiv * blockIdx.z; tmp += ls.tmp * blockIdx.z;
+    __shared__ int piv[LU_NBO];
+    if (threadIdx.x < LU_NBO) piv[threadIdx.x] = (int)threadIdx.x < nbp ? ipiv[K0 + threadIdx.x] : K0 + (int)threadIdx.x;
+    __syncthreads();
+    int idx = blockIdx.y;
+    if (idx >= nbp) idx += LU_NBO - nbp;                      // second half of the position list starts at 128
+    int x = idx < LU_NBO ? K0 + idx : piv[idx - LU_NBO];
+    for (int t0 = nbp - 1; t0 >= 0; t0 -= 16) {               // 16 pivots per batch of LDS reads (one by one: 22 us per launch)
+        int pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pv[u] = piv[max(t0 - u, 0)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int t = t0 - u, d = K0 + t, p = pv[u];
+            if (t >= 0) x = (x == d) ? p : (x == p ? d : x);
+        }
+    }
+    const int j = c0 + blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    tmp[(long)idx * ld + j] = w[(long)x * ld + j];
+}
+
+// U12 = L11^-1 A12 for 64 columns per workgroup of four wavefronts, A12 read from the gathered rows; the displaced rows (positions
+// 128.. whose row lies below the panel's top block) are written back to W on the way.  Rows in blocks of 8; within a block
+// wavefront w owns rows 2w, 2w+1: the rectangular part (every earlier x once, through LDS) runs on all four SIMDs, the 8 x 8
+// triangle is repeated by every wavefront.  The block's rows of L are staged in LDS; their loads are issued two blocks ahead and
+// parked in registers, so no global load sits in the dependent chain.  Per entry the subtractions run over ascending k (fused
+// multiply-adds).
+constexpr int TR_T = 256;
+__global__ __launch_bounds__(TR_T) void k_lu_trsm_scatter(const double *__restrict__ P, long np, double *__restrict__ w, long ld, int K0, int nbp, int c0,
+                                                           int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls)
+{
+    P += ls.p * blockIdx.y; w += ls.w * blockIdx.y; ipiv += ls.ipiv * blockIdx.y; tmp += ls.tmp * blockIdx.y;
+    __shared__ double xs[LU_NBO][64];
+    __shared__ double Lt[2][8][LU_NBO];
+    __shared__ double sx[8][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = c0 + blockIdx.x * 64 + lane;
+    const bool ok = j < ncols;
+    for (int i = wv; i < nbp; i += 4) {
+        const int p = ipiv[K0 + i];
+        if (p >= K0 + nbp && ok) w[(long)p * ld + j] = tmp[(long)(LU_NBO + i) * ld + j];
+    }
+    const double *L = P + K0;                                 // L(i,k) = L[k*np + i], i,k relative to the panel's top block
+    // element e = threadIdx.x + 256 m of block ib: k = e >> 3, r = e & 7 -> L(ib + r, k), k < ib + 8 (8 consecutive rows contiguous)
+    double pre[4];
+    auto stage_load = [&](int ib) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = threadIdx.x + TR_T * m, k = e >> 3, r = e & 7;
+            pre[m] = (ib < nbp && k < ib + 8 && ib + r < nbp && k < nbp) ? L[(long)k * np + ib + r] : 0.0;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = threadIdx.x + TR_T * m, k = e >> 3, r = e & 7;
+            Lt[buf][r][k] = pre[m];
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    stage_load(8);
+    const int r0 = 2 * wv, r1 = r0 + 1;
+    double s0 = (ok && r0 < nbp) ? tmp[(long)r0 * ld + j] : 0.0, s1 = (ok && r1 < nbp) ? tmp[(long)r1 * ld + j] : 0.0;
+    for (int ib = 0, b = 0; ib < nbp; ib += 8, b ^= 1) {
+        __syncthreads();                                      // Lt[b] staged; the previous block's x are in xs
+        stage_store(b ^ 1);                                   // block ib + 8 (loaded one iteration ago)
+        stage_load(ib + 16);
+        const double s0n = (ok && ib + 8 + r0 < nbp) ? tmp[(long)(ib + 8 + r0) * ld + j] : 0.0;
+        const double s1n = (ok && ib + 8 + r1 < nbp) ? tmp[(long)(ib + 8 + r1) * ld + j] : 0.0;
+        const double *l0 = Lt[b][r0], *l1 = Lt[b][r1];
+#pragma unroll 8
+        for (int k = 0; k < ib; ++k) {
+            const double xk = xs[k][lane];
+            s0 = __builtin_fma(-l0[k], xk, s0);
+            s1 = __builtin_fma(-l1[k], xk, s1);
+        }
+        sx[r0][lane] = s0;
+        sx[r1][lane] = s1;
+        __syncthreads();
+        double x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            double v = sx[r][lane];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < r) v = __builtin_fma(-Lt[b][r][ib + k], x[k], v);
+            x[r] = v;
+            if (r == r0 || r == r1) {                         // uniform per wavefront
+                xs[ib + r][lane] = v;
+                if (ok && ib + r < nbp) w[(long)(K0 + ib + r) * ld + j] = v;
+            }
+        }
+        s0 = s0n;
+        s1 = s1n;
+    }
+}
+
+// back substitution block: X_kb = U_kk^-1 Y_kb for 64 right-hand side columns per workgroup, the same four-wavefront scheme
+// bottom-up.  U is row-major in W (a read-only region here: columns < n_aug), so a block's rows are staged along k.  Per entry
+// the subtractions run over descending k and the diagonal is divided by, as dtrsm('L','U','N','N') does.
+__global__ __launch_bounds__(TR_T) void k_lu_trsm_upper(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls)
+{
+    y += ls.w * blockIdx.y; U += ls.w * blockIdx.y;
+    __shared__ double xs[LU_NBO][64];
+    __shared__ double Ut[2][8][LU_NBO];
+    __shared__ double sx[8][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const bool ok = j < nrhs;
+    // element e = threadIdx.x + 256 m of block ib: r = e >> 7, k = e & 127 -> U(ib + r, k), k >= ib (identity rows past nb)
+    double pre[4];
+    auto stage_load = [&](int ib) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = threadIdx.x + TR_T * m, r = e >> 7, k = e & (LU_NBO - 1);
+            pre[m] = (ib >= 0 && k >= ib && ib + r < nb && k < nb) ? U[(long)(ib + r) * ld + k] : (k == ib + r ? 1.0 : 0.0);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = threadIdx.x + TR_T * m, r = e >> 7, k = e & (LU_NBO - 1);
+            Ut[buf][r][k] = pre[m];
+        }
+    };
+    const int ib_last = ((nb - 1) / 8) * 8;
+    stage_load(ib_last);
+    stage_store(0);
+    stage_load(ib_last - 8);
+    const int r0 = 2 * wv, r1 = r0 + 1;
+    double s0 = (ok && ib_last + r0 < nb) ? y[(long)(K0 + ib_last + r0) * ld + j] : 0.0;
+    double s1 = (ok && ib_last + r1 < nb) ? y[(long)(K0 + ib_last + r1) * ld + j] : 0.0;
+    for (int ib = ib_last, b = 0; ib >= 0; ib -= 8, b ^= 1) {
+        __syncthreads();
+        stage_store(b ^ 1);
+        stage_load(ib - 16);
+        const double s0n = (ok && ib >= 8) ? y[(long)(K0 + ib - 8 + r0) * ld + j] : 0.0;
+        const double s1n = (ok && ib >= 8) ? y[(long)(K0 + ib - 8 + r1) * ld + j] : 0.0;
+        const double *u0 = Ut[b][r0], *u1 = Ut[b][r1];
+#pragma unroll 8
+        for (int k = nb - 1; k >= ib + 8; --k) {
+            const double xk = xs[k][lane];
+            s0 = __builtin_fma(-u0[k], xk, s0);
+            s1 = __builtin_fma(-u1[k], xk, s1);
+        }
+        sx[r0][lane] = s0;
+        sx[r1][lane] = s1;
+        __syncthreads();
+        double x[8];
+#pragma unroll
+        for (int r = 7; r >= 0; --r) {
+            double v = sx[r][lane];
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+                if (k > r) v = __builtin_fma(-Ut[b][r][ib + k], x[k], v);
+            v = v / Ut[b][r][ib + r];
+            x[r] = v;
+            if (r == r0 || r == r1) {
+                if (ib + r < nb) xs[ib + r][lane] = v;
+                if (ok && ib + r < nb) y[(long)(K0 + ib + r) * ld + j] = v;
+            }
+        }
+        s0 = s0n;
+        s1 = s1n;
+    }
+}
+
+// back substitution update: Y(i, :) -= sum_k U(i, K0 + k) X(K0 + k, :) for the rows i < K0 above a solved block (K = nb <= 128,
+// nrhs <= 136 right-hand sides).  A skinny product (136 columns) of one K-tile: on the MFMA kernel it costs a whole 128 x 128 x 128
+// tile's latency (41 us) for two column tiles, one of them 94 % empty.  Here the block of X (<= 139 KB) is staged in LDS once per
+// workgroup, 15 rows of U beside it, and each thread keeps 8 outputs of one row: 8 fused multiply-adds per 5 LDS reads.
+constexpr int BS_ROWS = 15, BS_CG = 17;                       // 15 rows x 17 column groups of 8 = 255 threads
+__global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls)
+{
+    y += ls.w * blockIdx.y; U += ls.w * blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) double bs_lds[];
+    double *xs = bs_lds;                                      // [nb][BS_CG * 8]
+    double *us = bs_lds + LU_NBO * BS_CG * 8;                 // [BS_ROWS][nb]
+    const int tid = threadIdx.x;
+    constexpr int XW = BS_CG * 8;
+    // (loads in batches of 17 / 8 per thread: a one-element-per-iteration loop waited for every load before the next, 54 us)
+    for (int e0 = 0; e0 < nb * XW; e0 += 256 * 17) {
+        double v[17];
+#pragma unroll
+        for (int m = 0; m < 17; ++m) {
+            const int e = e0 + tid + 256 * m, k = e / XW, o = e % XW;
+            v[m] = (e < nb * XW && o < nrhs) ? y[(long)(K0 + k) * ld + o] : 0.0;
+        }
+#pragma unroll
+        for (int m = 0; m < 17; ++m) {
+            const int e = e0 + tid + 256 * m;
+            if (e < nb * XW) xs[e] = v[m];
+        }
+    }
+    const int row0 = blockIdx.x * BS_ROWS;
+    {
+        double v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
+            v[m] = (r < BS_ROWS && k < nb && row0 + r < K0) ? U[(long)(row0 + r) * ld + K0 + k] : 0.0;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
+            if (r < BS_ROWS) us[r * LU_NBO + k] = v[m];
+        }
+    }
+    __syncthreads();
+    const int r = tid / BS_CG, g = tid % BS_CG;
+    if (r >= BS_ROWS || row0 + r >= K0) return;
+    double acc[8];
+    double *yp = y + (long)(row0 + r) * ld + g * 8;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = g * 8 + o < nrhs ? yp[o] : 0.0;
+    const double *ur = us + r * LU_NBO;
+    for (int k = nb - 1; k >= 0; --k) {                       // descending k, as the column-oriented dtrsm subtracts
+        const double u = ur[k];
+        const double *xk = xs + k * XW + g * 8;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = __builtin_fma(-u, xk[o], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+        if (g * 8 + o < nrhs) yp[o] = acc[o];
 }
 
 template <bool A_KC, bool B_KC>
 int gemm(const double *A, long sai, long sak, const double *B, long sbj, long sbk, double *C, long ldc, int M, int N, int K,
-         double alpha, int lower_only, hipStream_t st)
+         double alpha, int lower_only, hipStream_t st, int nbatch = 1, GemmBatch gb = GemmBatch{0, 0, 0})
 {
     if (M <= 0 || N <= 0 || K <= 0) return SML_OK;
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    hipLaunchKernelGGL((k_gemm_acc<A_KC, B_KC>), grid, dim3(GT), 0, st, A, sai, sak, B, sbj, sbk, C, ldc, M, N, K, alpha, lower_only);
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, nbatch);
+    hipLaunchKernelGGL((k_gemm_acc<A_KC, B_KC>), grid, dim3(GT), 0, st, A, sai, sak, B, sbj, sbk, C, ldc, M, N, K, alpha, lower_only, gb);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
 
 // C += alpha * A * B^T for row-contiguous operands: LDS-DMA kernel on the part of K that is a multiple of 16 (when the
 // alignment conditions hold), general kernel on the tail.
+// padded: both operands may be read one row past M / N (the LU's buffers are padded to 16 rows / columns).
 int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int M, int N, int K, double alpha, int lower_only,
-            hipStream_t st)
+            hipStream_t st, bool force_dma = false, bool padded = false, int nbatch = 1, GemmBatch gb = GemmBatch{0, 0, 0})
 {
     if (M <= 0 || N <= 0 || K <= 0) return SML_OK;
     auto ok = [](const double *p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0; };
     int kmain = 0;
     // short K (the shipped batch size m = 98) is bound by the read-modify-write of C: one pass with the general kernel
     // beats main + tail passes.  Long K (m = 2920, the 40-year configuration) takes the LDS-DMA kernel.
-    if (ok(A, lda) && ok(B, ldb) && M >= 2 && N >= 2 && K >= 512) {
+    const int Mr = padded ? (M + 1) & ~1 : M, Nr = padded ? (N + 1) & ~1 : N;
+    if (ok(A, lda) && ok(B, ldb) && M >= 2 && N >= 2 && !(Mr & 1) && !(Nr & 1) && (K >= 512 || (force_dma && K >= DKT))) {
         kmain = (K / DKT) * DKT;
         const int nbi = (M + BM - 1) / BM, nbj = (N + BN - 1) / BN;
         if (!lower_only || nbi != nbj)
-            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi, nbj), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0);
+            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi, nbj, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0, Mr, Nr, gb);
         else
-            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi * (nbi + 1) / 2), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 1);
+            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi * (nbi + 1) / 2, 1, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 1, Mr, Nr, gb);
         SML_HIP(hipGetLastError());
     }
     if (kmain < K)
-        return gemm<false, false>(A + (long)kmain * lda, 1, lda, B + (long)kmain * ldb, 1, ldb, C, ldc, M, N, K - kmain, alpha, lower_only, st);
+        return gemm<false, false>(A + (long)kmain * lda, 1, lda, B + (long)kmain * ldb, 1, ldb, C, ldc, M, N, K - kmain, alpha, lower_only, st, nbatch, gb);
     return SML_OK;
 }
 
@@ -662,62 +993,218 @@ int sml_train_symmetrize(double *c, int n_aug, void *stream)
     return SML_OK;
 }
 
-// enqueue one ridge solve on `st` (no synchronisation): W, ipiv are scratch of size n_aug*(n_aug+n_out) / n_aug, info_dev one int
-static int fit_enqueue(double *c, const double *b, int n, int n_model, int n_out, double beta_res, double beta_model, double prior_val,
-                       int using_prior, double *wout, double *w, int *ipiv, int *info, hipStream_t st)
+// ---- host side of the LU ----
+struct LuSys {                 // scratch and streams of one batch of factorisations
+    int nbatch = 0;
+    double *w = nullptr, *p[2] = {nullptr, nullptr}, *tmp = nullptr;
+    int *ipiv = nullptr, *info = nullptr;
+    const double **c_list = nullptr, **b_list = nullptr;      // device arrays of the callers' pointers
+    double **wout_list = nullptr;
+    hipStream_t sp = nullptr, sg = nullptr;
+    hipEvent_t ev_panel = nullptr, ev_strip = nullptr;
+    LuStride ls{};
+};
+
+static void lu_sys_free(LuSys &s)
+{
+    if (s.w) (void)hipFree(s.w);
+    for (int i = 0; i < 2; ++i) if (s.p[i]) (void)hipFree(s.p[i]);
+    if (s.tmp) (void)hipFree(s.tmp);
+    if (s.ipiv) (void)hipFree(s.ipiv);
+    if (s.info) (void)hipFree(s.info);
+    if (s.c_list) (void)hipFree((void *)s.c_list);
+    if (s.b_list) (void)hipFree((void *)s.b_list);
+    if (s.wout_list) (void)hipFree((void *)s.wout_list);
+    if (s.sp) (void)hipStreamDestroy(s.sp);
+    if (s.sg) (void)hipStreamDestroy(s.sg);
+    if (s.ev_panel) (void)hipEventDestroy(s.ev_panel);
+    if (s.ev_strip) (void)hipEventDestroy(s.ev_strip);
+    s = LuSys{};
+}
+
+static inline long lu_pad16(long v) { return (v + 15) & ~15L; }
+static inline bool lu_dma() { static const bool v = !(getenv("SML_LU_DMA") && atoi(getenv("SML_LU_DMA")) == 0); return v; }
+
+static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
+{
+    const long ld = lu_pad16(ncols), np = lu_pad16(n_aug);
+    s.nbatch = nbatch;
+    s.ls = LuStride{(long)n_aug * ld, (long)LU_NBO * np, 2L * LU_NBO * ld, n_aug};
+    SML_HIP(hipMalloc((void **)&s.w, (size_t)nbatch * s.ls.w * sizeof(double)));
+    for (int i = 0; i < 2; ++i) SML_HIP(hipMalloc((void **)&s.p[i], (size_t)nbatch * s.ls.p * sizeof(double)));
+    SML_HIP(hipMalloc((void **)&s.tmp, (size_t)nbatch * s.ls.tmp * sizeof(double)));
+    SML_HIP(hipMalloc((void **)&s.ipiv, (size_t)nbatch * n_aug * sizeof(int)));
+    SML_HIP(hipMalloc((void **)&s.info, (size_t)nbatch * sizeof(int)));
+    SML_HIP(hipMalloc((void **)&s.c_list, (size_t)nbatch * sizeof(double *)));
+    SML_HIP(hipMalloc((void **)&s.b_list, (size_t)nbatch * sizeof(double *)));
+    SML_HIP(hipMalloc((void **)&s.wout_list, (size_t)nbatch * sizeof(double *)));
+    SML_HIP(hipStreamCreateWithFlags(&s.sp, hipStreamNonBlocking));
+    // The trailing updates run on a stream whose CU mask leaves a few compute units free: a leaf workgroup needs a whole CU
+    // (all of its registers), and behind an unmasked GEMM grid it waited for one to drain (measured: 250 us instead of 30).
+    {
+        static const int reserve_env = getenv("SML_LU_RESERVE") ? atoi(getenv("SML_LU_RESERVE")) : -1;
+        const int reserve = reserve_env >= 0 ? reserve_env : std::max(16, 2 * nbatch);
+        int dev = 0, ncu = 0;
+        SML_HIP(hipGetDevice(&dev));
+        SML_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (reserve > 0 && reserve < ncu) {
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+            SML_HIP(hipExtStreamCreateWithCUMask(&s.sg, (uint32_t)mask.size(), mask.data()));
+        } else
+            SML_HIP(hipStreamCreateWithFlags(&s.sg, hipStreamNonBlocking));
+    }
+    SML_HIP(hipEventCreateWithFlags(&s.ev_panel, hipEventDisableTiming));
+    SML_HIP(hipEventCreateWithFlags(&s.ev_strip, hipEventDisableTiming));
+    return SML_OK;
+}
+
+// leaf shape by height: (threads, rows per thread, columns); R x LW doubles + ~56 registers must stay within 256
+struct LeafShape { int threads, slots, width; };
+static LeafShape leaf_shape(int rows_left)
+{
+    if (rows_left <= 14 * 256) return {256, (rows_left + 255) / 256, 8};
+    const int r = (rows_left + 511) / 512;
+    return {512, r, r <= 12 ? 8 : 6};
+}
+
+static int leaf_width(int rows_left) { return leaf_shape(rows_left).width; }
+
+static long long *g_lu_stamps = nullptr;                     // SML_LU_STAMP=1: 32 words per leaf (slot = first column / 2) of system 0
+constexpr int LU_STAMP_LEAVES = 4096;
+
+static int launch_leaf(LuSys &S, int nb, long np, int n, int K0, int c, int lw, int nbp)
+{
+    const LeafShape sh = leaf_shape(n - c);
+    long long *stamps = (g_lu_stamps && c / 2 < LU_STAMP_LEAVES) ? g_lu_stamps + 32 * (c / 2) : nullptr;
+    hipStream_t st = S.sp;
+    double *Pk = S.p[(K0 / LU_NBO) & 1];
+#define LEAF_CASE(T, R, LW)                                                                                                                      \
+    case R:                                                                                                                                      \
+        if (lw == LW) hipLaunchKernelGGL((k_lu_leaf<T, R, LW, true>), dim3(nb), dim3(T), 0, st, Pk, np, n, K0, c, lw, nbp, S.ipiv, S.info, stamps, S.ls);  \
+        else hipLaunchKernelGGL((k_lu_leaf<T, R, LW, false>), dim3(nb), dim3(T), 0, st, Pk, np, n, K0, c, lw, nbp, S.ipiv, S.info, stamps, S.ls);          \
+        break
+    if (sh.threads == 256) {
+        switch (sh.slots) {
+            LEAF_CASE(256, 1, 8); LEAF_CASE(256, 2, 8); LEAF_CASE(256, 3, 8); LEAF_CASE(256, 4, 8); LEAF_CASE(256, 5, 8); LEAF_CASE(256, 6, 8);
+            LEAF_CASE(256, 7, 8); LEAF_CASE(256, 8, 8); LEAF_CASE(256, 9, 8); LEAF_CASE(256, 10, 8); LEAF_CASE(256, 11, 8); LEAF_CASE(256, 12, 8);
+            LEAF_CASE(256, 13, 8); LEAF_CASE(256, 14, 8);
+        default: return sml::fail(SML_ERR_STATE, "sml_train_fit: no leaf kernel for %d rows", n - c);
+        }
+    } else {
+        switch (sh.slots) {
+            LEAF_CASE(512, 8, 8); LEAF_CASE(512, 9, 8); LEAF_CASE(512, 10, 8); LEAF_CASE(512, 11, 8); LEAF_CASE(512, 12, 8);
+            LEAF_CASE(512, 13, 6); LEAF_CASE(512, 14, 6);
+        default: return sml::fail(SML_ERR_ARG, "sml_train_fit: n_aug = %d exceeds the %d rows the register-resident LU leaf holds", n, 14 * 512);
+        }
+    }
+#undef LEAF_CASE
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+// trailing update W[c0.., j0..j1) -= L21 U12 (row-major C: the contiguous column index j is the MFMA kernel's i)
+static int lu_trailing(LuSys &S, int nb, long ld, long np, int n_aug, int K0, int nbp, int j0, int j1, const double *Pk)
+{
+    const int c0 = K0 + nbp;
+    return gemm_nt(S.w + (long)K0 * ld + j0, ld, Pk + c0, np, S.w + (long)c0 * ld + j0, ld, j1 - j0, n_aug - c0, nbp, -1.0, 0, S.sg, lu_dma(), /*padded=*/true,
+                   nb, GemmBatch{S.ls.w, S.ls.p, S.ls.w});
+}
+
+// enqueue the ridge solves of systems [first, first + nb) (no host synchronisation): everything is ordered on S.sg / S.sp
+static int fit_enqueue(double *const *c, const double *const *b, int first, int nb, int n, int n_model, int n_out, double beta_res, double beta_model,
+                       double prior_val, int using_prior, double *const *wout, LuSys &S)
 {
     const int n_aug = n + n_model, ncols = n_aug + n_out;
-    constexpr int NB = LU_NB;
+    const long ld = lu_pad16(ncols), np = lu_pad16(n_aug);
+    const LuStride ls = S.ls;
     int rc;
-    if ((rc = sml_train_symmetrize(c, n_aug, (void *)st))) return rc;
-    SML_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    for (int i = 0; i < nb; ++i)
+        if ((rc = sml_train_symmetrize(c[first + i], n_aug, (void *)S.sg))) return rc;
+    SML_HIP(hipMemsetAsync(S.info, 0, sizeof(int) * nb, S.sg));
+    SML_HIP(hipMemcpyAsync((void *)S.c_list, c + first, sizeof(double *) * nb, hipMemcpyHostToDevice, S.sg));
+    SML_HIP(hipMemcpyAsync((void *)S.b_list, b + first, sizeof(double *) * nb, hipMemcpyHostToDevice, S.sg));
+    SML_HIP(hipMemcpyAsync((void *)S.wout_list, wout + first, sizeof(double *) * nb, hipMemcpyHostToDevice, S.sg));
     // with a prior the betas enter squared (quirk Q8, src/mod_reservoir.f90:1271-1290)
     const double reg_model = using_prior ? beta_model * beta_model : beta_model;
     const double reg_res = using_prior ? beta_res * beta_res : beta_res;
     const double prior_diag = using_prior ? prior_val * (beta_model * beta_model) : 0.0;
-    const long total = (long)n_aug * ncols;
-    hipLaunchKernelGGL(k_build_system, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c, b, w, n_aug, n_model, n_out,
-                       reg_model, reg_res, prior_diag);
-    rc = SML_OK;
-    for (int k0 = 0; k0 < n_aug && rc == SML_OK; k0 += NB) {
-        const int nb = std::min(NB, n_aug - k0);
-        static const int old_panel = getenv("SML_LU_OLD_PANEL") ? atoi(getenv("SML_LU_OLD_PANEL")) : 0;
-        if (old_panel || n_aug - k0 > PBT * RPT)
-            hipLaunchKernelGGL(k_panel, dim3(1), dim3(PT), 0, st, w, n_aug, k0, nb, ipiv, info);
-        else
-            hipLaunchKernelGGL(k_panel_blocked, dim3(1), dim3(PBT), 0, st, w, n_aug, k0, nb, ipiv, info);
-        hipLaunchKernelGGL(k_swap, dim3((ncols - nb + 255) / 256), dim3(256), 0, st, w, n_aug, ncols, k0, nb, ipiv);
-        const int rest_cols = ncols - (k0 + nb), rest_rows = n_aug - (k0 + nb);
-        if (rest_cols > 0) {
-            hipLaunchKernelGGL(k_trsm_lower, dim3((rest_cols + TRSM_T - 1) / TRSM_T), dim3(TRSM_T), 0, st, w, n_aug, ncols, k0, nb);
-            if (rest_rows > 0)
-                rc = gemm<false, true>(w + (k0 + nb) + (long)k0 * n_aug, 1, n_aug,                  // L21(i,k)
-                                       w + k0 + (long)(k0 + nb) * n_aug, n_aug, 1,                 // U12(k,j) as B(j,k)
-                                       w + (k0 + nb) + (long)(k0 + nb) * n_aug, n_aug, rest_rows, rest_cols, nb, -1.0, 0, st);
+    hipLaunchKernelGGL(k_build_system, dim3((unsigned)((ld + 255) / 256), n_aug, nb), dim3(256), 0, S.sg, S.c_list, S.b_list, S.w, ld, n_aug, n_model, n_out,
+                       reg_model, reg_res, prior_diag, ls);
+    SML_HIP(hipGetLastError());
+    auto strip_to_panel = [&](int K0, int nbp, double *P) {
+        hipLaunchKernelGGL(k_lu_strip_to_panel, dim3((n_aug - K0 + 31) / 32, (nbp + 31) / 32, nb), dim3(256), 0, S.sg, S.w, ld, P, np, n_aug, K0, nbp, ls);
+    };
+    strip_to_panel(0, std::min(LU_NBO, n_aug), S.p[0]);
+    SML_HIP(hipEventRecord(S.ev_strip, S.sg));
+    for (int K0 = 0, k = 0; K0 < n_aug; K0 += LU_NBO, ++k) {
+        const int nbp = std::min(LU_NBO, n_aug - K0);
+        double *Pk = S.p[k & 1];
+        SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));
+        for (int cc = K0, lw = 0; cc < K0 + nbp; cc += lw) {
+            lw = std::min(leaf_width(n_aug - cc), K0 + nbp - cc);
+            if ((rc = launch_leaf(S, nb, np, n_aug, K0, cc, lw, nbp))) return rc;
+            const int rows = n_aug - (cc + lw), cols = K0 + nbp - (cc + lw);
+            if (rows > 0 && cols > 0)
+                hipLaunchKernelGGL(k_lu_panel_update, dim3((rows + 255) / 256, (cols + PU_COLS - 1) / PU_COLS, nb), dim3(256), 0, S.sp, Pk, np, n_aug, K0, cc, lw,
+                                   nbp, ls);
         }
+        SML_HIP(hipGetLastError());
+        SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+        SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+        const int c0 = K0 + nbp;
+        hipLaunchKernelGGL(k_lu_swap_gather, dim3((ncols - c0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, S.sg, S.w, ld, c0, ncols, K0, nbp, S.ipiv, S.tmp, ls);
+        hipLaunchKernelGGL(k_lu_trsm_scatter, dim3((ncols - c0 + 63) / 64, nb), dim3(TR_T), 0, S.sg, Pk, np, S.w, ld, K0, nbp, c0, ncols, S.ipiv, S.tmp, ls);
+        SML_HIP(hipGetLastError());
+        if (c0 < n_aug) {
+            const int nbn = std::min(LU_NBO, n_aug - c0);
+            if ((rc = lu_trailing(S, nb, ld, np, n_aug, K0, nbp, c0, c0 + nbn, Pk))) return rc;       // the next panel's columns first
+            strip_to_panel(c0, nbn, S.p[(k + 1) & 1]);
+            SML_HIP(hipGetLastError());
+            SML_HIP(hipEventRecord(S.ev_strip, S.sg));
+            if ((rc = lu_trailing(S, nb, ld, np, n_aug, K0, nbp, c0 + nbn, ncols, Pk))) return rc;    // the rest runs beside the next leaf chain
+        }
+        hipLaunchKernelGGL(k_lu_u11_to_w, dim3((nbp + 31) / 32, (nbp + 31) / 32, nb), dim3(256), 0, S.sg, Pk, np, S.w, ld, K0, nbp, ls);
+        SML_HIP(hipGetLastError());
     }
-    // back substitution on the right-hand sides
-    for (int k0 = ((n_aug - 1) / NB) * NB; k0 >= 0 && rc == SML_OK; k0 -= NB) {
-        const int nb = std::min(NB, n_aug - k0);
-        hipLaunchKernelGGL(k_trsm_upper, dim3((n_out + TRSM_T - 1) / TRSM_T), dim3(TRSM_T), 0, st, w, n_aug, ncols, k0, nb);
-        if (k0 > 0)
-            rc = gemm<false, true>(w + (long)k0 * n_aug, 1, n_aug,                                  // U(i, k0+k), i < k0
-                                   w + k0 + (long)n_aug * n_aug, n_aug, 1,                          // X(k0+k, j) as B(j,k)
-                                   w + (long)n_aug * n_aug, n_aug, k0, n_out, nb, -1.0, 0, st);
+    // back substitution on the right-hand sides (columns n_aug .. ncols of W)
+    SML_REQUIRE(n_out <= BS_CG * 8, "sml_train_fit: n_out = %d exceeds the %d right-hand sides of the back substitution kernel", n_out, BS_CG * 8);
+    const size_t bs_lds = (size_t)(LU_NBO * BS_CG * 8 + BS_ROWS * LU_NBO) * sizeof(double);
+    static bool bs_attr = false;
+    if (!bs_attr) {
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
+        bs_attr = true;
     }
-    if (rc == SML_OK) {
-        const long tw = (long)n_aug * n_out;
-        hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, st, w, wout, n_aug, n_out);
-        if (hipGetLastError() != hipSuccess) rc = sml::fail(SML_ERR_HIP, "k_extract_wout launch failed");
+    for (int K0 = ((n_aug - 1) / LU_NBO) * LU_NBO; K0 >= 0; K0 -= LU_NBO) {
+        const int nbk = std::min(LU_NBO, n_aug - K0);
+        hipLaunchKernelGGL(k_lu_trsm_upper, dim3((n_out + 63) / 64, nb), dim3(TR_T), 0, S.sg, S.w + n_aug, S.w + (long)K0 * ld + K0, ld, K0, nbk, n_out, ls);
+        if (K0 > 0)
+            hipLaunchKernelGGL(k_lu_backsub_update, dim3((K0 + BS_ROWS - 1) / BS_ROWS, nb), dim3(256), bs_lds, S.sg, S.w + n_aug, S.w, ld, K0, nbk, n_out, ls);
+        SML_HIP(hipGetLastError());
     }
-    return rc;
+    const long tw = (long)n_aug * n_out;
+    hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256), nb), dim3(256), 0, S.sg, S.w, ld, S.wout_list, n_aug, n_out, ls);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
 }
 
-// Several independent ridge solves at once.  One LU is latency-bound on its panel kernel (a single workgroup finds each
-// pivot), so up to FIT_STREAMS systems are kept in flight on separate streams: the panels of one system run beside the
-// trailing updates of the others.  All systems share the sizes (n, n_model, n_out); c/b/wout are host arrays of device
-// pointers.  Synchronises; returns SML_ERR_NUMERIC if any system is singular (sml_last_error names the first).
-constexpr int FIT_STREAMS = 8;
+// Several independent ridge solves at once: up to FIT_BATCH equally sized systems are factorised in lockstep by ONE chain of
+// launches (the grid's batch dimension), so the latency-bound leaf chain is paid once per batch and the trailing updates of all of
+// them fill the chip together.  c/b/wout are host arrays of device pointers.  Synchronises; returns SML_ERR_NUMERIC if any system is
+// singular (sml_last_error names the first).
+// The scratch of a batch (per system: the row-major system, two panel buffers, the gathered rows: ~310 MB at n_aug = 5892) and its
+// streams are kept between calls: allocating them took 12 ms of a 43 ms call.  sml_train_release_workspace frees them.
+constexpr int FIT_BATCH = 8;
+static LuSys g_lu;
+static int g_lu_n = 0, g_lu_cols = 0;
+
+int sml_train_release_workspace(void)
+{
+    lu_sys_free(g_lu);
+    g_lu_n = g_lu_cols = 0;
+    return SML_OK;
+}
+
 int sml_train_fit_batched(int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res,
                           double beta_model, double prior_val, int using_prior, double *const *wout, void *stream)
 {
@@ -725,46 +1212,46 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
     for (int i = 0; i < count; ++i) SML_REQUIRE(c[i] && b[i] && wout[i], "sml_train_fit_batched: null system %d", i);
     hipStream_t st = sml::as_stream(stream);
     const int n_aug = n + n_model, ncols = n_aug + n_out;
-    const int ns = std::min(count, FIT_STREAMS);
-    std::vector<hipStream_t> streams(ns, nullptr);
-    std::vector<double *> w(ns, nullptr);
-    std::vector<int *> ipiv(ns, nullptr);
-    int *info = nullptr;
-    hipEvent_t fork = nullptr;
+    const int nbmax = std::min(count, FIT_BATCH);
     int rc = SML_OK;
-    auto cleanup = [&]() {
-        for (int i = 0; i < ns; ++i) {
-            if (w[i]) (void)hipFree(w[i]);
-            if (ipiv[i]) (void)hipFree(ipiv[i]);
-            if (streams[i] && ns > 1) (void)hipStreamDestroy(streams[i]);
-        }
-        if (info) (void)hipFree(info);
-        if (fork) (void)hipEventDestroy(fork);
-    };
-#define FB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return sml::fail(SML_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
-    FB_HIP(hipMalloc((void **)&info, sizeof(int) * count));
-    FB_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    FB_HIP(hipEventRecord(fork, st));
-    for (int i = 0; i < ns; ++i) {
-        if (ns == 1) streams[i] = st;
-        else { FB_HIP(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking)); FB_HIP(hipStreamWaitEvent(streams[i], fork, 0)); }
-        FB_HIP(hipMalloc((void **)&w[i], (size_t)n_aug * ncols * sizeof(double)));
-        FB_HIP(hipMalloc((void **)&ipiv[i], (size_t)n_aug * sizeof(int)));
+    if (g_lu_n != n_aug || g_lu_cols != ncols || g_lu.nbatch < nbmax) {
+        sml_train_release_workspace();
+        if ((rc = lu_sys_alloc(g_lu, n_aug, ncols, nbmax))) { sml_train_release_workspace(); return rc; }
+        g_lu_n = n_aug; g_lu_cols = ncols;
     }
-    for (int i = 0; i < count && rc == SML_OK; ++i) {
-        const int s_ = i % ns;
-        rc = fit_enqueue(c[i], b[i], n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout[i], w[s_], ipiv[s_], info + i, streams[s_]);
+    static const bool want_stamps = getenv("SML_LU_STAMP") && atoi(getenv("SML_LU_STAMP"));
+    if (want_stamps && !g_lu_stamps) {
+        SML_HIP(hipMalloc((void **)&g_lu_stamps, sizeof(long long) * 32 * LU_STAMP_LEAVES));
+        SML_HIP(hipMemset(g_lu_stamps, 0, sizeof(long long) * 32 * LU_STAMP_LEAVES));
     }
+    // the caller's stream must have produced C and B before the factorisation's streams read them
+    hipEvent_t fork = nullptr;
+    SML_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    hipError_t fe = hipEventRecord(fork, st);
+    if (fe == hipSuccess) fe = hipStreamWaitEvent(g_lu.sg, fork, 0);
+    (void)hipEventDestroy(fork);
+    if (fe != hipSuccess) return sml::fail(SML_ERR_HIP, "sml_train_fit_batched: %s", hipGetErrorString(fe));
     std::vector<int> hinfo(count, 0);
-    for (int i = 0; i < ns; ++i) {
-        hipError_t e = hipStreamSynchronize(streams[i]);
+    for (int first = 0; first < count && rc == SML_OK; first += g_lu.nbatch) {
+        const int nb = std::min(g_lu.nbatch, count - first);
+        rc = fit_enqueue(c, b, first, nb, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, g_lu);
+        // (the pointer lists and info are reused by the next batch: wait for this one)
+        hipError_t e = hipStreamSynchronize(g_lu.sg);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_lu.sp);
         if (e != hipSuccess && rc == SML_OK) rc = sml::fail(SML_ERR_HIP, "sml_train_fit_batched: %s", hipGetErrorString(e));
+        if (rc == SML_OK && hipMemcpy(hinfo.data() + first, g_lu.info, sizeof(int) * nb, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = sml::fail(SML_ERR_HIP, "sml_train_fit_batched: reading info failed");
     }
-    if (rc == SML_OK && hipMemcpy(hinfo.data(), info, sizeof(int) * count, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = sml::fail(SML_ERR_HIP, "sml_train_fit_batched: reading info failed");
-#undef FB_HIP
-    cleanup();
     if (rc) return rc;
+    if (g_lu_stamps) {
+        std::vector<long long> h(32 * LU_STAMP_LEAVES);
+        if (hipMemcpy(h.data(), g_lu_stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(getenv("SML_LU_STAMP_FILE") ? getenv("SML_LU_STAMP_FILE") : "lu_stamps.bin", "wb")) {
+                fwrite(h.data(), sizeof(long long), h.size(), f);
+                fclose(f);
+            }
+        }
+    }
     for (int i = 0; i < count; ++i)
         if (hinfo[i]) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", i, hinfo[i], hinfo[i], hinfo[i]);
     return SML_OK;
