@@ -664,22 +664,19 @@ __global__ __launch_bounds__(256) void k_lu_u11_to_w(const double *__restrict__ 
     }
 }
 
-// tmp[idx][j] = W[src(idx)][j] for the columns j >= c0 to the right of the panel: the rows as they will read after the panel's
-// nbp interchanges.  Position idx < 128 is row K0 + idx, idx >= 128 is row ipiv[K0 + idx - 128]; after the interchanges position
-// x holds what was at src(x) = s_0(s_1(... s_{nbp-1}(x))), s_t = transposition (K0 + t, ipiv[K0 + t]) -- every workgroup works
-// that out for its own position (128 LDS broadcasts).  Nothing is written into W here, so no ordering between positions is
-// needed and no column walks a dependent chain of 128 swaps.
-__global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict__ w, long ld, int c0, int ncols, int K0, int nbp, const int *__restrict__ ipiv,
-                                                         double *__restrict__ tmp, LuStride ls)
+// The composite permutation of a panel's nbp interchanges on the <= 2 nbp rows they touch.  Position idx < 128 is row K0 + idx,
+// idx >= 128 is row ipiv[K0 + idx - 128]; after the interchanges position x holds what was at
+// src(x) = s_0(s_1(... s_{nbp-1}(x))), s_t = transposition (K0 + t, ipiv[K0 + t]).  One thread per position, the pivots read from
+// LDS 16 at a time.  (Worked out inside every workgroup of the gather kernel instead, that kernel took 22 - 37 us.)
+__global__ __launch_bounds__(256) void k_lu_perm_src(int K0, int nbp, const int *__restrict__ ipiv, int *__restrict__ src, LuStride ls)
 {
-    w += ls.w * blockIdx.z; ipiv += ls.ipiv * blockIdx.z; tmp += ls.tmp * blockIdx.z;
+    ipiv += ls.ipiv * blockIdx.x; src += 2 * LU_NBO * blockIdx.x;
     __shared__ int piv[LU_NBO];
     if (threadIdx.x < LU_NBO) piv[threadIdx.x] = (int)threadIdx.x < nbp ? ipiv[K0 + threadIdx.x] : K0 + (int)threadIdx.x;
     __syncthreads();
-    int idx = blockIdx.y;
-    if (idx >= nbp) idx += LU_NBO - nbp;                      // second half of the position list starts at 128
+    const int idx = threadIdx.x;
     int x = idx < LU_NBO ? K0 + idx : piv[idx - LU_NBO];
-    for (int t0 = nbp - 1; t0 >= 0; t0 -= 16) {               // 16 pivots per batch of LDS reads (one by one: 22 us per launch)
+    for (int t0 = nbp - 1; t0 >= 0; t0 -= 16) {
         int pv[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) pv[u] = piv[max(t0 - u, 0)];
@@ -689,9 +686,21 @@ __global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict
             if (t >= 0) x = (x == d) ? p : (x == p ? d : x);
         }
     }
+    src[idx] = x;
+}
+
+// tmp[idx][j] = W[src(idx)][j] for the columns j >= c0 to the right of the panel: the rows as they will read after the panel's
+// interchanges.  Nothing is written into W here, so no ordering between positions is needed and no column walks a dependent
+// chain of 128 swaps.
+__global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict__ w, long ld, int c0, int ncols, int nbp, const int *__restrict__ src,
+                                                         double *__restrict__ tmp, LuStride ls)
+{
+    w += ls.w * blockIdx.z; src += 2 * LU_NBO * blockIdx.z; tmp += ls.tmp * blockIdx.z;
     const int j = c0 + blockIdx.x * 256 + threadIdx.x;
+    int idx = blockIdx.y;
+    if (idx >= nbp) idx += LU_NBO - nbp;                      // second half of the position list starts at 128
     if (j >= ncols) return;
-    tmp[(long)idx * ld + j] = w[(long)x * ld + j];
+    tmp[(long)idx * ld + j] = w[(long)src[idx] * ld + j];
 }
 
 // U12 = L11^-1 A12 for 64 columns per workgroup of four wavefronts, A12 read from the gathered rows; the displaced rows (positions
@@ -844,17 +853,19 @@ __global__ __launch_bounds__(TR_T) void k_lu_trsm_upper(double *__restrict__ y, 
 // back substitution update: Y(i, :) -= sum_k U(i, K0 + k) X(K0 + k, :) for the rows i < K0 above a solved block (K = nb <= 128,
 // nrhs <= 136 right-hand sides).  A skinny product (136 columns) of one K-tile: on the MFMA kernel it costs a whole 128 x 128 x 128
 // tile's latency (41 us) for two column tiles, one of them 94 % empty.  Here the block of X (<= 139 KB) is staged in LDS once per
-// workgroup, 15 rows of U beside it, and each thread keeps 8 outputs of one row: 8 fused multiply-adds per 5 LDS reads.
-constexpr int BS_ROWS = 15, BS_CG = 17;                       // 15 rows x 17 column groups of 8 = 255 threads
+// workgroup with 24 rows of U beside it (all 160 KB: one workgroup per CU, 240 workgroups cover 5760 rows in one round -- staging X
+// is the cost of a workgroup, so fewer and taller workgroups win: 15 rows per workgroup took 39 us per launch), and each thread
+// keeps 8 outputs of two rows: 16 fused multiply-adds per 6 LDS reads.
+constexpr int BS_ROWS = 24, BS_CG = 17;                       // 12 row pairs x 17 column groups of 8 = 204 threads
 __global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls)
 {
     y += ls.w * blockIdx.y; U += ls.w * blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) double bs_lds[];
     double *xs = bs_lds;                                      // [nb][BS_CG * 8]
-    double *us = bs_lds + LU_NBO * BS_CG * 8;                 // [BS_ROWS][nb]
+    double *us = bs_lds + LU_NBO * BS_CG * 8;                 // [BS_ROWS][LU_NBO]
     const int tid = threadIdx.x;
     constexpr int XW = BS_CG * 8;
-    // (loads in batches of 17 / 8 per thread: a one-element-per-iteration loop waited for every load before the next, 54 us)
+    // (loads in batches of 17 / 12 per thread: a one-element-per-iteration loop waited for every load before the next, 54 us)
     for (int e0 = 0; e0 < nb * XW; e0 += 256 * 17) {
         double v[17];
 #pragma unroll
@@ -870,35 +881,47 @@ __global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ 
     }
     const int row0 = blockIdx.x * BS_ROWS;
     {
-        double v[8];
+        double v[12];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 12; ++m) {
             const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
-            v[m] = (r < BS_ROWS && k < nb && row0 + r < K0) ? U[(long)(row0 + r) * ld + K0 + k] : 0.0;
+            v[m] = (k < nb && row0 + r < K0) ? U[(long)(row0 + r) * ld + K0 + k] : 0.0;
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 12; ++m) {
             const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
-            if (r < BS_ROWS) us[r * LU_NBO + k] = v[m];
+            us[r * LU_NBO + k] = v[m];
         }
     }
     __syncthreads();
-    const int r = tid / BS_CG, g = tid % BS_CG;
-    if (r >= BS_ROWS || row0 + r >= K0) return;
-    double acc[8];
-    double *yp = y + (long)(row0 + r) * ld + g * 8;
+    const int rp = tid / BS_CG, g = tid % BS_CG;              // row pair, column group
+    const int r = 2 * rp;
+    if (rp >= BS_ROWS / 2 || row0 + r >= K0) return;
+    const bool two = row0 + r + 1 < K0;
+    double acc0[8], acc1[8];
+    double *yp0 = y + (long)(row0 + r) * ld + g * 8, *yp1 = yp0 + ld;
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = g * 8 + o < nrhs ? yp[o] : 0.0;
-    const double *ur = us + r * LU_NBO;
+    for (int o = 0; o < 8; ++o) {
+        acc0[o] = g * 8 + o < nrhs ? yp0[o] : 0.0;
+        acc1[o] = (two && g * 8 + o < nrhs) ? yp1[o] : 0.0;
+    }
+    const double *ur0 = us + r * LU_NBO, *ur1 = ur0 + LU_NBO;
     for (int k = nb - 1; k >= 0; --k) {                       // descending k, as the column-oriented dtrsm subtracts
-        const double u = ur[k];
+        const double u0 = ur0[k], u1 = ur1[k];
         const double *xk = xs + k * XW + g * 8;
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = __builtin_fma(-u, xk[o], acc[o]);
+        for (int o = 0; o < 8; ++o) {
+            const double xv = xk[o];
+            acc0[o] = __builtin_fma(-u0, xv, acc0[o]);
+            acc1[o] = __builtin_fma(-u1, xv, acc1[o]);
+        }
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o)
-        if (g * 8 + o < nrhs) yp[o] = acc[o];
+        if (g * 8 + o < nrhs) {
+            yp0[o] = acc0[o];
+            if (two) yp1[o] = acc1[o];
+        }
 }
 
 template <bool A_KC, bool B_KC>
@@ -997,7 +1020,7 @@ int sml_train_symmetrize(double *c, int n_aug, void *stream)
 struct LuSys {                 // scratch and streams of one batch of factorisations
     int nbatch = 0;
     double *w = nullptr, *p[2] = {nullptr, nullptr}, *tmp = nullptr;
-    int *ipiv = nullptr, *info = nullptr;
+    int *ipiv = nullptr, *info = nullptr, *src = nullptr;
     const double **c_list = nullptr, **b_list = nullptr;      // device arrays of the callers' pointers
     double **wout_list = nullptr;
     hipStream_t sp = nullptr, sg = nullptr;
@@ -1012,6 +1035,7 @@ static void lu_sys_free(LuSys &s)
     if (s.tmp) (void)hipFree(s.tmp);
     if (s.ipiv) (void)hipFree(s.ipiv);
     if (s.info) (void)hipFree(s.info);
+    if (s.src) (void)hipFree(s.src);
     if (s.c_list) (void)hipFree((void *)s.c_list);
     if (s.b_list) (void)hipFree((void *)s.b_list);
     if (s.wout_list) (void)hipFree((void *)s.wout_list);
@@ -1035,6 +1059,7 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
     SML_HIP(hipMalloc((void **)&s.tmp, (size_t)nbatch * s.ls.tmp * sizeof(double)));
     SML_HIP(hipMalloc((void **)&s.ipiv, (size_t)nbatch * n_aug * sizeof(int)));
     SML_HIP(hipMalloc((void **)&s.info, (size_t)nbatch * sizeof(int)));
+    SML_HIP(hipMalloc((void **)&s.src, (size_t)nbatch * 2 * LU_NBO * sizeof(int)));
     SML_HIP(hipMalloc((void **)&s.c_list, (size_t)nbatch * sizeof(double *)));
     SML_HIP(hipMalloc((void **)&s.b_list, (size_t)nbatch * sizeof(double *)));
     SML_HIP(hipMalloc((void **)&s.wout_list, (size_t)nbatch * sizeof(double *)));
@@ -1153,7 +1178,8 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         SML_HIP(hipEventRecord(S.ev_panel, S.sp));
         SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
         const int c0 = K0 + nbp;
-        hipLaunchKernelGGL(k_lu_swap_gather, dim3((ncols - c0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, S.sg, S.w, ld, c0, ncols, K0, nbp, S.ipiv, S.tmp, ls);
+        hipLaunchKernelGGL(k_lu_perm_src, dim3(nb), dim3(256), 0, S.sg, K0, nbp, S.ipiv, S.src, ls);
+        hipLaunchKernelGGL(k_lu_swap_gather, dim3((ncols - c0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, S.sg, S.w, ld, c0, ncols, nbp, S.src, S.tmp, ls);
         hipLaunchKernelGGL(k_lu_trsm_scatter, dim3((ncols - c0 + 63) / 64, nb), dim3(TR_T), 0, S.sg, Pk, np, S.w, ld, K0, nbp, c0, ncols, S.ipiv, S.tmp, ls);
         SML_HIP(hipGetLastError());
         if (c0 < n_aug) {
