@@ -757,3 +757,35 @@ class PhysHook:
         s = self.s
         return self.ref.phypar(ug, vg, tg, qg, phig, pslg, s["fmask"], s["phis0"], s["tland"], s["tsea"], s["swav"], self.lradsw,
                                ut, vt, tt, qt)[:4]
+
+
+def oracle_rest_state(o, phi0_grid, hsg):
+    """invars with istart = 0 (src/ini_invars.f90:27-111): the reference atmosphere at rest over the surface geopotential
+    phi0_grid[48][96] (m2/s2) -- zero vorticity / divergence, 288 K at z = 0 with a 6 K/km lapse rate under a 216 K stratosphere,
+    log(ps) in hydrostatic balance with it, tropospheric humidity from the reference relative humidity.  Returns (level-1 dict of
+    oracle-layout arrays vor/div/t/tr (62,32,8), ps (62,32); phis (62,32)).  Complex (1.,0.)*sqrt(2) = the (re, im) pair of
+    coefficient (1,1)."""
+    gamma, hscale, hshum, refrh1, grav = 6.0, 7.5, 2.5, 0.7, 9.81
+    rgas = 2.0 / 7.0 * 1004.0
+    fsg = 0.5 * (np.asarray(hsg)[1:] + np.asarray(hsg)[:-1])
+    gam1 = gamma / (1000.0 * grav)
+    ccon = np.sqrt(2.0)
+    phis = o.trunct(o.spec(np.asarray(phi0_grid, dtype=np.float64).T))
+    phis0 = o.grid(phis, 1)                                   # Fortran (ix, il)
+    out = {k: np.zeros(S3) for k in ("vor", "div", "t", "tr")}
+    tref, ttop = 288.0, 216.0
+    gam2, rgam = gam1 / tref, rgas * gam1
+    rgamr = 1.0 / rgam
+    surfs = -gam1 * phis
+    surfs[0, 0] = ccon * tref - gam1 * phis[0, 0]
+    out["t"][0, 0, 0] = out["t"][0, 0, 1] = ccon * ttop
+    for k in range(2, KX):
+        out["t"][..., k] = surfs * fsg[k] ** rgam
+    rlog0 = np.log(1.013)
+    surfg = rlog0 + rgamr * np.log(1.0 - gam2 * phis0)
+    out["ps"] = o.trunct(o.spec(surfg))
+    qref, qexp = refrh1 * 0.622 * 17.0, hscale / hshum
+    qs = o.trunct(o.spec(qref * np.exp(qexp * surfg)))
+    for k in range(2, KX):
+        out["tr"][..., k] = qs * fsg[k] ** qexp
+    return out, phis

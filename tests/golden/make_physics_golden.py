@@ -105,12 +105,12 @@ def coupled_inputs(seed=5):
     return o, st, phis, {k: surf[k] for k in ("fmask", "phis0", "tland", "tsea", "swav", "snowc", "alb_l", "alb_s", "albsfc")}
 
 
-def run_coupled_reference(o, st, phis, surf, ref, nsteps=WINDOW_STEPS, delt=900.0):
+def run_coupled_reference(o, st, phis, surf, ref, nsteps=WINDOW_STEPS, delt=900.0, tyear=TYEAR):
     """stepone + nsteps leapfrog steps (src/ini_stepone.f90, src/dyn_stloop.f90:28-43) with the oracle's dynamics and, in grtend's
     physics slot (src/dyn_grtend.f90:222-225), the compiled reference parametrisations."""
     from _oracle import DynOracle
     ref.set_surface(surf["phis0"], surf["alb_l"], surf["alb_s"], surf["albsfc"], surf["snowc"])
-    ref.sol_oz(TYEAR)
+    ref.sol_oz(tyear)
     do = DynOracle(o)
     zero = np.zeros((62, 32))
     flag = {"lradsw": True}

@@ -1,0 +1,150 @@
+"""GPU: BASELINE config 1 -- SPEEDY-only T30L8 free run from rest, reservoir off (src/at_gcm.f90:84-90 agcm_1day -> src/dyn_stloop.f90:26-43,
+started by invars with istart = 0, src/ini_invars.f90:27-111, and stepone, src/ini_stepone.f90) -- on the device: stepone + 960 leapfrog
+steps of 900 s (10 days = 40 six-hour windows) with the column physics attached, short-wave radiation every third step
+(mod(istep, nstrad) == 1 with istep running through the days, 96 % 3 == 0) and the daily solar / ozone fields (fordate -> sol_oz).
+
+Parity: the first two windows (stepone + 48 steps) against the oracle's dynamics with the compiled reference parametrisations in
+grtend's physics slot, 1e-10 of each field's max-abs (the discrete switches of the parametrisations make longer trajectories
+incomparable).  Beyond that, the size-independent properties of the run: everything finite, the global mean of log(ps)
+untouched (psdt(1,1) = 0), temperatures and winds physical, the atmosphere spins up from rest, and a second run reproduces the
+first bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from make_physics_golden import HSG, gaussian_latitudes, physics_inputs  # noqa: E402
+
+from speedy_ml_amd import synth  # noqa: E402
+from speedy_ml_amd.dynamics import F_DIV, F_PS, F_T, F_TR, F_VOR, Dynamics  # noqa: E402
+from speedy_ml_amd.physics import Physics  # noqa: E402
+from speedy_ml_amd.spectral import Spectral  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+KEYS = ("vor", "div", "t", "tr", "ps")
+SURF = ("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc")
+STEPS_PER_WINDOW, WINDOWS, WINDOWS_PER_DAY = 24, 40, 4
+TYEAR0 = 0.0                                                   # 1 January (iyear0/imont0 = 1982/01, src/ini_agcm_init.f90:33-45)
+
+
+def to_state(lvl):
+    """level-1 dict -> device state[2][33][32][62]; level 2 is undefined before stepone (src/ini_stepone.f90) and set to 1e30"""
+    s = np.full((2, 33, 32, 62), 1e30)
+    for off, k in ((F_VOR, "vor"), (F_DIV, "div"), (F_T, "t"), (F_TR, "tr")):
+        s[0, off:off + 8] = lvl[k].transpose(2, 1, 0)
+    s[0, F_PS] = lvl["ps"].T
+    return torch.from_numpy(s).cuda()
+
+
+def from_state(t):
+    s = t.cpu().numpy()
+    out = {k: np.stack([s[j, off:off + 8].transpose(2, 1, 0) for j in range(2)], axis=-1) for off, k in ((F_VOR, "vor"), (F_DIV, "div"), (F_T, "t"), (F_TR, "tr"))}
+    out["ps"] = np.stack([s[j, F_PS].T for j in range(2)], axis=-1)
+    return out
+
+
+def surface():
+    surf = physics_inputs(0)
+    # the rest state's surface geopotential is the orography itself; the synthetic surface fields sit on the same mask
+    surf["phis0"] = np.maximum(0.0, synth.synthetic_orography().ravel())
+    return {k: surf[k] for k in SURF}
+
+
+def free_run(lvl, phis, surf, windows, keep_after=None):
+    sp = Spectral()
+    dyn = Dynamics(sp)
+    spec2 = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    zero = np.zeros((62, 32))
+    dyn.set_boundary(spec2(phis), spec2(zero), spec2(zero))
+    ph = Physics(gaussian_latitudes())
+    ph.set_surface(*[np.asarray(surf[k]).reshape(48, 96) for k in SURF])
+    dyn.attach_physics(ph)
+    state = to_state(lvl)
+    kept = None
+    for w in range(windows):
+        if w % WINDOWS_PER_DAY == 0:
+            ph.sol_oz(TYEAR0 + (w // WINDOWS_PER_DAY) / 365.0)          # fordate(1) once a day (src/at_gcm.f90:75)
+        dyn.window(state, STEPS_PER_WINDOW, start=(w == 0))
+        if keep_after is not None and w + 1 == keep_after:
+            torch.cuda.synchronize()
+            kept = state.clone()
+    torch.cuda.synchronize()
+    return state, kept, sp
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def test_first_two_windows_match_oracle_with_reference_physics(oracle):
+    """stepone + 48 leapfrog steps from rest against the oracle's dynamics with the compiled reference parametrisations in grtend's
+    physics slot (oracle/_ref/libref_phy.so, built from the reference's own phy_*.f90)."""
+    from _oracle import RefPhys, oracle_rest_state
+    if not RefPhys.available():
+        pytest.skip("oracle/_ref/libref_phy.so not present")
+    from make_physics_golden import run_coupled_reference
+    lvl, phis = oracle_rest_state(oracle, synth.synthetic_orography(), HSG)
+    surf = surface()
+    state, _, _ = free_run(lvl, phis, surf, 2)
+    got = from_state(state)
+    st = {k: np.stack([lvl[k], np.full_like(lvl[k], 1e30)], axis=-1) for k in KEYS}
+    want = run_coupled_reference(oracle, st, phis, surf, RefPhys(HSG, gaussian_latitudes()), nsteps=2 * STEPS_PER_WINDOW, tyear=TYEAR0)
+    for k in KEYS:
+        assert rel(got[k], want[k]) < 1e-10, (k, rel(got[k], want[k]))
+    assert np.max(np.abs(want["vor"])) > 0                     # the physics set the atmosphere in motion
+
+
+def test_speedy_only_free_run_from_rest(oracle):
+    """ten days (stepone + 960 steps): the run's size-independent properties"""
+    from _oracle import oracle_rest_state
+    lvl, phis = oracle_rest_state(oracle, synth.synthetic_orography(), HSG)
+    surf = surface()
+    state, _, sp = free_run(lvl, phis, surf, WINDOWS)
+    end = from_state(state)
+    for k in KEYS:
+        assert np.all(np.isfinite(end[k])), k
+    assert end["ps"][0, 0, 0] == lvl["ps"][0, 0] and end["ps"][0, 0, 1] == lvl["ps"][0, 0]          # global mean of log(ps)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(2, 1, 0))).cuda()
+    tg = sp.grid(dev(end["t"][..., 0]), 1).cpu().numpy()
+    assert 150.0 < tg.min() and tg.max() < 340.0, (tg.min(), tg.max())
+    ucos, vcos = sp.uvspec(dev(end["vor"][..., 0]), dev(end["div"][..., 0]))
+    ug, vg = sp.grid(ucos, 2).cpu().numpy(), sp.grid(vcos, 2).cpu().numpy()
+    wind = np.sqrt(ug ** 2 + vg ** 2)
+    assert 1.0 < wind.max() < 150.0, wind.max()                                                       # spun up from rest, and physical
+    assert rel(end["t"][..., 0], lvl["t"]) > 1e-4
+    # ---- and repeatable bit for bit ----
+    again, _, _ = free_run(lvl, phis, surf, WINDOWS)
+    assert torch.equal(again, state)
+
+
+def test_hybrid_style_windows_restart_with_stepone(oracle):
+    """The hybrid's use of SPEEDY (40 windows, each restarted with stepone from time level 1, src/mpires.f90:1637 -> agcm_main) on the
+    same rest state: finite and physical for ten days, and not the continuous run (the starter steps damp the computational mode)."""
+    from _oracle import oracle_rest_state
+    lvl, phis = oracle_rest_state(oracle, synth.synthetic_orography(), HSG)
+    surf = surface()
+    cont, _, sp = free_run(lvl, phis, surf, 8)
+    sp2 = Spectral()
+    dyn = Dynamics(sp2)
+    spec2 = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    zero = np.zeros((62, 32))
+    dyn.set_boundary(spec2(phis), spec2(zero), spec2(zero))
+    ph = Physics(gaussian_latitudes())
+    ph.set_surface(*[np.asarray(surf[k]).reshape(48, 96) for k in SURF])
+    dyn.attach_physics(ph)
+    state = to_state(lvl)
+    for w in range(WINDOWS):
+        if w % WINDOWS_PER_DAY == 0:
+            ph.sol_oz(TYEAR0 + (w // WINDOWS_PER_DAY) / 365.0)
+        dyn.window(state, STEPS_PER_WINDOW, start=True)
+        if w == 7:
+            torch.cuda.synchronize()
+            eight = state.clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(state[0]).all()
+    tg = sp2.grid(state[0, F_T:F_T + 8].contiguous(), 1).cpu().numpy()
+    assert 150.0 < tg.min() and tg.max() < 340.0
+    assert not torch.equal(eight[0], cont[0])

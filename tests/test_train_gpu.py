@@ -107,10 +107,12 @@ def test_singular_matrix_fails_loudly():
         train.fit_chunk_hybrid(c, b, n, 0, n_out, 0.0, 0.0, 0.0, False)
 
 
-def test_full_size_gram_against_torch_fp64():
-    """BASELINE config 4 shape: n=5760, n_model=132, n_out=136, m=98 (shipped batch size)."""
+@pytest.mark.parametrize("m", [98, 2920])
+def test_full_size_gram_against_torch_fp64(m):
+    """BASELINE config 4 shape: n=5760, n_model=132, n_out=136; m=98 (shipped batch size, general kernel) and m=2920 (the
+    40-year configuration, LDS-DMA kernel)."""
     torch.manual_seed(5)
-    n, n_model, n_out, m = 5760, 132, 136, 98
+    n, n_model, n_out = 5760, 132, 136
     n_aug = n + n_model
     states = torch.randn((m, n), dtype=torch.float64, device="cuda")
     model = torch.randn((m, n_model), dtype=torch.float64, device="cuda")
@@ -220,3 +222,49 @@ def test_batched_fit_equals_single(oracle):
     batched = train.fit_chunk_hybrid_batched(cs, bs, n, n_model, n_out)
     for w1, w2 in zip(single, batched):
         assert np.array_equal(w1, to_host(w2))
+
+
+def test_full_size_ridge_fit_of_a_driven_reservoir():
+    """BASELINE config 4 at full size: the 5892 x 5892 system with 136 right-hand sides that fit_chunk_hybrid hands to dgesv
+    (src/mod_reservoir.f90:1235-1334, src/mod_linalg.f90:109-151), built from the Gram matrices of a DRIVEN region-954 reservoir:
+    12 batches of 98 columns, so C has rank <= 1176 << 5892 and the ridge (beta_res^2 = 1e-6, beta_model^2 = 1) alone makes it
+    regular (condition number ~1e9..1e10).  Checked against LAPACK's dgesv itself (numpy.linalg.solve: the routine the
+    reference calls) through (i) the normwise backward error of the device solution, (ii) the agreement of the two W_out in what
+    they predict on the training columns -- ||(W - W_ref) aug||_F / ||W_ref aug||_F evaluated through the Gram matrix -- and (iii)
+    the entries of W_out to cond * eps."""
+    from speedy_ml_amd.reservoir import ReservoirBank
+    from speedy_ml_amd.synth import make_reservoir
+    n, d, n_model, n_out = 5760, 576, 132, 136
+    n_aug = n + n_model
+    r = make_reservoir(n=n, d=d, n_model=n_model, n_out=n_out, seed=20240954)
+    bank = ReservoirBank(1)
+    bank.load(0, n, d, n_model, n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
+    rng = np.random.default_rng(954)
+    batch, discard = 98, 40
+    T = discard + 12 * batch
+    drive = np.zeros((T, d))
+    e = rng.standard_normal((T, d)) * 0.3
+    for t in range(1, T):
+        drive[t] = 0.95 * drive[t - 1] + e[t]
+    noisy = np.zeros((T, 1, 576))
+    noisy[:, 0, :d] = drive
+    targ = drive[:, :n_out].T + 0.05 * rng.standard_normal((n_out, T))
+    model = targ[:n_model] * 0.9 + 0.1 * rng.standard_normal((n_model, T))
+    cs, bs = [train.fortran_zeros(n_aug, n_aug)], [train.fortran_zeros(n_out, n_aug)]
+    nb = bank.train_pass(torch.from_numpy(noisy).cuda(), discard, batch, [to_dev(model)], [to_dev(targ)], cs, bs)
+    assert nb == 12                                   # steps i = 1 .. T - discard - 1 flush whenever (i + 1) % 98 == 0
+    beta_res, beta_model = 1e-3, 1.0
+    wg = to_host(train.fit_chunk_hybrid(cs[0], bs[0], n, n_model, n_out, beta_res, beta_model, 0.0, True))
+    c, b = to_host(cs[0]), to_host(bs[0])            # the fit mirrored C's lower triangle into the upper one
+    assert np.array_equal(c, c.T)
+    a = c + np.diag(np.r_[np.full(n_model, beta_model ** 2), np.full(n, beta_res ** 2)])
+    want = np.linalg.solve(a.T, b.T).T                # dgesv
+    resid = a.T @ wg.T - b.T
+    eta = np.linalg.norm(resid) / (np.linalg.norm(a) * np.linalg.norm(wg) + np.linalg.norm(b))
+    resid_ref = a.T @ want.T - b.T
+    eta_ref = np.linalg.norm(resid_ref) / (np.linalg.norm(a) * np.linalg.norm(want) + np.linalg.norm(b))
+    assert eta <= 1e-15 + 4.0 * eta_ref, (eta, eta_ref)
+    dw = wg - want
+    pred = np.sqrt(np.trace(dw @ c @ dw.T) / np.trace(want @ c @ want.T))
+    assert pred <= 1e-9, pred
+    assert np.max(np.abs(dw)) <= 1e-5 * np.max(np.abs(want)), np.max(np.abs(dw)) / np.max(np.abs(want))
