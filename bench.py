@@ -34,6 +34,7 @@ def parse():
                     help="sweep = reservoir predict sweep only; ml_only = the reference's ML-only forecast loop (predict_ml + exchange, no "
                          "SPEEDY); development aids, the driver uses the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training", action="store_true", help="skip the BASELINE config 4 training-kernel block (N = 1 only) of the JSON line")
     ap.add_argument("--slab", action="store_true", help="BASELINE config 5: add the 1152-region slab-ocean reservoirs and their coupling")
     ap.add_argument("--no-physics", action="store_true", help="adiabatic SPEEDY window (development aid: isolates the cost of the column physics)")
     ap.add_argument("--regions", type=int, default=1152, help=argparse.SUPPRESS)
@@ -162,6 +163,108 @@ def cpu_baseline(model, budget_s=12.0):
             "all_cores": {"value": 1.0 / total_par, "unit": "steps/s", "cores": ncores}}
 
 
+def training_block(with_cpu):
+    """BASELINE config 4 on this GPU, reported beside the hybrid step (rank 0, N = 1): the fp64-MFMA Gram accumulation of chunking_matmul
+    (src/mod_reservoir.f90:1645-1701) at the shipped batch size m = 98 and at the 40-year size m = 2920, the ridge solve of
+    fit_chunk_hybrid / dgesv (:1235-1334, src/mod_linalg.f90:109-151) for the 5892 x 5892 system with 136 right-hand sides, one at a
+    time and eight in one batch, and the device training pass (recurrence + Gram flushes) of eight resident full-size reservoirs.
+    Rooflines are EXECUTED flops (only tiles on / below the diagonal of C are computed) over the 78.6 TFLOP/s fp64 MFMA spec."""
+    import torch
+    from speedy_ml_amd import train
+    from speedy_ml_amd.reservoir import ReservoirBank
+    from speedy_ml_amd.synth import make_reservoir
+    PEAK = 78.6
+    n, d, n_model, n_out = 5760, 576, 132, 136
+    n_aug = n + n_model
+    dev = "cuda"
+
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    out = {"peak_tflops_fp64_mfma_spec": PEAK, "flop_convention": "executed (lower-triangle tiles of C + the skinny blocks)"}
+    nt = (n + 127) // 128
+    tiles = nt * (nt + 1) // 2
+    c = b = None
+    for m in (98, 2920):
+        states = torch.randn((m, n), dtype=torch.float64, device=dev)
+        model = torch.randn((m, n_model), dtype=torch.float64, device=dev)
+        y = torch.randn((m, n_out), dtype=torch.float64, device=dev)
+        c, b = train.fortran_zeros(n_aug, n_aug), train.fortran_zeros(n_out, n_aug)
+        for _ in range(2):
+            train.chunking_matmul(states, model, y, c, b)
+        dt = timed(lambda: train.chunking_matmul(states, model, y, c, b), 10 if m == 98 else 4)
+        executed = 2.0 * 128 * 128 * m * tiles + 2.0 * m * n_aug * (n_model + n_out)
+        out[f"gram_m{m}"] = {"ms": dt * 1e3, "tflops": executed / dt / 1e12, "frac": executed / dt / 1e12 / PEAK,
+                             "tflops_full_dgemm_convention": (2.0 * n_aug * n_aug * m + 2.0 * n_out * n_aug * m) / dt / 1e12}
+    # the ridge solve on the Gram matrix just accumulated (6 batches of 2920 columns) + the reference's regularisation
+    flops_lu = (2.0 / 3.0) * n_aug ** 3 + 2.0 * n_aug ** 2 * n_out
+    train.fit_chunk_hybrid(c, b, n, n_model, n_out)                                   # allocates the workspace
+    dt1 = timed(lambda: train.fit_chunk_hybrid(c, b, n, n_model, n_out), 3)
+    w = train.fit_chunk_hybrid(c, b, n, n_model, n_out)
+    reg = torch.diag(torch.cat([torch.full((n_model,), 1.0), torch.full((n,), 1e-6)])).to(dev, torch.float64)
+    resid = (c + reg) @ w - b                                                          # column-major buffers: torch [n_aug, n_out] = Z; C symmetric
+    berr = float(resid.norm() / (torch.linalg.matrix_norm(c + reg) * w.norm() + b.norm()))
+    del reg, resid
+    cs = [c.clone() for _ in range(8)]
+    train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out)                     # grows the workspace to 8 systems
+    dt8 = timed(lambda: train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out), 2)
+    out["ridge_solve_5892"] = {"ms": dt1 * 1e3, "tflops": flops_lu / dt1 / 1e12, "frac": flops_lu / dt1 / 1e12 / PEAK,
+                               "normwise_backward_error": berr,
+                               "batched8": {"ms_per_system": dt8 * 1e3 / 8, "tflops": 8 * flops_lu / dt8 / 1e12,
+                                            "frac": 8 * flops_lu / dt8 / 1e12 / PEAK}}
+    del cs
+    # the training pass (reservoir_layer_chunking_hybrid, :1067-1175) of 8 resident full-size reservoirs: 4 batches of the shipped size
+    nres, batch, discard = 8, 98, 40
+    T = discard + 4 * batch
+    bank = ReservoirBank(nres)
+    rs = [make_reservoir(n=n, d=d, n_model=n_model, n_out=n_out, seed=20240954 + i) for i in range(nres)]
+    for i, r in enumerate(rs):
+        bank.load(i, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
+    noisy = torch.randn((T, nres, 576), dtype=torch.float64, device=dev) * 0.5
+    models = [torch.randn((T, n_model), dtype=torch.float64, device=dev) for _ in range(nres)]
+    targs = [torch.randn((T, n_out), dtype=torch.float64, device=dev) for _ in range(nres)]
+    cs8 = [train.fortran_zeros(n_aug, n_aug) for _ in range(nres)]
+    bs8 = [train.fortran_zeros(n_out, n_aug) for _ in range(nres)]
+    bank.train_pass(noisy, discard, batch, models, targs, cs8, bs8)
+    dtp = timed(lambda: bank.train_pass(noisy, discard, batch, models, targs, cs8, bs8), 2)
+    per_batch = dtp / (4 * nres)
+    shipped_batches = 120                                                              # traininglength 12000 h, timestep 6, 20 batches per pass
+    per_res = shipped_batches * per_batch + dt8 / 8
+    out["train_pass"] = {"ms_per_reservoir_batch": per_batch * 1e3, "resident_reservoirs": nres, "batch_size": batch,
+                         "reservoirs_per_s_shipped_config": 1.0 / per_res,
+                         "note": "shipped config: 120 batches of m = 98 per reservoir (12000 h, 6 interleaved passes) + one ridge solve (batched 8)"}
+    bank.close()
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _oracle import Oracle
+        o = Oracle()
+        rng = np.random.default_rng(4)
+        mm = 4
+        st, md, yy = rng.standard_normal((n, mm)), rng.standard_normal((n_model, mm)), rng.standard_normal((n_out, mm))
+        co, bo = np.zeros((n_aug, n_aug), order="F"), np.zeros((n_out, n_aug), order="F")
+        t0 = time.perf_counter()
+        o.chunking_matmul(st, md, yy, co, bo)
+        t_gram = (time.perf_counter() - t0) * 98.0 / mm
+        ns = 1068
+        na = ns + n_model
+        a = rng.standard_normal((na, 2 * na))
+        cc = np.asfortranarray(a @ a.T)
+        bb = np.asfortranarray(rng.standard_normal((n_out, na)))
+        t0 = time.perf_counter()
+        o.fit_chunk_hybrid(ns, n_model, n_out, 1e-3, 1.0, 0.0, True, cc, bb)
+        t_fit = (time.perf_counter() - t0) * (n_aug / na) ** 3
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "gram_m98_s": t_gram, "ridge_solve_5892_s": t_fit,
+                               "reservoirs_per_s_shipped_config": 1.0 / (shipped_batches * t_gram + t_fit),
+                               "sample": f"oracle ro_chunking_matmul at full n with {mm} columns scaled to 98 (linear in m); oracle "
+                                         f"ro_fit_chunk_hybrid (unblocked LU) at n_aug = {na} scaled by (5892/{na})^3; recurrence not priced"}
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -270,6 +373,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is measured at N = 1 only (the other ranks would idle)
             line["cpu_baseline"] = cpu_baseline(model)
+        if not args.no_training and world == 1 and args.mode == "hybrid":
+            del model
+            torch.cuda.empty_cache()
+            line["training"] = training_block(not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
