@@ -327,6 +327,17 @@ def main():
     elapsed = time.perf_counter() - t_start
     kern = model.timing_collect()
     model.timing(False)
+    if model.aborted(wait=True):
+        raise SystemExit("bench.py: the range guard of iogrid(30) tripped -- the forecast loop stopped (src/mpires.f90:744); no number")
+    # every rank's view of the step: kernel and phase times (an N-GPU line is read through these: the SPEEDY leg is replicated)
+    per_rank = {"rank": rank, "regions": len(regions),
+                "update_ms": kern["update_ms"] / max(kern["update_launches"], 1), "readout_ms": kern["readout_ms"] / max(kern["readout_launches"], 1)}
+    for k, v in kern.get("phases_ms_per_step", {}).items():
+        per_rank[{"speedy": "speedy_ms", "allgather": "allgather_ms", "predict": "predict_ms", "scatter": "scatter_ms", "gather": "gather_ms"}[k]] = v
+    ranks = [per_rank]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, per_rank)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
@@ -363,6 +374,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": model.describe(),
+            "per_rank": ranks,
             "roofline": {"bound": "hbm", "kernel": "k_readout<17> (W_out [local_model;x~] GEMV, all resident reservoirs)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,

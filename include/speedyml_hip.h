@@ -73,6 +73,9 @@ typedef struct sml_res_sizes {
 /* processor_decomposition / processor_decomposition_manual (src/res_domain.f90:31-94).
  * Writes the regions owned by `rank`; returns their count (or <0). */
 int sml_domain_decompose(int rank, int nranks, int number_of_regions, int32_t *region_indices, int capacity);
+/* its inverse: the rank that owns `region` and the region's position in that rank's list (the remainder rule of
+ * src/res_domain.f90:53-60 puts the tail regions at position number_of_regions / nranks of ranks 1..left_over) */
+int sml_domain_region_owner(int nranks, int number_of_regions, int region, int *rank_out, int *slot_out);
 /* initializedomain (src/res_domain.f90:96-121) and everything it calls (:123-292, :547-600) */
 int sml_domain_region(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
                       int vert_overlap, sml_region *out);
@@ -229,14 +232,21 @@ int sml_handoff_check(const double *fields_dev, int32_t *safe_dev, void *stream)
 
 /* ---- RCCL from the C-ABI, for a multi-rank host that is not Python (Fortran under MPI): the step's one data-path collective.
  * One rank calls sml_comm_unique_id and distributes the 128 bytes (MPI_Bcast); every rank then calls sml_comm_create.
- * sml_comm_allgather_outvec: ncclAllGather of the bank's outvec slab ([capacity][max_n_out] per rank, equal on all ranks) into
- * all_outvec_dev [nranks*capacity][max_n_out] = the region-ordered slab of sml_exchange_scatter when the region count divides
- * by the rank count (src/mpires.f90:347-454).  librccl.so is resolved at the first call (dlopen), not at link time. */
+ * sml_comm_allgather_outvec: every rank ends up with all_outvec_dev [number_of_regions][max_n_out], the region-ordered slab of
+ * sml_exchange_scatter (the gather-to-root + root-side tiling of src/mpires.f90:347-454).  When the region count divides by the
+ * rank count and the bank holds exactly its share, this is ONE ncclAllGather of the bank's outvec slab straight into the result
+ * (no packing).  With the remainder of processor_decomposition (src/res_domain.f90:53-60: ranks 1..left_over own one extra
+ * region from the tail) every rank contributes number_of_regions / nranks + 1 slots through a padded staging slab and
+ * sml_comm_unpack_regions puts the rows in region order.  The bank's slot i must hold the rank's i-th region
+ * (sml_domain_decompose order).  librccl.so is resolved at the first call (dlopen), not at link time.
+ * sml_comm_unpack_regions: the reordering alone (stage_dev [nranks][slots_per_rank][max_n_out] -> region order); no RCCL. */
 typedef struct sml_comm sml_comm;
 int sml_comm_unique_id(char *id128);
 int sml_comm_create(int nranks, int rank, const char *id128, sml_comm **out);
 int sml_comm_destroy(sml_comm *comm);
-int sml_comm_allgather_outvec(sml_comm *comm, sml_bank *bank, double *all_outvec_dev, void *stream);
+int sml_comm_allgather_outvec(sml_comm *comm, sml_bank *bank, int number_of_regions, double *all_outvec_dev, void *stream);
+int sml_comm_unpack_regions(const double *stage_dev, int nranks, int slots_per_rank, int number_of_regions, int max_n_out,
+                            double *all_outvec_dev, void *stream);
 
 /* ---- slab-ocean coupling (config 5): the `ocean_model` branches of sendrecievegrid, src/mpires.f90:286-330, 470-484,
  * 756-790; sizes of initialize_slab_ocean_model, src/mod_slab_ocean_reservoir.f90:9-133.  The slab reservoirs live in a second

@@ -48,14 +48,14 @@ class ResSizes(C.Structure):
 EXPORTS = [
     "sml_last_error", "sml_version", "sml_device_count", "sml_set_device",
     "sml_stream_create_cu_mask", "sml_stream_destroy", "sml_dev_alloc", "sml_dev_free", "sml_dev_zero", "sml_dev_upload", "sml_dev_download",
-    "sml_domain_decompose", "sml_domain_region", "sml_domain_sizes", "sml_domain_out_map", "sml_domain_in_map", "sml_domain_message_sizes", "sml_domain_target_map", "sml_find_closest_divisor", "sml_calendar_date", "sml_hours_into_year", "sml_tisr_index",
+    "sml_domain_decompose", "sml_domain_region_owner", "sml_domain_region", "sml_domain_sizes", "sml_domain_out_map", "sml_domain_in_map", "sml_domain_message_sizes", "sml_domain_target_map", "sml_find_closest_divisor", "sml_calendar_date", "sml_hours_into_year", "sml_tisr_index",
     "sml_bank_create", "sml_bank_destroy", "sml_bank_load", "sml_bank_load_sparse_win", "sml_bank_set_wout",
     "sml_bank_set_state", "sml_bank_get_state", "sml_bank_set_feedback", "sml_bank_set_local_model",
     "sml_bank_get_outvec", "sml_bank_feedback_dev", "sml_bank_local_model_dev", "sml_bank_outvec_dev",
     "sml_bank_predict_all", "sml_bank_predict_one", "sml_bank_synchronize_all", "sml_bank_advance_all", "sml_bank_readout_part",
     "sml_bank_algorithmic_bytes", "sml_bank_readout_part_bytes", "sml_bank_timing", "sml_bank_timing_collect",
     "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
-    "sml_comm_unique_id", "sml_comm_create", "sml_comm_destroy", "sml_comm_allgather_outvec",
+    "sml_comm_unique_id", "sml_comm_create", "sml_comm_destroy", "sml_comm_allgather_outvec", "sml_comm_unpack_regions",
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",

@@ -62,7 +62,26 @@ int check(Rccl *r, int rc, const char *what)
 struct sml_comm {
     void *comm = nullptr;
     int nranks = 0, rank = 0;
+    double *send = nullptr, *stage = nullptr;          // padded contribution / gathered slabs of the ragged split
+    size_t send_count = 0, stage_count = 0;
 };
+
+namespace {
+
+// all_out[r][:] = stage[owner(r)][slot(r)][:]  (sml_domain_region_owner's rule)
+__global__ void k_unpack_regions(const double *__restrict__ stage, int nranks, int slots, int nreg, int width, double *__restrict__ all_out)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)nreg * width) return;
+    const int r = (int)(t / width), o = (int)(t % width);
+    const int per = nreg / nranks, left = nreg % nranks;
+    int rank, slot;
+    if (r < per * nranks) { rank = r / per; slot = r % per; }
+    else { rank = r - (nreg - left) + 1; slot = per; }
+    all_out[t] = stage[((long)rank * slots + slot) * width + o];
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -98,20 +117,57 @@ int sml_comm_destroy(sml_comm *c)
     if (!c) return SML_OK;
     Rccl *r;
     if (load(&r) == SML_OK && c->comm) (void)r->destroy(c->comm);
+    if (c->send) (void)hipFree(c->send);
+    if (c->stage) (void)hipFree(c->stage);
     delete c;
     return SML_OK;
 }
 
-int sml_comm_allgather_outvec(sml_comm *c, sml_bank *bank, double *all_outvec_dev, void *stream)
+int sml_comm_unpack_regions(const double *stage_dev, int nranks, int slots_per_rank, int number_of_regions, int max_n_out,
+                            double *all_outvec_dev, void *stream)
 {
-    SML_REQUIRE(c && bank && all_outvec_dev, "sml_comm_allgather_outvec: bad arguments");
+    SML_REQUIRE(stage_dev && all_outvec_dev && nranks > 0 && number_of_regions > 0 && max_n_out > 0, "sml_comm_unpack_regions: bad arguments");
+    const int per = number_of_regions / nranks, left = number_of_regions % nranks;
+    SML_REQUIRE(slots_per_rank >= per + (left ? 1 : 0), "sml_comm_unpack_regions: %d slots per rank cannot hold %d regions on %d ranks", slots_per_rank,
+                number_of_regions, nranks);
+    const long total = (long)number_of_regions * max_n_out;
+    hipLaunchKernelGGL(k_unpack_regions, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sml::as_stream(stream), stage_dev, nranks, slots_per_rank,
+                       number_of_regions, max_n_out, all_outvec_dev);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_comm_allgather_outvec(sml_comm *c, sml_bank *bank, int number_of_regions, double *all_outvec_dev, void *stream)
+{
+    SML_REQUIRE(c && bank && all_outvec_dev && number_of_regions > 0, "sml_comm_allgather_outvec: bad arguments");
     Rccl *r;
     int rc = load(&r);
     if (rc) return rc;
-    // every rank contributes its whole [capacity][max_n_out] slab: with processor_decomposition's equal blocks (the region count
-    // divides by the rank count) the result IS the region-ordered slab sml_exchange_scatter wants
-    const size_t count = (size_t)bank->capacity * bank->max_n_out;
-    return check(r, r->all_gather(bank->d_outvec, all_outvec_dev, count, NCCL_FLOAT64, c->comm, sml::as_stream(stream)), "ncclAllGather");
+    hipStream_t st = sml::as_stream(stream);
+    const int per = number_of_regions / c->nranks, left = number_of_regions % c->nranks;
+    const int mine = per + ((c->rank >= 1 && c->rank <= left) ? 1 : 0);
+    SML_REQUIRE(bank->capacity >= mine, "sml_comm_allgather_outvec: the bank holds %d slots, rank %d of %d owns %d of %d regions", bank->capacity, c->rank,
+                c->nranks, mine, number_of_regions);
+    const size_t width = (size_t)bank->max_n_out;
+    if (left == 0 && bank->capacity == per)       // equal blocks: the gathered slab IS the region-ordered slab
+        return check(r, r->all_gather(bank->d_outvec, all_outvec_dev, (size_t)per * width, NCCL_FLOAT64, c->comm, st), "ncclAllGather");
+    // ragged (or an over-sized bank): every rank contributes per + 1 slots; its own first `mine` are real
+    const int slots = per + 1;
+    const size_t send_count = (size_t)slots * width, stage_count = send_count * c->nranks;
+    if (c->send_count < send_count) {
+        if (c->send) (void)hipFree(c->send);
+        SML_HIP(hipMalloc((void **)&c->send, send_count * sizeof(double)));
+        SML_HIP(hipMemset(c->send, 0, send_count * sizeof(double)));
+        c->send_count = send_count;
+    }
+    if (c->stage_count < stage_count) {
+        if (c->stage) (void)hipFree(c->stage);
+        SML_HIP(hipMalloc((void **)&c->stage, stage_count * sizeof(double)));
+        c->stage_count = stage_count;
+    }
+    SML_HIP(hipMemcpyAsync(c->send, bank->d_outvec, (size_t)mine * width * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = check(r, r->all_gather(c->send, c->stage, send_count, NCCL_FLOAT64, c->comm, st), "ncclAllGather"))) return rc;
+    return sml_comm_unpack_regions(c->stage, c->nranks, slots, number_of_regions, bank->max_n_out, all_outvec_dev, stream);
 }
 
 }  // extern "C"

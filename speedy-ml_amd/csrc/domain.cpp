@@ -114,6 +114,17 @@ int sml_domain_decompose(int rank, int nranks, int number_of_regions, int32_t *r
     return count;
 }
 
+// the inverse of sml_domain_decompose: which rank owns `region`, and at which position of that rank's list
+int sml_domain_region_owner(int nranks, int number_of_regions, int region, int *rank_out, int *slot_out)
+{
+    SML_REQUIRE(nranks > 0 && number_of_regions > 0 && region >= 0 && region < number_of_regions && rank_out && slot_out,
+                "sml_domain_region_owner: bad arguments");
+    const int per = number_of_regions / nranks, left = number_of_regions % nranks;
+    if (region < per * nranks) { *rank_out = region / per; *slot_out = region % per; }
+    else { *rank_out = region - (number_of_regions - left) + 1; *slot_out = per; }     // the tail: one each for ranks 1..left_over
+    return SML_OK;
+}
+
 int sml_domain_region(int number_of_regions, int region_num, int overlap, int num_vert_levels, int vert_level,
                       int vert_overlap, sml_region *out)
 {

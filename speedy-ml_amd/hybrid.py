@@ -158,6 +158,8 @@ class HybridRank:
         self.start_hours = start_hours
         self.timestep_hours = 6
         self.t = 0
+        self._safe_ring, self._safe_ev, self._safe_n, self._aborted = None, None, 0, False
+        self._phase_on, self._phase_log = False, []
         if mode == "ml_only":
             # the reference's ml_only run (src/parallelmain.f90:229-231, src/mpires.f90:566,588): predict_ml, the same exchange,
             # no SPEEDY window, no local_model
@@ -424,17 +426,26 @@ class HybridRank:
             self.ex.gather(self.G, None, stream=stream)          # feedback only: there is no forecast to tile
             return
         if not self.pipeline:
+            if self.aborted():                                           # run_speedy == .false. ends the forecast loop
+                return False                                             # (src/mpires.f90:744, src/parallelmain.f90:269-271)
+            ph = self._phase_events(stream) if self._phase_on else None
             self.bank.predict(stream=stream)
             if self.slab is not None and self.slab.due(self.t + 1):      # mod(t*timestep, timestep_slab) == 0, parallelmain.f90:238
                 self.slab_predict_and_share(stream)
+            if ph: ph.mark("predict")
             allv = self.exchange_outvec(stream)
+            if ph: ph.mark("allgather")
             self.scatter_all(allv, stream)
+            if ph: ph.mark("scatter")
             self.speedy_leg(stream)
+            if ph: ph.mark("speedy")
             self.next_tisr()
             self.ex.gather(self.G, self.F, stream=stream)
             if self.slab is not None:
                 self.slab.update_inputs(self.t, stream=stream)
-            return
+            if ph: ph.mark("gather")
+            self._post_safe(stream)
+            return True
         assert self.slab is None, "the pipelined schedule does not carry the slab-ocean coupling"
         if self.main is not None:                               # CU-partitioned form: the whole main leg runs on the masked stream
             caller = stream
@@ -464,16 +475,82 @@ class HybridRank:
         self.ex.gather(None, self.F, stream=stream)             # local_model(t+1)
 
     # ------------------------------------------------------------------ measurement helpers
+    # ------------------------------------------------------------------ abort propagation (the range guard of iogrid(30))
+    # The reference's root sets run_speedy = .false. when SPEEDY's input is unphysical, broadcasts it (src/mpires.f90:744) and every
+    # rank leaves the forecast loop (src/parallelmain.f90:269-271).  Here every rank evaluates the guard itself (SPEEDY is
+    # replicated and deterministic, so all ranks see the same flag: no broadcast).  The flag lives on the device; each step copies
+    # it asynchronously into a pinned ring, and step() polls the COMPLETED copies without blocking -- the host stays ahead of the
+    # GPU and the loop stops within the few steps that were already enqueued.
+    SAFE_RING = 8
+
+    def _post_safe(self, stream):
+        if getattr(self, "safe", None) is None:
+            return
+        if self._safe_ring is None:
+            self._safe_ring = self.torch.ones(self.SAFE_RING, dtype=self.torch.int32).pin_memory()
+            self._safe_ev = [None] * self.SAFE_RING
+        k = self._safe_n % self.SAFE_RING
+        if self._safe_ev[k] is not None:
+            self._safe_ev[k].synchronize()                               # 8 steps old
+            if int(self._safe_ring[k]) == 0:
+                self._aborted = True
+        else:
+            self._safe_ev[k] = self.torch.cuda.Event()
+        self._safe_ring[k:k + 1].copy_(self.safe, non_blocking=True)
+        self._safe_ev[k].record(stream)
+        self._safe_n += 1
+
+    def aborted(self, wait=False):
+        """True once the range guard has tripped in a step whose flag has reached the host (wait=True: in any enqueued step)."""
+        if self._aborted or self._safe_ring is None:
+            return self._aborted
+        for k, ev in enumerate(self._safe_ev):
+            if ev is None:
+                continue
+            if wait:
+                ev.synchronize()
+            if ev.query() and int(self._safe_ring[k]) == 0:
+                self._aborted = True
+        return self._aborted
+
+    # ------------------------------------------------------------------ timing
+    class _Phases:
+        def __init__(self, torch, stream, sink):
+            self.torch, self.stream, self.sink = torch, stream, sink
+            self.last = torch.cuda.Event(enable_timing=True)
+            self.last.record(stream)
+
+        def mark(self, name):
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record(self.stream)
+            self.sink.append((name, self.last, ev))
+            self.last = ev
+
+    def _phase_events(self, stream):
+        return self._Phases(self.torch, stream, self._phase_log)
+
     def timing(self, on):
         from ._lib import check, lib
         check(lib().sml_bank_timing(self.bank._h, 1 if on else 0))
+        self._phase_on = bool(on) and self.mode == "hybrid" and not self.pipeline
 
     def timing_collect(self):
+        """per-kernel totals of the bank (HIP events around k_update / k_readout) and, for the sequential hybrid step, the time of
+        each phase of the step on this rank: predict, all-gather of the outvec slab, scatter + clamps, the SPEEDY leg, gather"""
         import ctypes as C
         from ._lib import check, lib
         um, rm, uc, rc = C.c_double(), C.c_double(), C.c_int(), C.c_int()
         check(lib().sml_bank_timing_collect(self.bank._h, C.byref(um), C.byref(uc), C.byref(rm), C.byref(rc)))
-        return {"update_ms": um.value, "update_launches": uc.value, "readout_ms": rm.value, "readout_launches": rc.value}
+        out = {"update_ms": um.value, "update_launches": uc.value, "readout_ms": rm.value, "readout_launches": rc.value}
+        if self._phase_log:
+            self.torch.cuda.synchronize()
+            tot, cnt = {}, {}
+            for name, a, b in self._phase_log:
+                tot[name] = tot.get(name, 0.0) + a.elapsed_time(b)
+                cnt[name] = cnt.get(name, 0) + 1
+            out["phases_ms_per_step"] = {k: tot[k] / cnt[k] for k in tot}
+            self._phase_log.clear()
+        return out
 
     def describe(self):
         if self.mode == "sweep":

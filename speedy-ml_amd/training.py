@@ -107,3 +107,41 @@ def train_reservoirs(bank, specs, traininglength, discardlength, timestep, beta_
             bank.set_wout(slot, host)
             out[slot] = dict(wout=host, batch_size=batch, batches=nb_total // timestep)
     return out
+
+
+def shard_plan(rank, world, number_of_regions, group=8):
+    """The regions rank `rank` of `world` trains, in bank-sized groups: processor_decomposition (src/res_domain.f90:31-62) exactly as
+    program main's training loop uses it (src/parallelmain.f90:82-128), cut into groups of `group` reservoirs that are resident
+    (and factorised) together.  Training has no collective: the ranks' region sets are disjoint and cover all regions."""
+    regions = [int(r) for r in domain.processor_decomposition_manual(rank, world, number_of_regions)]
+    return [regions[i:i + group] for i in range(0, len(regions), group)]
+
+
+def train_sharded(rank, world, number_of_regions, build, traininglength, discardlength, timestep, group=8, out_dir=None, trial="trial",
+                  **ridge):
+    """program main's training loop for one rank (src/parallelmain.f90:82-128): every region of shard_plan(rank, world, ...) is built
+    (`build(region)` -> dict with n, d, n_model, n_out, rows, cols, vals, win, mean, std, out_stat and the train_reservoirs spec keys
+    trainingdata / clean / imperfect_model / target_rows), trained in a bank of `group` slots and, when out_dir is given, written as
+    worker_RRRR_level_LL_<trial>.nc (write_trained_res, src/mod_reservoir.f90:1703-1737).  No rank talks to another.
+    Returns {region: W_out (n_out, n_aug), Fortran order}."""
+    from . import weights
+    from .reservoir import ReservoirBank
+    out = {}
+    for regions in shard_plan(rank, world, number_of_regions, group):
+        built = [build(r) for r in regions]
+        bank = ReservoirBank(len(regions), max_d=max(b["d"] for b in built), max_n_model=max(max(b["n_model"], 1) for b in built),
+                             max_n_out=max(b["n_out"] for b in built))
+        specs = []
+        for slot, b in enumerate(built):
+            bank.load(slot, b["n"], b["d"], b["n_model"], b["n_out"], b["rows"], b["cols"], b["vals"], b["win"],
+                      np.zeros((b["n_out"], b["n"] + b["n_model"])), b["mean"], b["std"], b.get("out_stat"))
+            specs.append({k: b[k] for k in ("n", "n_model", "n_out", "trainingdata", "clean", "imperfect_model", "target_rows") if k in b})
+        res = train_reservoirs(bank, specs, traininglength, discardlength, timestep, **ridge)
+        for slot, (region, b) in enumerate(zip(regions, built)):
+            out[region] = res[slot]["wout"]
+            if out_dir is not None:
+                import os
+                weights.write_trained_res(os.path.join(out_dir, weights.trained_res_filename(region, trial)), b["win"], res[slot]["wout"],
+                                          b["rows"], b["cols"], b["vals"], b["mean"], b["std"])
+        bank.close()
+    return out

@@ -55,3 +55,37 @@ def test_outvec_slab_gloo(world, tmp_path):
         assert ok == 1, f"rank {r} assembled a wrong slab"
         total += int(n)
     assert total == NREG
+
+
+def _plan_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+    load_package()
+    from speedy_ml_amd import training
+    mine = [r for g in training.shard_plan(rank, world, NREG, group=8) for r in g]
+    groups = [len(g) for g in training.shard_plan(rank, world, NREG, group=8)]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)             # only the TEST gathers: training itself has no collective
+    flat = sorted(r for lst in everyone for r in lst)
+    np.save(os.path.join(out_dir, f"plan_{rank}.npy"), np.array([flat == list(range(NREG)), max(groups) <= 8, len(mine)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_training_shards_are_disjoint_and_complete(world, tmp_path):
+    """config 4's 'reservoirs sharded 1 -> 8 GPUs': program main's training loop (src/parallelmain.f90:82-128) gives every rank the
+    regions of processor_decomposition; the ranks' sets are disjoint, cover all 1152 regions (remainder rule included) and are cut
+    into bank-sized groups."""
+    mp.spawn(_plan_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    total = 0
+    for r in range(world):
+        complete, groups_ok, n = np.load(tmp_path / f"plan_{r}.npy")
+        assert complete == 1 and groups_ok == 1
+        total += int(n)
+    assert total == NREG

@@ -85,8 +85,90 @@ def test_rccl_from_the_cabi_single_rank():
         bank.set_local_model(i, r.local_model)
     bank.predict()
     slab = torch.zeros((3, 6), dtype=torch.float64, device="cuda")
-    _lib.check(L.sml_comm_allgather_outvec(comm, bank._h, _lib.dp(slab.data_ptr()), None))
+    _lib.check(L.sml_comm_allgather_outvec(comm, bank._h, 3, _lib.dp(slab.data_ptr()), None))
     torch.cuda.synchronize()
     want = np.stack([bank.get_outvec(i) for i in range(3)])
     assert np.array_equal(slab.cpu().numpy(), want) and np.abs(want).max() > 0
     _lib.check(L.sml_comm_destroy(comm))
+
+
+def test_ragged_region_unpack_of_the_cabi():
+    """sml_comm_unpack_regions: the reordering sml_comm_allgather_outvec applies after a ragged all-gather (5 ranks x 231 slots for
+    1152 regions: ranks 1 and 2 own regions 1150 and 1151 at slot 230), checked on a staged slab built on the host."""
+    import ctypes as C
+    from speedy_ml_amd import _lib, domain
+    nranks, nreg, width = 5, 1152, 136
+    slots = nreg // nranks + 1
+    stage = np.full((nranks, slots, width), -7.0)
+    for p in range(nranks):
+        for i, r in enumerate(domain.processor_decomposition_manual(p, nranks, nreg)):
+            stage[p, i] = 1000.0 * int(r) + np.arange(width)
+    d_stage = torch.from_numpy(stage).cuda()
+    out = torch.zeros((nreg, width), dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().sml_comm_unpack_regions(_lib.dp(d_stage.data_ptr()), nranks, slots, nreg, width, _lib.dp(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    want = 1000.0 * np.arange(nreg)[:, None] + np.arange(width)[None, :]
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def _train_worker(rank, world, port, out_dir):
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from __graft_entry__ import load_package
+    load_package()
+    from speedy_ml_amd import training
+    from test_distributed_gpu import TRAIN_NREG, build_region, TRAIN_ARGS
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+
+    def no_collective(*a, **k):
+        raise AssertionError("training must not use a collective")
+    for name in ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast", "reduce_scatter"):
+        setattr(dist, name, no_collective)
+    res = training.train_sharded(rank, world, TRAIN_NREG, build_region, *TRAIN_ARGS, group=2, out_dir=out_dir, trial="shard")
+    np.savez(os.path.join(out_dir, f"train_rank{rank}.npz"), **{str(k): v for k, v in res.items()})
+    dist.destroy_process_group()
+
+
+TRAIN_NREG, TRAIN_ARGS = 5, (246, 6, 6)            # 5 regions over 2 ranks: 2 + 2 and the tail region on rank 1; 246 h, discard 6, timestep 6
+
+
+def build_region(region):
+    from speedy_ml_amd import training
+    from speedy_ml_amd.synth import make_reservoir
+    n, d, n_model, n_out = 96, 12, 4, 6
+    r = make_reservoir(n=n, d=d, n_model=n_model, n_out=n_out, seed=900 + region)
+    rng = np.random.default_rng(900 + region)
+    win = training.make_win(n, d, 0.5, rng.random((d, n // d)))
+    L = TRAIN_ARGS[0]
+    truth = np.cumsum(rng.standard_normal((d, L)) * 0.1, axis=1) * 0.2 + np.sin(np.arange(L) / 9.0 + region)[None, :]
+    rows_t = np.arange(n_out)
+    model = truth[rows_t[:n_model]] * 0.9 + 0.05 * rng.standard_normal((n_model, L))
+    noisy = training.add_input_noise(truth, rng.standard_normal(truth.shape), 0.1)
+    return dict(n=n, d=d, n_model=n_model, n_out=n_out, rows=r.rows, cols=r.cols, vals=r.vals, win=win, mean=r.mean, std=r.std,
+                trainingdata=noisy, clean=truth, imperfect_model=model, target_rows=rows_t)
+
+
+def test_sharded_training_equals_single_rank(tmp_path):
+    """config 4's sharding (src/parallelmain.f90:82-128 over processor_decomposition): two ranks train disjoint region sets with
+    no collective; together they produce, bit for bit, the W_out a single rank trains for all regions, and one weight file per
+    region."""
+    import torch.multiprocessing as mp
+    from speedy_ml_amd import training, weights
+    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = training.train_sharded(0, 1, TRAIN_NREG, build_region, *TRAIN_ARGS, group=2)
+    got = {}
+    for r in range(2):
+        d = np.load(tmp_path / f"train_rank{r}.npz")
+        for k in d.files:
+            assert int(k) not in got
+            got[int(k)] = d[k]
+    assert sorted(got) == list(range(TRAIN_NREG))
+    for region in range(TRAIN_NREG):
+        assert np.array_equal(got[region], single[region]), region
+        assert os.path.exists(tmp_path / weights.trained_res_filename(region, "shard"))

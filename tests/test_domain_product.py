@@ -184,3 +184,19 @@ def test_target_map_rejects_bad_arguments():
     assert rc < 0
     with pytest.raises(Exception):
         domain.target_map(1152, 5000)
+
+
+@pytest.mark.parametrize("nreg,nranks", [(1152, 1), (1152, 2), (1152, 5), (1152, 7), (1152, 8), (1152, 16), (288, 5), (72, 7), (13, 4)])
+def test_region_owner_inverts_processor_decomposition(nreg, nranks):
+    """sml_domain_region_owner (used by the ragged all-gather of the C-ABI, sml_comm_unpack_regions): rank p's i-th region is owned
+    by (p, i), for even splits and for the remainder rule of src/res_domain.f90:53-60."""
+    import ctypes as C
+    from speedy_ml_amd import _lib
+    seen = set()
+    for p in range(nranks):
+        for i, r in enumerate(domain.processor_decomposition_manual(p, nranks, nreg)):
+            rk, sl = C.c_int(), C.c_int()
+            _lib.check(_lib.lib().sml_domain_region_owner(nranks, nreg, int(r), C.byref(rk), C.byref(sl)))
+            assert (rk.value, sl.value) == (p, i), (p, i, r)
+            seen.add(int(r))
+    assert seen == set(range(nreg))

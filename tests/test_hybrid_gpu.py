@@ -178,6 +178,26 @@ def test_hybrid_closed_loop_stays_physical(model):
     assert 180.0 < float(T.min()) and float(T.max()) < 320.0
 
 
+def test_unsafe_state_stops_the_forecast_loop():
+    """Abort propagation (src/mpires.f90:744 broadcast of run_speedy, src/parallelmain.f90:269-271 exit): once the range guard of
+    iogrid(30) has tripped, step() stops stepping -- without a host synchronisation per step, so within the few steps already
+    enqueued -- and says so."""
+    sea = synth.land_mask()
+    m = hybrid.HybridRank(list(range(hybrid.NREG)), hybrid.region_classes(sea), sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2)
+    stream = torch.cuda.current_stream()
+    assert m.step(stream) is True and not m.aborted(wait=True)
+    m.safe.zero_()                                                # what the guard does on an unphysical state (tested above); it never sets it back
+    done = 0
+    for _ in range(3 * m.SAFE_RING):
+        if not m.step(stream):
+            break
+        done += 1
+    assert m.aborted(wait=True)
+    assert done <= m.SAFE_RING + 1, done                          # stopped within the ring's lag
+    t_before = m.t
+    assert m.step(stream) is False and m.t == t_before            # and stays stopped
+
+
 def test_pipelined_step_equals_sequential_step():
     """The software-pipelined schedule (advance + state block of the readout on a side stream under the SPEEDY window) must
     reproduce the sequential schedule: same G, F, feedback, local_model and reservoir states after several steps.  The only
