@@ -248,6 +248,37 @@ int sml_comm_allgather_outvec(sml_comm *comm, sml_bank *bank, int number_of_regi
 int sml_comm_unpack_regions(const double *stage_dev, int nranks, int slots_per_rank, int number_of_regions, int max_n_out,
                             double *all_outvec_dev, void *stream);
 
+/* ---- the device-resident body of sendrecievegrid as one native engine (for hosts that are not Python: the Fortran drop-in
+ * speedy-ml_amd/fortran/mpires.f90).  Everything the reference's root does between the predict calls of two consecutive steps
+ * (src/mpires.f90:218-804): tile every region's outvec into the global grids + clamps, run_model -> agcm_main (iogrid(30), stepone +
+ * the leapfrog steps of one window with phypar inside grtend, iogrid(31)), get_tisr_by_date, tile + standardise the next feedback /
+ * local_model of every reservoir resident in `bank` (slot i holds region_of_slot[i]).  Global state G = grid4d(4,96,48,8) | logp |
+ * precip | sst | tisr (SML_G4_OFF ...); F = SPEEDY's forecast in the same layout.
+ *   set_orography : phi0(96,48) -> phis, tcorh (src/ini_fordate.f90:72-113)
+ *   set_tisr_table: full_tisr [8760][48][96] (src/mod_reservoir.f90:890-909) + hours since 1 Jan 1981 00h of the first step
+ *   attach_physics: phypar inside every time step with these surface fields ((96,48) each); sst_am = G's SST grid
+ *   initial_inputs: TISR slice 0 into G, feedback and local_model of every slot gathered from G
+ *   exchange_and_speedy: all_outvec_dev = region-ordered slab [number_of_regions][max_n_out] after the all-gather, or NULL to take
+ *                   the bank's own outvec buffer; leapfrog_steps = 24 for the 6-hour window (< 0: hand-off only)
+ *   safe          : run_speedy (src/mpires.f90:744): 1 while iogrid(30)'s range guard has not tripped; synchronises */
+typedef struct sml_hybrid sml_hybrid;
+int sml_hybrid_create(sml_bank *bank, int number_of_regions, const int32_t *region_of_slot, int nslots, int overlap, int precip_bool,
+                      const int32_t *sst_input_of_slot, sml_hybrid **out);
+int sml_hybrid_destroy(sml_hybrid *h);
+int sml_hybrid_set_state(sml_hybrid *h, const double *g_host);
+int sml_hybrid_get_state(sml_hybrid *h, double *g_host, double *f_host);
+int sml_hybrid_set_base_sst(sml_hybrid *h, const double *base_sst, const int32_t *sea_mask);
+int sml_hybrid_set_orography(sml_hybrid *h, const double *phi0_grid);
+int sml_hybrid_set_tisr_table(sml_hybrid *h, const double *tisr_8760x48x96, int start_hours, int timestep_hours);
+int sml_hybrid_attach_physics(sml_hybrid *h, const double *hsg9, const double *radang48, const double *fmask, const double *phis0,
+                              const double *tland, const double *swav, const double *alb_l, const double *alb_s, const double *albsfc,
+                              const double *snowc, int nstrad);
+int sml_hybrid_initial_inputs(sml_hybrid *h, void *stream);
+int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream);
+int sml_hybrid_safe(sml_hybrid *h, int *safe_out);
+double *sml_hybrid_g_dev(sml_hybrid *h);
+double *sml_hybrid_f_dev(sml_hybrid *h);
+
 /* ---- slab-ocean coupling (config 5): the `ocean_model` branches of sendrecievegrid, src/mpires.f90:286-330, 470-484,
  * 756-790; sizes of initialize_slab_ocean_model, src/mod_slab_ocean_reservoir.f90:9-133.  The slab reservoirs live in a second
  * sml_bank (n_model = 0, every output un-standardised with the SST statistics as predict_slab_ml does, :1318-1363) and are

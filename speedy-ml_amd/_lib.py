@@ -56,6 +56,9 @@ EXPORTS = [
     "sml_bank_algorithmic_bytes", "sml_bank_readout_part_bytes", "sml_bank_timing", "sml_bank_timing_collect",
     "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
     "sml_comm_unique_id", "sml_comm_create", "sml_comm_destroy", "sml_comm_allgather_outvec", "sml_comm_unpack_regions",
+    "sml_hybrid_create", "sml_hybrid_destroy", "sml_hybrid_set_state", "sml_hybrid_get_state", "sml_hybrid_set_base_sst", "sml_hybrid_set_orography",
+    "sml_hybrid_set_tisr_table", "sml_hybrid_attach_physics", "sml_hybrid_initial_inputs", "sml_hybrid_exchange_and_speedy", "sml_hybrid_safe",
+    "sml_hybrid_g_dev", "sml_hybrid_f_dev",
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",
@@ -82,7 +85,7 @@ def lib():
                        "there is no CPU fallback for the product path")
     L = C.CDLL(LIB_PATH)
     L.sml_last_error.restype = C.c_char_p
-    for name in ("sml_bank_feedback_dev", "sml_bank_local_model_dev", "sml_bank_outvec_dev"):
+    for name in ("sml_bank_feedback_dev", "sml_bank_local_model_dev", "sml_bank_outvec_dev", "sml_hybrid_g_dev", "sml_hybrid_f_dev"):
         getattr(L, name).restype = C.c_void_p
         getattr(L, name).argtypes = [C.c_void_p]
     _lib = L

@@ -1,0 +1,286 @@
+// The device-resident body of mpires::sendrecievegrid (src/mpires.f90:218-804) as ONE native engine behind the C-ABI, for hosts that
+// are not Python (the Fortran drop-in of speedy-ml_amd/fortran/mpires.f90): everything the root rank does between the reservoirs'
+// predict calls of two consecutive steps --
+//   tile every region's outvec into the global grids + clamps (:309-330,460-490, src/res_domain.f90:791-826),
+//   run_model -> agcm_main: iogrid(30) (src/ppo_iogrid.f90:497-577), stepone + the leapfrog steps of one window
+//   (src/ini_stepone.f90, src/dyn_stloop.f90:28-43) with phypar inside grtend, iogrid(31) (:579-601),
+//   get_tisr_by_date (:1676-1708), tile + standardise the next feedback / local_model of every resident reservoir (:580-775)
+// -- on top of the same kernels the Python host (speedy-ml_amd/hybrid.py) drives: sml_exchange_*, sml_handoff_*, sml_spectral_*,
+// sml_dyn_window.  SPEEDY is one global T30 model: every rank runs this replica on the full grids.
+#include <cmath>
+#include <vector>
+
+#include "bank.h"
+
+namespace {
+constexpr int IX = 96, IL = 48, GR = IX * IL, SPF = 32 * 62, NFIELD = 33, NSTATE = 33;
+constexpr int F_VOR = 0, F_DIV = 8, F_T = 16, F_TR = 24, F_PS = 32;
+constexpr double REARTH = 6.371e6, GAMLAT = 6.0 / (1000.0 * 9.81);     // src/mod_dyncon1.f90, setgam (src/ini_fordate.f90:117-135)
+}  // namespace
+
+struct sml_hybrid {
+    sml_bank *bank = nullptr;
+    sml_exchange *ex = nullptr;
+    sml_spectral *sp = nullptr;
+    sml_dyn *dyn = nullptr;
+    sml_phys *phys = nullptr;
+    int nreg = 0, nslots = 0, max_n_out = 0;
+    double *G = nullptr, *F = nullptr, *fields = nullptr, *fields_out = nullptr, *raw_spec = nullptr, *state = nullptr;
+    double *bc = nullptr;                      // phis | tcorh | qcorh
+    double *base_sst = nullptr, *tisr = nullptr, *all_out = nullptr;
+    int32_t *sea_mask = nullptr, *in_scale = nullptr, *in_desc = nullptr, *out_desc = nullptr, *safe = nullptr;
+    int32_t *region_index = nullptr;
+    int start_hours = 12000 + 24 * 14, timestep_hours = 6, t = 0, phys_day = -1;
+    std::vector<void *> owned;
+};
+
+namespace {
+
+template <class T>
+int dalloc(sml_hybrid *h, T **p, size_t count)
+{
+    int rc = sml::dev_zeros(p, count);
+    if (rc == SML_OK) h->owned.push_back((void *)*p);
+    return rc;
+}
+
+// rows of an absent-region-tolerant slab: all_out[region_of_slot[s]][:] = outvec[s][:]
+__global__ void k_place_rows(const double *__restrict__ outvec, const int32_t *__restrict__ region_of_slot, int nslots, int width, double *__restrict__ all_out)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)nslots * width) return;
+    const int s = (int)(t / width), o = (int)(t % width);
+    all_out[(long)region_of_slot[s] * width + o] = outvec[t];
+}
+
+int upload_i32(sml_hybrid *h, int32_t **dst, const std::vector<int32_t> &v)
+{
+    int rc = dalloc(h, dst, v.size());
+    if (rc) return rc;
+    SML_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sml_hybrid_destroy(sml_hybrid *h)
+{
+    if (!h) return SML_OK;
+    if (h->ex) (void)sml_exchange_destroy(h->ex);
+    if (h->dyn) (void)sml_dyn_destroy(h->dyn);
+    if (h->phys) (void)sml_phys_destroy(h->phys);
+    if (h->sp) (void)sml_spectral_destroy(h->sp);
+    for (void *p : h->owned) (void)hipFree(p);
+    delete h;
+    return SML_OK;
+}
+
+int sml_hybrid_create(sml_bank *bank, int number_of_regions, const int32_t *region_of_slot, int nslots, int overlap, int precip_bool,
+                      const int32_t *sst_input_of_slot, sml_hybrid **out)
+{
+    SML_REQUIRE(bank && region_of_slot && sst_input_of_slot && out && nslots > 0 && number_of_regions >= nslots, "sml_hybrid_create: bad arguments");
+    sml_hybrid *h = new sml_hybrid;
+    h->bank = bank; h->nreg = number_of_regions; h->nslots = nslots;
+    int rc;
+#define HY(call) do { rc = (call); if (rc) { sml_hybrid_destroy(h); return rc; } } while (0)
+    HY(sml_exchange_create(bank, number_of_regions, region_of_slot, nslots, overlap, precip_bool, sst_input_of_slot, &h->ex));
+    HY(sml_spectral_create(REARTH, &h->sp));
+    HY(sml_dyn_create(h->sp, &h->dyn));
+    HY(sml_dyn_state_dev(h->dyn, &h->state));
+    HY(dalloc(h, &h->G, SML_G_SIZE));
+    HY(dalloc(h, &h->F, SML_G_SIZE));
+    HY(dalloc(h, &h->fields, (size_t)NFIELD * GR));
+    HY(dalloc(h, &h->fields_out, (size_t)NFIELD * GR));
+    HY(dalloc(h, &h->raw_spec, (size_t)NFIELD * SPF));
+    HY(dalloc(h, &h->bc, (size_t)3 * SPF));
+    HY(dalloc(h, &h->base_sst, (size_t)GR));
+    HY(dalloc(h, &h->safe, 1));
+    const int32_t one = 1;
+    if (hipMemcpy(h->safe, &one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) { sml_hybrid_destroy(h); return sml::fail(SML_ERR_HIP, "sml_hybrid_create: upload failed"); }
+    // iogrid(30)'s forward side: all 33 fields [t u v q ps] transformed in one launch (u, v pre-scaled by 1/cos as vdspec(.,.,2)
+    // does), then vds + trunct straight into time level 1 [vor div t q ps]; iogrid(31)'s inverse side: [t | u v of uvspec | q | ps]
+    std::vector<int32_t> scale(NFIELD, 0), ind, outd;
+    for (int k = 8; k < 24; ++k) scale[k] = 1;
+    for (int k = 0; k < 8; ++k) { ind.insert(ind.end(), {5, 8 + k, 16 + k, 1}); }
+    for (int k = 0; k < 8; ++k) { ind.insert(ind.end(), {6, 8 + k, 16 + k, 1}); }
+    for (int k = 0; k < 8; ++k) { ind.insert(ind.end(), {0, k, k, 1}); }
+    for (int k = 0; k < 8; ++k) { ind.insert(ind.end(), {0, 24 + k, 24 + k, 1}); }
+    ind.insert(ind.end(), {0, 32, 32, 1});
+    for (int k = 0; k < 8; ++k) { outd.insert(outd.end(), {0, F_T + k, F_T + k, 1}); }
+    for (int k = 0; k < 8; ++k) { outd.insert(outd.end(), {1, F_VOR + k, F_DIV + k, 2}); }
+    for (int k = 0; k < 8; ++k) { outd.insert(outd.end(), {2, F_VOR + k, F_DIV + k, 2}); }
+    for (int k = 0; k < 8; ++k) { outd.insert(outd.end(), {0, F_TR + k, F_TR + k, 1}); }
+    outd.insert(outd.end(), {0, F_PS, F_PS, 1});
+    HY(upload_i32(h, &h->in_scale, scale));
+    HY(upload_i32(h, &h->in_desc, ind));
+    HY(upload_i32(h, &h->out_desc, outd));
+    HY(upload_i32(h, &h->region_index, std::vector<int32_t>(region_of_slot, region_of_slot + nslots)));
+    HY(sml_dyn_set_range_guard(h->dyn, h->safe));
+#undef HY
+    h->max_n_out = bank->max_n_out;
+    if ((rc = dalloc(h, &h->all_out, (size_t)number_of_regions * bank->max_n_out))) { sml_hybrid_destroy(h); return rc; }
+    *out = h;
+    return SML_OK;
+}
+
+/* the hybrid's global state G = grid4d(4,96,48,8) | logp | precip | sst | tisr (layout of SML_G4_OFF ...), host <-> device */
+int sml_hybrid_set_state(sml_hybrid *h, const double *g_host)
+{
+    SML_REQUIRE(h && g_host, "sml_hybrid_set_state: bad arguments");
+    SML_HIP(hipMemcpy(h->G, g_host, sizeof(double) * SML_G_SIZE, hipMemcpyHostToDevice));
+    SML_HIP(hipMemcpy(h->base_sst, g_host + SML_GS_OFF, sizeof(double) * GR, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+int sml_hybrid_get_state(sml_hybrid *h, double *g_host, double *f_host)
+{
+    SML_REQUIRE(h, "sml_hybrid_get_state: null handle");
+    SML_HIP(hipDeviceSynchronize());
+    if (g_host) SML_HIP(hipMemcpy(g_host, h->G, sizeof(double) * SML_G_SIZE, hipMemcpyDeviceToHost));
+    if (f_host) SML_HIP(hipMemcpy(f_host, h->F, sizeof(double) * SML_G_SIZE, hipMemcpyDeviceToHost));
+    return SML_OK;
+}
+
+/* model_parameters%base_sst_grid / sea_mask of the slab coupling (src/mod_reservoir.f90:846-884); sea_mask may be NULL */
+int sml_hybrid_set_base_sst(sml_hybrid *h, const double *base_sst, const int32_t *sea_mask)
+{
+    SML_REQUIRE(h && base_sst, "sml_hybrid_set_base_sst: bad arguments");
+    SML_HIP(hipMemcpy(h->base_sst, base_sst, sizeof(double) * GR, hipMemcpyHostToDevice));
+    if (sea_mask) {
+        if (!h->sea_mask) { int rc = dalloc(h, &h->sea_mask, (size_t)GR); if (rc) return rc; }
+        SML_HIP(hipMemcpy(h->sea_mask, sea_mask, sizeof(int32_t) * GR, hipMemcpyHostToDevice));
+    }
+    return SML_OK;
+}
+
+/* surface geopotential phi0(96,48) [m2/s2]: phis = trunct(spec(phi0)), tcorh = trunct(spec(gamlat * phi0)) (src/ini_fordate.f90:72-113);
+ * the humidity correction needs the physics' saturation routine and stays zero */
+int sml_hybrid_set_orography(sml_hybrid *h, const double *phi0_grid)
+{
+    SML_REQUIRE(h && phi0_grid, "sml_hybrid_set_orography: bad arguments");
+    std::vector<double> two(2 * GR);
+    for (int i = 0; i < GR; ++i) { two[i] = phi0_grid[i]; two[GR + i] = phi0_grid[i] * GAMLAT; }
+    double *tmp = nullptr;
+    int rc = sml::dev_upload(&tmp, two.data(), two.size());
+    if (rc) return rc;
+    rc = sml_spectral_spec(h->sp, tmp, h->bc, 2, nullptr);
+    if (!rc) rc = sml_spectral_trunct(h->sp, h->bc, 2, nullptr);
+    if (!rc) rc = sml_dyn_set_boundary(h->dyn, h->bc, h->bc + SPF, h->bc + 2 * SPF, nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    return rc;
+}
+
+/* full_tisr: the pre-standardisation TISR table, one (96,48) slice per hour of a 365-day year (src/mod_reservoir.f90:890-909), and the
+ * hours since 1 January 1981 00h of the first prediction step (traininglength + prediction marker + synclength) */
+int sml_hybrid_set_tisr_table(sml_hybrid *h, const double *tisr_8760x48x96, int start_hours, int timestep_hours)
+{
+    SML_REQUIRE(h && tisr_8760x48x96 && timestep_hours > 0, "sml_hybrid_set_tisr_table: bad arguments");
+    if (!h->tisr) { int rc = dalloc(h, &h->tisr, (size_t)8760 * GR); if (rc) return rc; }
+    SML_HIP(hipMemcpy(h->tisr, tisr_8760x48x96, sizeof(double) * 8760 * GR, hipMemcpyHostToDevice));
+    h->start_hours = start_hours; h->timestep_hours = timestep_hours;
+    return SML_OK;
+}
+
+/* phypar inside every later time step (src/dyn_grtend.f90:222-225); surface fields as phypar reads them, each (96,48);
+ * the sea temperature is the hybrid state's SST grid, read in place */
+int sml_hybrid_attach_physics(sml_hybrid *h, const double *hsg9, const double *radang48, const double *fmask, const double *phis0,
+                              const double *tland, const double *swav, const double *alb_l, const double *alb_s, const double *albsfc,
+                              const double *snowc, int nstrad)
+{
+    SML_REQUIRE(h && hsg9 && radang48 && fmask && phis0 && tland && swav && alb_l && alb_s && albsfc && snowc, "sml_hybrid_attach_physics: null array");
+    int rc;
+    if (!h->phys && (rc = sml_phys_create(hsg9, radang48, &h->phys))) return rc;
+    std::vector<double> tsea(GR);
+    SML_HIP(hipMemcpy(tsea.data(), h->base_sst, sizeof(double) * GR, hipMemcpyDeviceToHost));
+    if ((rc = sml_phys_set_surface(h->phys, fmask, phis0, tland, tsea.data(), swav, alb_l, alb_s, albsfc, snowc))) return rc;
+    if ((rc = sml_phys_bind_sst_dev(h->phys, h->G + SML_GS_OFF))) return rc;
+    h->phys_day = -1;
+    return sml_dyn_attach_physics(h->dyn, h->phys, nstrad);
+}
+
+static int tisr_to_G(sml_hybrid *h, int timestep, hipStream_t st)
+{
+    if (!h->tisr) return SML_OK;
+    const int idx = sml_tisr_index(1981, h->start_hours + timestep * h->timestep_hours);
+    if (idx < 1) return idx;
+    SML_HIP(hipMemcpyAsync(h->G + SML_GT_OFF, h->tisr + (size_t)(idx - 1) * GR, sizeof(double) * GR, hipMemcpyDeviceToDevice, st));
+    return SML_OK;
+}
+
+/* the first inputs of a prediction (what start_prediction leaves in feedback / local_model comes from the data; this is the
+ * device-resident equivalent for a state that is already in G: TISR slice 0, then feedback and local_model gathered from G) */
+int sml_hybrid_initial_inputs(sml_hybrid *h, void *stream)
+{
+    SML_REQUIRE(h, "sml_hybrid_initial_inputs: null handle");
+    hipStream_t st = sml::as_stream(stream);
+    h->t = 0;
+    int rc = tisr_to_G(h, 0, st);
+    if (rc) return rc;
+    return sml_exchange_gather(h->ex, h->G, h->G, stream);
+}
+
+/* everything of sendrecievegrid after the reservoirs' predict calls.  all_outvec_dev: the region-ordered slab of every region's
+ * outvec on this rank (after the all-gather), or NULL when this rank's bank holds the regions itself (rows of absent regions then
+ * keep their previous values).  leapfrog_steps < 0 skips the SPEEDY window (hand-off only).  Returns SML_OK; the range guard's
+ * verdict is read with sml_hybrid_safe. */
+int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream)
+{
+    SML_REQUIRE(h, "sml_hybrid_exchange_and_speedy: null handle");
+    hipStream_t st = sml::as_stream(stream);
+    int rc;
+    const double *slab = all_outvec_dev;
+    if (!slab) {
+        const long total = (long)h->nslots * h->max_n_out;
+        hipLaunchKernelGGL(k_place_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double *)h->bank->d_outvec, h->region_index, h->nslots,
+                           h->max_n_out, h->all_out);
+        SML_HIP(hipGetLastError());
+        slab = h->all_out;
+    }
+    if ((rc = sml_exchange_scatter(h->ex, slab, h->G, h->base_sst, h->sea_mask, stream))) return rc;
+    // iogrid(30)
+    if ((rc = sml_handoff_to_fields(h->G, h->fields, stream))) return rc;
+    if ((rc = sml_spectral_spec_mixed(h->sp, h->fields, h->raw_spec, NFIELD, h->in_scale, stream))) return rc;
+    if ((rc = sml_spectral_spec_post(h->sp, h->raw_spec, h->in_desc, h->state, NSTATE, stream))) return rc;
+    if (h->phys) {          // fordate's daily sol_oz(tyear), tyear = (day of the 365-day year - 0.5) / 365 (src/ini_fordate.f90:47-50)
+        int32_t date[4];
+        if ((rc = sml_calendar_date(1981, h->start_hours + h->t * h->timestep_hours, date)) < 0) return rc;
+        static const int ndaycal[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};
+        const int day = ndaycal[date[1] - 1] + date[2];
+        if (day != h->phys_day) {
+            h->phys_day = day;
+            if ((rc = sml_phys_sol_oz(h->phys, (day - 0.5) / 365.0))) return rc;
+        }
+    }
+    if (leapfrog_steps >= 0) {
+        if ((rc = sml_dyn_window(h->dyn, h->state, 1, leapfrog_steps, 900.0, 0.5, 0.05, 0.53, stream))) return rc;
+    } else {
+        if ((rc = sml_spectral_grid_derived(h->sp, h->state, h->out_desc, h->fields_out, NFIELD, stream))) return rc;
+        if ((rc = sml_handoff_check(h->fields_out, h->safe, stream))) return rc;
+    }
+    // iogrid(31)
+    if ((rc = sml_spectral_grid_derived(h->sp, h->state, h->out_desc, h->fields_out, NFIELD, stream))) return rc;
+    if ((rc = sml_handoff_from_fields(h->fields_out, h->F, stream))) return rc;
+    // next inputs: get_tisr_by_date(timestep - 1) (src/mpires.f90:750), then tile + standardise
+    h->t += 1;
+    if ((rc = tisr_to_G(h, h->t - 1, st))) return rc;
+    return sml_exchange_gather(h->ex, h->G, h->F, stream);
+}
+
+/* run_speedy of the reference (src/mpires.f90:744): 1 while every state handed to SPEEDY passed iogrid(30)'s range guard.
+ * Synchronises the device. */
+int sml_hybrid_safe(sml_hybrid *h, int *safe_out)
+{
+    SML_REQUIRE(h && safe_out, "sml_hybrid_safe: bad arguments");
+    int32_t v = 0;
+    SML_HIP(hipMemcpy(&v, h->safe, sizeof v, hipMemcpyDeviceToHost));
+    *safe_out = v;
+    return SML_OK;
+}
+
+double *sml_hybrid_g_dev(sml_hybrid *h) { return h ? h->G : nullptr; }
+double *sml_hybrid_f_dev(sml_hybrid *h) { return h ? h->F : nullptr; }
+
+}  // extern "C"
