@@ -173,6 +173,9 @@ int sml_bank_predict_one(sml_bank *bank, int slot, double *x_inout_host, const d
                          double *outvec_host);
 /* synchronize (src/mod_reservoir.f90:1354-1381) for every loaded slot: `length` teacher-forced steps.
  * inputs_dev: [length][capacity][max_d] (step-major) device array. */
+/* synchronize for ONE slot of a shared bank with the reference's host arrays: inputs(d, length) column-major, x(n) in/out.  Only
+ * that slot is stepped (the per-region calls of initialize_prediction / start_prediction, src/mod_reservoir.f90:822-824,949-951). */
+int sml_bank_synchronize_one(sml_bank *bank, int slot, const double *inputs_host, int length, double *x_inout);
 int sml_bank_synchronize_all(sml_bank *bank, const double *inputs_dev, int length, void *stream);
 /* one advance without readout (K1-K3) for every slot, feedback taken from the bank */
 int sml_bank_advance_all(sml_bank *bank, void *stream);

@@ -887,6 +887,34 @@ int sml_bank_predict_one(sml_bank *bank, int slot, double *x_inout, const double
     return SML_OK;
 }
 
+int sml_bank_synchronize_one(sml_bank *bank, int slot, const double *inputs, int length, double *x_inout)
+{
+    // synchronize (src/mod_reservoir.f90:1354-1381) for ONE reservoir of a shared bank, host arrays as the reference passes them:
+    // inputs(d, length) column-major, x in/out.  Only this slot is stepped; the bank's ping-pong parity is left as it was.
+    BANK_SLOT(bank, slot);
+    SML_REQUIRE(inputs && x_inout && length >= 0, "sml_bank_synchronize_one: bad arguments");
+    int rc = sync_descs(bank);
+    if (rc) return rc;
+    if ((rc = upload_state(bank->res[slot], D.x[bank->cur], x_inout))) return rc;
+    const int before = bank->cur;
+    double *u = nullptr;
+    const size_t stride = (size_t)bank->max_d;                 // launch_update reads u_all + slot * max_d
+    SML_HIP(hipMalloc((void **)&u, sizeof(double) * stride * (size_t)std::max(length, 1)));
+    if (hipMemcpy2D(u, stride * sizeof(double), inputs, (size_t)D.d * sizeof(double), (size_t)D.d * sizeof(double), (size_t)length, hipMemcpyHostToDevice) != hipSuccess &&
+        length > 0) {
+        (void)hipFree(u);
+        return sml::fail(SML_ERR_HIP, "sml_bank_synchronize_one: input upload failed");
+    }
+    for (int t = 0; t < length && rc == SML_OK; ++t)
+        rc = launch_update(bank, slot, slot + 1, u + (size_t)t * stride - (size_t)slot * stride, nullptr);
+    if (rc == SML_OK) rc = download_state(bank->res[slot], D.x[bank->cur], x_inout);
+    if (rc == SML_OK && bank->cur != before) SML_HIP(hipMemcpy(D.x[before], D.x[bank->cur], sizeof(double) * D.n, hipMemcpyDeviceToDevice));
+    if (rc == SML_OK && bank->cur == before) SML_HIP(hipMemcpy(D.x[before ^ 1], D.x[before], sizeof(double) * D.n, hipMemcpyDeviceToDevice));
+    bank->cur = before;
+    (void)hipFree(u);
+    return rc;
+}
+
 int sml_bank_synchronize_all(sml_bank *b, const double *inputs_dev, int length, void *stream)
 {
     SML_REQUIRE(b && inputs_dev && length >= 0, "sml_bank_synchronize_all: bad arguments");

@@ -3,6 +3,22 @@
 module speedyml_hip
   use iso_c_binding
   implicit none
+  ! sml_region / sml_res_sizes of include/speedyml_hip.h (interoperable mirrors of grid_type's extents and allocate_res_new's sizes)
+  type, bind(C) :: sml_region
+    integer(c_int32_t) :: res_xstart, res_xend, res_ystart, res_yend, resxchunk, resychunk
+    integer(c_int32_t) :: res_zstart, res_zend, reszchunk
+    integer(c_int32_t) :: input_xstart, input_xend, input_ystart, input_yend, inputxchunk, inputychunk
+    integer(c_int32_t) :: input_zstart, input_zend, inputzchunk
+    integer(c_int32_t) :: pole, periodicboundary, top, bottom
+    integer(c_int32_t) :: tdata_xstart, tdata_xend, tdata_ystart, tdata_yend, tdata_zstart, tdata_zend
+  end type
+  type, bind(C) :: sml_res_sizes
+    integer(c_int32_t) :: chunk_size, chunk_size_prediction, chunk_size_speedy, locality
+    integer(c_int32_t) :: nodes_per_input, n, k, reservoir_numinputs
+    integer(c_int32_t) :: atmo3d_start, atmo3d_end, logp_start, logp_end, precip_start, precip_end
+    integer(c_int32_t) :: sst_start, sst_end, tisr_start, tisr_end
+  end type
+
 
   integer(c_int), parameter :: SML_OK = 0
 
@@ -242,9 +258,181 @@ module speedyml_hip
       integer(c_int), value :: lradsw
       integer(c_int) :: rc
     end function
+    ! ---- added for the module-API drop-ins (mod_reservoir / resdomain / mpires) ----
+    function sml_domain_region(number_of_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap, out) &
+        bind(C, name="sml_domain_region") result(rc)
+      import :: c_int, sml_region
+      integer(c_int), value :: number_of_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap
+      type(sml_region), intent(out) :: out
+      integer(c_int) :: rc
+    end function
+    function sml_domain_sizes(g, m, deg, local_predictvars, logp_bool, precip_bool, sst_bool_input, tisr_input_bool, ml_only, out) &
+        bind(C, name="sml_domain_sizes") result(rc)
+      import :: c_int, sml_region, sml_res_sizes
+      type(sml_region), intent(in) :: g
+      integer(c_int), value :: m, deg, local_predictvars, logp_bool, precip_bool, sst_bool_input, tisr_input_bool, ml_only
+      type(sml_res_sizes), intent(out) :: out
+      integer(c_int) :: rc
+    end function
+    function sml_domain_target_map(number_of_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap, precip_bool, in_pos, capacity) &
+        bind(C, name="sml_domain_target_map") result(n)
+      import :: c_int
+      integer(c_int), value :: number_of_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap, precip_bool, capacity
+      integer(c_int), intent(out) :: in_pos(*)
+      integer(c_int) :: n
+    end function
+    function sml_find_closest_divisor(target, number) bind(C, name="sml_find_closest_divisor") result(d)
+      import :: c_int
+      integer(c_int), value :: target, number
+      integer(c_int) :: d
+    end function
+    function sml_gen_res(n, k, radius, seed, rows, cols, vals, eigs) bind(C, name="sml_gen_res") result(rc)
+      import :: c_int, c_double, c_int64_t
+      integer(c_int), value :: n, k
+      real(c_double), value :: radius
+      integer(c_int64_t), value :: seed
+      integer(c_int), intent(out) :: rows(*), cols(*)
+      real(c_double), intent(out) :: vals(*), eigs
+      integer(c_int) :: rc
+    end function
+    function sml_bank_set_wout(bank, slot, wout) bind(C, name="sml_bank_set_wout") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(in) :: wout(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_set_local_model(bank, slot, lm) bind(C, name="sml_bank_set_local_model") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(in) :: lm(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_get_outvec(bank, slot, out) bind(C, name="sml_bank_get_outvec") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(out) :: out(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_predict_all(bank, flags, stream) bind(C, name="sml_bank_predict_all") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: bank, stream
+      integer(c_int), value :: flags
+      integer(c_int) :: rc
+    end function
+    function sml_bank_synchronize_one(bank, slot, inputs, length, x) bind(C, name="sml_bank_synchronize_one") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot, length
+      real(c_double), intent(in) :: inputs(*)
+      real(c_double), intent(inout) :: x(*)
+      integer(c_int) :: rc
+    end function
+    function sml_bank_train_pass(bank, noisy_inputs_dev, T, discard, batch, model_dev, targets_dev, c_dev, b_dev, ml_variant, stream) &
+        bind(C, name="sml_bank_train_pass") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: bank, noisy_inputs_dev, stream
+      integer(c_int), value :: T, discard, batch, ml_variant
+      type(c_ptr), intent(in) :: model_dev(*), targets_dev(*), c_dev(*), b_dev(*)
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_create(bank, number_of_regions, region_of_slot, nslots, overlap, precip_bool, sst_input_of_slot, h) &
+        bind(C, name="sml_hybrid_create") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: bank
+      integer(c_int), value :: number_of_regions, nslots, overlap, precip_bool
+      integer(c_int), intent(in) :: region_of_slot(*), sst_input_of_slot(*)
+      type(c_ptr), intent(out) :: h
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_set_state(h, g) bind(C, name="sml_hybrid_set_state") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: g(*)
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_get_state(h, g, f) bind(C, name="sml_hybrid_get_state") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: g(*), f(*)
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_set_orography(h, phi0) bind(C, name="sml_hybrid_set_orography") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: phi0(*)
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_set_tisr_table(h, tisr, start_hours, timestep_hours) bind(C, name="sml_hybrid_set_tisr_table") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: tisr(*)
+      integer(c_int), value :: start_hours, timestep_hours
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_attach_physics(h, hsg9, radang48, fmask, phis0, tland, swav, alb_l, alb_s, albsfc, snowc, nstrad) &
+        bind(C, name="sml_hybrid_attach_physics") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: hsg9(*), radang48(*), fmask(*), phis0(*), tland(*), swav(*), alb_l(*), alb_s(*), albsfc(*), snowc(*)
+      integer(c_int), value :: nstrad
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_initial_inputs(h, stream) bind(C, name="sml_hybrid_initial_inputs") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, stream
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_exchange_and_speedy(h, all_outvec_dev, leapfrog_steps, stream) bind(C, name="sml_hybrid_exchange_and_speedy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, all_outvec_dev, stream
+      integer(c_int), value :: leapfrog_steps
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_safe(h, safe) bind(C, name="sml_hybrid_safe") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), intent(out) :: safe
+      integer(c_int) :: rc
+    end function
+    function sml_domain_in_map(number_of_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap, precip_bool, sst_bool_input, &
+                               tisr_input_bool, g_index, stat_idx, capacity) bind(C, name="sml_domain_in_map") result(n)
+      import :: c_int
+      integer(c_int), value :: number_of_regions, region_num, overlap, num_vert_levels, vert_level, vert_overlap, precip_bool, sst_bool_input, &
+                               tisr_input_bool, capacity
+      integer(c_int), intent(out) :: g_index(*), stat_idx(*)
+      integer(c_int) :: n
+    end function
+    function sml_bank_feedback_dev(bank) bind(C, name="sml_bank_feedback_dev") result(p)
+      import :: c_ptr
+      type(c_ptr), value :: bank
+      type(c_ptr) :: p
+    end function
+    function sml_bank_local_model_dev(bank) bind(C, name="sml_bank_local_model_dev") result(p)
+      import :: c_ptr
+      type(c_ptr), value :: bank
+      type(c_ptr) :: p
+    end function
+    function sml_dev_download_raw(dst_host, src_dev, bytes) bind(C, name="sml_dev_download") result(rc)
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: dst_host, src_dev
+      integer(c_int64_t), value :: bytes
+      integer(c_int) :: rc
+    end function
   end interface
 
 contains
+
+  ! download `bytes` bytes starting `off` bytes into a device buffer
+  function sml_dev_download_off(dst, src_dev, off, bytes) result(rc)
+    real(c_double), intent(out), target :: dst(*)
+    type(c_ptr), intent(in) :: src_dev
+    integer(c_int64_t), intent(in) :: off, bytes
+    integer(c_int) :: rc
+    rc = sml_dev_download_raw(c_loc(dst), transfer(transfer(src_dev, 0_c_intptr_t) + off, src_dev), bytes)
+  end function
 
   ! The reference prints library status and stops (src/mod_linalg.f90:18-22,147-150); same here.
   subroutine sml_check(rc, where)
