@@ -296,6 +296,9 @@ int sml_slab_destroy(sml_slab *slab);
 /* wholegrid_sst before the mask and floor: region r writes its res patch from all_slab_out[r][0:resx*resy] (REGION order,
  * stride out_stride) if sea_of_region[r], 272 K otherwise (src/mpires.f90:309-330).  Call it BEFORE sml_exchange_scatter,
  * whose SST kernel then restores base_sst where sea_mask > 0 and applies the 272 K floor (:470-484). */
+/* predict_slab (src/mod_slab_ocean_reservoir.f90:1268-1316), the hybrid slab ocean (ml_only_ocean = .false.): slots loaded with
+ * n_model = n_out; advance + readout of every loaded slot, local_model <- the raw (standardised) output, outvec un-standardised */
+int sml_slab_predict_hybrid(sml_bank *slab_bank, void *stream);
 int sml_slab_scatter_sst(sml_slab *slab, const double *all_slab_out_dev, int out_stride, const int32_t *sea_of_region_dev, double *g_dev,
                          void *stream);
 /* after sml_exchange_gather: ring column (timestep-1) mod ring <- atmo_training_data_idx entries of the atmosphere feedback;

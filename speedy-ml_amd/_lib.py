@@ -59,7 +59,7 @@ EXPORTS = [
     "sml_hybrid_create", "sml_hybrid_destroy", "sml_hybrid_set_state", "sml_hybrid_get_state", "sml_hybrid_set_base_sst", "sml_hybrid_set_orography",
     "sml_hybrid_set_tisr_table", "sml_hybrid_attach_physics", "sml_hybrid_initial_inputs", "sml_hybrid_exchange_and_speedy", "sml_hybrid_safe",
     "sml_hybrid_g_dev", "sml_hybrid_f_dev",
-    "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_update_inputs",
+    "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_predict_hybrid", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",
     "sml_spectral_spec", "sml_spectral_grid_mixed", "sml_spectral_grid_derived", "sml_spectral_grid_derived_aux", "sml_spectral_spec_post", "sml_spectral_spec_mixed", "sml_spectral_vdspec", "sml_spectral_uvspec", "sml_spectral_vds", "sml_spectral_grad",

@@ -58,6 +58,24 @@ __global__ void k_slab_inputs(const double *__restrict__ atmo_fb, int atmo_strid
     slab_fb[o] = sum / (double)nring;
 }
 
+// predict_slab's tail (src/mod_slab_ocean_reservoir.f90:1303-1309): the raw readout becomes the next call's local_model (the
+// reservoir's own previous output is its "imperfect model"), then the outputs are un-standardised -- multiply, then add
+__global__ void k_slab_hybrid_tail(const ResDesc *__restrict__ descs, int capacity, double *__restrict__ outvec, int out_stride,
+                                   double *__restrict__ local_model, int lm_stride)
+{
+    const int s = blockIdx.x, i = threadIdx.x;
+    if (s >= capacity) return;
+    const ResDesc D = descs[s];
+    if (!D.loaded || i >= D.n_out) return;
+    const double raw = outvec[(size_t)s * out_stride + i];
+    if (i < D.n_model) local_model[(size_t)s * lm_stride + i] = raw;
+    const int st = D.out_stat[i];
+    if (st >= 0) {
+        const double scaled = __dmul_rn(raw, D.stdv[st]);
+        outvec[(size_t)s * out_stride + i] = __dadd_rn(scaled, D.mean[st]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +181,22 @@ int sml_slab_update_inputs(sml_slab *sl, int timestep, void *stream)
     dim3 grid((sl->stride + 127) / 128, sl->nslots);
     hipLaunchKernelGGL(k_slab_inputs, grid, dim3(128), 0, sml::as_stream(stream), sl->atmo->d_feedback, sl->atmo->max_d, sl->d_idx,
                        sl->d_sea_of_slot, sl->d_ring, sl->ring, col, sl->nslots, sl->stride, sl->slab->d_feedback);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+/* predict_slab (src/mod_slab_ocean_reservoir.f90:1268-1316), the hybrid slab ocean: the bank's slots were loaded with n_model = n_out
+ * (the physics-model rows are the reservoir's own previous, standardised output).  Advances and reads out every loaded slot, feeds
+ * the raw readout back as the next local_model and leaves the un-standardised output in the bank's outvec buffer. */
+int sml_slab_predict_hybrid(sml_bank *slab_bank, void *stream)
+{
+    SML_REQUIRE(slab_bank, "sml_slab_predict_hybrid: null bank");
+    int rc = sml_bank_predict_all(slab_bank, 1, stream);           // flags bit0: raw readout
+    if (rc) return rc;
+    SML_REQUIRE(slab_bank->max_n_out <= 1024, "sml_slab_predict_hybrid: too many outputs");
+    hipLaunchKernelGGL(k_slab_hybrid_tail, dim3(slab_bank->capacity), dim3(((slab_bank->max_n_out + 63) / 64) * 64), 0, sml::as_stream(stream),
+                       (const ResDesc *)slab_bank->d_descs, slab_bank->capacity, slab_bank->d_outvec, slab_bank->max_n_out, slab_bank->d_local_model,
+                       slab_bank->max_n_model);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }

@@ -52,3 +52,9 @@ class SlabCoupler:
 
     def update_inputs(self, timestep, stream=None):
         check(_lib.lib().sml_slab_update_inputs(self._h, int(timestep), vp(stream)))
+
+
+def predict_slab(slab_bank, stream=None):
+    """predict_slab (src/mod_slab_ocean_reservoir.f90:1268-1316) for every slot of a slab bank loaded with n_model = n_out: the raw
+    output is fed back as the next local_model, the bank's outvec holds the un-standardised SST / OHTC."""
+    check(_lib.lib().sml_slab_predict_hybrid(slab_bank._h, vp(stream)))

@@ -95,3 +95,104 @@ def test_slab_predict_matches_oracle(oracle):
     ow = ow * r.std[35] + r.mean[35]
     assert np.max(np.abs(bank.get_state(1) - xw)) <= 1e-13
     assert np.max(np.abs(bank.get_outvec(1) - ow)) <= 1e-11 * np.max(np.abs(ow))
+
+
+def test_predict_slab_hybrid_matches_oracle(oracle):
+    """predict_slab (src/mod_slab_ocean_reservoir.f90:1268-1316), the hybrid slab ocean: 8 physics-model rows that are the reservoir's
+    own previous standardised output, no leak, every output un-standardised with the SST statistics; two consecutive calls at the
+    full slab size so that the fed-back local_model is exercised."""
+    from speedy_ml_amd.reservoir import ReservoirBank
+    from speedy_ml_amd.slab import predict_slab
+    r = synth.make_reservoir(n=3968, d=128, n_model=8, n_out=8, seed=78, deg=6, m=4000, radius=0.9, sigma=0.6)
+    bank = ReservoirBank(2, max_d=128, max_n_model=8, max_n_out=8)
+    stat = np.full(8, 35, dtype=np.int32)
+    bank.load(0, r.n, r.d, 8, 8, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, stat)
+    rng = np.random.default_rng(3)
+    x, lm = rng.standard_normal(r.n) * 0.3, rng.standard_normal(8)
+    bank.set_state(0, x)
+    bank.set_local_model(0, lm)
+    for step in range(2):
+        fb = rng.standard_normal(128)
+        bank.set_feedback(0, fb)
+        predict_slab(bank)
+        torch.cuda.synchronize()
+        x, raw = oracle.predict_raw(r.n, r.d, 8, 8, r.rows, r.cols, r.vals, r.win, r.wout, 1.0, fb, lm, x)
+        lm = raw                                                  # reservoir%local_model = reservoir%outvec (:1307)
+        want = raw * r.std[35] + r.mean[35]
+        assert np.max(np.abs(bank.get_state(0) - x)) <= 1e-13, step
+        assert np.max(np.abs(bank.get_outvec(0) - want)) <= 1e-11 * np.max(np.abs(want)), step
+
+
+def _slab_series(d, n_out, L, rng):
+    t = np.arange(L)
+    base = 0.5 * np.sin(2 * np.pi * t[None, :] / 37.0 + rng.uniform(0, 6.28, (d, 1)))
+    ar = np.zeros((d, L))
+    e = rng.standard_normal((d, L)) * 0.2
+    for k in range(1, L):
+        ar[:, k] = 0.9 * ar[:, k - 1] + e[:, k]
+    return base + ar
+
+
+@pytest.mark.parametrize("hybrid_ocean", [False, True])
+def test_slab_training_end_to_end(oracle, hybrid_ocean):
+    """train_slab_ocean_model (src/mod_slab_ocean_reservoir.f90:172-269) through the device path at the slab shape (d = 128, n = 3968,
+    8 outputs, sigma 0.6, noise 0.1, beta_res = 1e-4): the `timestep_slab` interleaved passes of reservoir_layer_chunking_ml (:869-1059,
+    quirk Q6) or, for the hybrid ocean, reservoir_layer_chunking_hybrid with the persistence forecast as imperfect model (:211-218),
+    then fit_chunk_ml (:1061-1101: C(i,i) += beta_res, no prior) / fit_chunk_hybrid.  Against the oracle's recurrence and Gram
+    accumulation (1e-12) and LAPACK's dgesv on the oracle's matrices (ridge residual 1e-9, predictions 1e-6).  The interleave is 6
+    instead of the shipped 168 hours and the window 44 columns per pass, which keeps the CPU oracle's n^2-per-column Gram to seconds;
+    batch size (2) and batch count (20) follow initialize_chunk_training exactly as for 168.  (A window so short that the batch
+    size comes out as 1 makes the reference index states(:,0): undefined there, so not a test case.)"""
+    from speedy_ml_amd import training
+    from speedy_ml_amd.reservoir import ReservoirBank
+    step, n, d, n_out = 6, 3968, 128, 8
+    n_model = n_out if hybrid_ocean else 0
+    L, discard = step * 44, step * 4
+    r = synth.make_reservoir(n=n, d=d, n_model=n_model, n_out=n_out, seed=91, deg=6, m=4000, radius=0.9, sigma=0.6)
+    rng = np.random.default_rng(92)
+    r.win = training.make_win(n, d, 0.6, rng.random((d, n // d)))
+    truth = _slab_series(d, n_out, L, rng)
+    rows_t = np.arange(n_out)                                     # tile_full_input_to_target_data_ocean_model: SST then OHTC of the res patch
+    noisy = training.add_input_noise(truth, rng.standard_normal(truth.shape), 0.10)
+    model = None
+    if hybrid_ocean:                                              # persistence: the targets one slab step earlier (the first step: themselves)
+        model = np.concatenate([truth[rows_t, :step], truth[rows_t, :L - step]], axis=1)
+    batch = training.chunk_batch_size(L, discard, step)
+    assert batch == 2
+    bank = ReservoirBank(1, max_d=d, max_n_model=max(n_model, 1), max_n_out=n_out)
+    stat = np.full(n_out, 35, dtype=np.int32)
+    bank.load(0, n, d, n_model, n_out, r.rows, r.cols, r.vals, r.win, np.zeros((n_out, n + n_model)), r.mean, r.std, stat)
+    spec = dict(n=n, n_model=n_model, n_out=n_out, trainingdata=noisy, clean=truth, imperfect_model=model, target_rows=rows_t)
+    kw = dict(beta_res=1e-4, beta_model=1.0, prior_val=0.0, using_prior=hybrid_ocean, ml_only=not hybrid_ocean)
+    res = training.train_reservoirs(bank, [spec], L, discard, step, **kw)[0]
+    assert res["batches"] == 20
+    n_aug = n + n_model
+    co, bo = np.zeros((n_aug, n_aug), order="F"), np.zeros((n_out, n_aug), order="F")
+    for i in range(step):
+        md = model[:, i::step] if hybrid_ocean else np.zeros((0, L // step))
+        nb = oracle.train_states(n, d, r.rows, r.cols, r.vals, r.win, 1.0, np.asfortranarray(noisy[:, i::step]), discard // step, batch,
+                                 np.asfortranarray(md), np.asfortranarray(truth[rows_t, i::step]), co, bo, ml_variant=not hybrid_ocean)
+        assert nb == 20
+    cs = np.tril(co) + np.tril(co, -1).T
+    reg = np.r_[np.full(n_model, 1.0), np.full(n, 1e-8)] if hybrid_ocean else np.full(n, 1e-4)      # with a prior the betas enter squared (Q8)
+    want = np.linalg.solve((cs + np.diag(reg)).T, bo.T).T
+    wg = res["wout"]
+    assert np.isfinite(co).all() and np.isfinite(bo).all(), "oracle Gram matrices"
+    assert np.isfinite(want).all(), "dgesv solution"
+    assert np.isfinite(wg).all(), "device W_out"
+    lhs = wg @ (cs + np.diag(reg))
+    assert np.max(np.abs(lhs - bo)) <= 1e-9 * np.max(np.abs(bo)), np.max(np.abs(lhs - bo)) / np.max(np.abs(bo))
+    dw = wg - want
+    assert np.sqrt(max(np.trace(dw @ cs @ dw.T), 0.0) / np.trace(want @ cs @ want.T)) <= 1e-6
+    # the trained slot predicts with the fitted W_out
+    x0, fb = rng.standard_normal(n) * 0.2, truth[:, 5].copy()
+    lm = rng.standard_normal(max(n_model, 1))
+    bank.set_state(0, x0)
+    bank.set_feedback(0, fb)
+    bank.set_local_model(0, lm)
+    bank.predict()
+    torch.cuda.synchronize()
+    xw, ow = oracle.predict_raw(n, d, n_model, n_out, r.rows, r.cols, r.vals, r.win, wg, 1.0, fb, lm[:n_model] if n_model else None, x0)
+    ow = ow * r.std[35] + r.mean[35]
+    assert np.max(np.abs(bank.get_state(0) - xw)) <= 1e-13
+    assert np.max(np.abs(bank.get_outvec(0) - ow)) <= 1e-10 * np.max(np.abs(ow))

@@ -265,6 +265,6 @@ def test_full_size_ridge_fit_of_a_driven_reservoir():
     eta_ref = np.linalg.norm(resid_ref) / (np.linalg.norm(a) * np.linalg.norm(want) + np.linalg.norm(b))
     assert eta <= 1e-15 + 4.0 * eta_ref, (eta, eta_ref)
     dw = wg - want
-    pred = np.sqrt(np.trace(dw @ c @ dw.T) / np.trace(want @ c @ want.T))
+    pred = np.sqrt(max(np.trace(dw @ c @ dw.T), 0.0) / np.trace(want @ c @ want.T))
     assert pred <= 1e-9, pred
     assert np.max(np.abs(dw)) <= 1e-5 * np.max(np.abs(want)), np.max(np.abs(dw)) / np.max(np.abs(want))
