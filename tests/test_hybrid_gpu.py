@@ -227,6 +227,43 @@ def test_pipelined_step_equals_sequential_step():
         assert np.max(np.abs(seq.bank.get_state(s) - pip.bank.get_state(s))) <= 1e-11
 
 
+def test_pipelined_step_with_physics_teacher_forced():
+    """The pipelined schedule WITH the column physics, pinned per window: the two schedules differ only in the association of the
+    readout's column sum (1e-13 in the outvec, hence in the state handed to SPEEDY), which a discrete switch of the parametrisations
+    can turn into 1e-3 K a few steps later.  So each step the pipelined run's hybrid state is (a) compared with the sequential run's
+    at the moment it is handed to SPEEDY (1e-11) and then (b) set to it: from identical inputs the window with physics -- the same
+    kernels on the same stream order -- must give the same bits, and so must the next local_model gathered from its forecast."""
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = list(range(NREG))
+    seq = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, pipeline=False, leapfrog_steps=6, physics=True)
+    pip = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, pipeline=True, leapfrog_steps=6, physics=True)
+    stream = torch.cuda.current_stream()
+    handed = []
+    seq_leg, pip_leg = seq.speedy_leg, pip.speedy_leg
+
+    def seq_hook(st):
+        handed.append(seq.G.clone())
+        seq_leg(st)
+
+    def pip_hook(st):
+        want = handed[-1]
+        part = slice(0, domain.GT_OFF)                          # (the TISR slice is advanced after the window in the sequential order)
+        scale = float(want[part].abs().max())
+        assert float((pip.G[part] - want[part]).abs().max()) <= 1e-11 * scale
+        pip.G[part].copy_(want[part])
+        pip_leg(st)
+
+    seq.speedy_leg, pip.speedy_leg = seq_hook, pip_hook
+    for _ in range(3):
+        seq.step(stream)
+        pip.step(stream)
+        torch.cuda.synchronize()
+        assert torch.equal(seq.F[:domain.GP_OFF], pip.F[:domain.GP_OFF])
+        assert torch.equal(seq.local_model, pip.local_model)
+    assert int(seq.safe.item()) == 1 and int(pip.safe.item()) == 1
+
+
 def test_single_gather_launch_equals_the_two_halves(model):
     """sml_exchange_gather with both sources (one launch) against the feedback-only and the local_model-only calls"""
     m = model
