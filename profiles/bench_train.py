@@ -27,10 +27,10 @@ def main():
         y = torch.randn((m, n_out), dtype=torch.float64, device="cuda")
         c = train.fortran_zeros(n_aug, n_aug)
         b = train.fortran_zeros(n_out, n_aug)
-        for _ in range(2):
+        for _ in range(3):
             train.chunking_matmul(states, model, y, c, b)
         torch.cuda.synchronize()
-        reps = 10 if m == 98 else 3
+        reps = 20
         t0 = time.perf_counter()
         for _ in range(reps):
             train.chunking_matmul(states, model, y, c, b)

@@ -1,7 +1,11 @@
-"""SYRK-only timing of the Gram accumulation (n = 5760, m = 2920): the script behind the ablation table in the header of
-k_gemm_nt_dma (speedy-ml_amd/csrc/train.hip).  The ablated variants (no DMA, no barrier, operands from registers, other ring
-shapes, XCD-aware tile map, split-K tail) were compile-time switches of that kernel and are not kept in the tree; this
-script times whatever kernel the library currently holds."""
+"""SYRK-only timing of the Gram accumulation (n = 5760, m = 2920, 8 target rows): the script behind the ablation numbers in the
+headers of k_gemm_nt_dma and k_gemm_nt_big (speedy-ml_amd/csrc/train.hip).
+  SML_GEMM_BIG=0            the 128 x 128 kernel + side streams (its own ablated variants were compile-time switches that are
+                            not kept in the tree)
+  SML_GEMM_ABL=1|2|4|7      k_gemm_nt_big without DMA | without LDS reads | without barrier | without all three (results are wrong,
+                            the timing is the point)
+  SML_GEMM_STAMPS=1         shader cycles per full-K tile, clock, cycles per MFMA, cycles at the scalar point (stderr)
+  SML_GEMM_XCD=0 / SML_GEMM_SPLIT=0   list not dealt per XCD / no K-split tail"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package

@@ -240,6 +240,241 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict_
     store_tile(C, ldc, M, N, i0, j0, w, alpha, acc);
 }
 
+// ---- Gram update with 256 x 128 tiles: four wavefronts of 128 (I) x 64 (J) each, ONE workgroup per CU ----
+// Why: in k_gemm_nt_dma (128 x 128 tile, four 64 x 64 wavefronts, two workgroups per CU) the eight wavefronts of a CU issue
+// 20 operand reads per 64 MFMAs (31 % of the LDS cycles, in bursts right after every barrier) beside 16 B/clk of LDS-DMA writes;
+// its own ablation prices that contention at 15 % and DMA + barrier at 14 %.  A 128 x 64 wavefront tile needs 24 reads per 128
+// MFMAs (9 % of the LDS cycles with four wavefronts) and the 256 x 128 workgroup tile 6 B/clk of DMA.  With ONE wavefront per
+// SIMD nothing covers an instruction that is not an MFMA, so the kernel is one MFMA stream with everything else threaded
+// through it (profiles/micro/mfma_f64_issue.hip: one wavefront per SIMD issues independent f64 MFMAs at 93-96 % of the
+// two-wavefront rate when nothing else is in the stream):
+//   * the fragments of the NEXT k-step are read from LDS while the MFMAs of the current one issue, one two-double read per group
+//     of eight MFMAs -- across K-tile boundaries too: the barrier of a K-tile sits at the top of its iteration, where that tile's
+//     first fragments are already in registers (read, after the previous barrier, from a slot that had landed by then);
+//   * the six LDS-DMA instructions a wavefront owes per K-tile go one each into six of those groups; what they need besides
+//     (counted wait, barrier, M0, base advance) sits at one scalar point per K-tile (see "What a non-MFMA instruction costs").
+// A workgroup of this kernel owns its CU (512 registers per lane, 108 KB of LDS): anything else in flight -- the skinny products
+// of the same update on side streams, as k_gemm_nt_dma had them -- takes whole CUs away from it (measured: 1.77 -> 2.39 ms).  So
+// ALL products of one Gram update are tiles of one work list (BigItem), balanced over the chip by the host (gemm_big_plan).
+// Measured, one Gram update of the shipped shape (n = 5760, 132 model rows, 136 targets, m = 2920; profiles/gram_only.py):
+// 1.81 ms = 59.9 TF/s of executed flops (lower-triangle 128-blocks + skinny blocks) = 76 % of the 78.6 TF/s fp64 MFMA spec, against
+// 2.50 ms = 43.3 TF/s for k_gemm_nt_dma + side streams; 16.6 cycles per MFMA inside the K loop (16.0 = the instruction's length;
+// SML_GEMM_STAMPS=1), matrix pipe busy 87.7 % of the launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r2_gram_pmc.json; the rest is the
+// K loop's 4 %, prologue / epilogue of 624 tiles and the last round).  History of this kernel, same update: DMA issue and LDS
+// reads as blocks in front of the MFMAs 2.7 ms; reads and DMAs threaded through the MFMAs 2.22; all products in one list 1.98; no
+// vector ALU work in the loop and one scalar point per K-tile 1.84; the six DMAs in separate groups 1.80; tail dealt out by K-tiles
+// (stream-K) 1.79.  Ablations (SML_GEMM_ABL, profiles/micro/gemm_phase_ablation.py; SYRK + 8 target rows): full 1.82 ms, no DMA
+// 1.74, no LDS reads 1.82, no barrier 1.80, none of the three 1.75.  An XCD-aware deal of the list (runs of 32 tiles sharing operand rows per L2) is
+// worth < 1 %; a look-ahead of 2 K-tiles instead of 3 costs 230 cycles of exposed wait per K-tile.
+// Accumulators: 128 doubles per lane (the 256 AGPRs); two fragment sets of 8 + 16 doubles.
+constexpr int GB_I = 256, GB_J = 128, GB_T = 256, GB_LDA = 272, GB_LDB = 160, GB_NBUF = 4, GB_AHEAD = 3;
+constexpr int GB_ROW = GB_LDA + GB_LDB;                          // doubles per k: the A rows then the B rows
+constexpr int GB_SLOT = DKT * GB_ROW;                            // doubles per ring slot
+
+struct BigFrag { double a[8], b[16]; };
+
+// (the 12 two-double reads of a fragment set: units 0-3 = a[2j], a[2j+1]; units 4-11 = b[2j'], b[2j'+1] -- gb_read_unit)
+__device__ __forceinline__ void gb_mma_u(const BigFrag &f, int u, double (&acc)[8][16])
+{
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.b[u], f.a[t], acc[t][u], 0, 0, 0);
+}
+
+// The operands of one Gram update: sources 0 = states, 1 = imperfect-model states, 2 = targets (row-contiguous: X(i,k) = X[i + k*ld]),
+// outputs 0 = C (n_aug x n_aug), 1 = B (n_out x n_aug), both column-major.
+struct BigOperands { const double *src[3]; long ld[3]; double *out[2]; long ldo[2]; unsigned long long *stamps; };
+
+// One work item: D = A_tile * B_tile^T over the K range [k_begin, k_end) (multiples of DKT), A_tile = rows a_row0.. of source a_src
+// (a_rows of them readable: rows past that are clamped to valid memory, their products only reach elements that are never stored),
+// likewise B.  Rows < si and columns < sj of D are added to out[c_out] at element offset c_off (dst = 0), or the whole tile is
+// stored into partial[dst - 1] (a K-split piece; k_gemm_big_reduce adds the pieces of a tile into the output in a fixed order).
+struct BigItem { int a_src, a_row0, a_rows, b_src, b_row0, b_rows, c_out, si, sj, k_begin, k_end, dst, np, pad; long c_off; };
+
+// What a non-MFMA instruction costs a wavefront that owns its SIMD (profiles/micro/mfma_f64_issue.hip, cycles lost per occurrence
+// in a stream of independent f64 MFMAs, 16 cycles each): ds_read2_b64 2.8, global_load 8, ONE scalar instruction 16 (eight in a row
+// 36), ONE vector-ALU instruction 28 (four in a row 40), a not-taken branch 26.  So the K loop holds no vector ALU work at all
+// (every LDS read address and DMA lane offset is a register computed before the loop; the ring is unrolled so the slot is a
+// compile-time choice of register), and its scalar work -- the counted wait, the barrier, the M0 write, the advance of the two
+// operand bases, the loop test -- sits at ONE point per K-tile.  The six DMA instructions share that one M0: the instruction
+// offset of global_load_lds applies to the global address AND the LDS address (profiles/micro/lds_dma_offset.hip), so the lane
+// offsets carry its opposite; each sits alone in an MFMA group, because a DMA whose lines miss the vector L1 holds the issue port
+// for ~36 cycles and six in a row cost 240 cycles per K-tile (measured) against ~60 spread out.  First version of this loop
+// (address arithmetic and an M0 write per DMA, a branch around each): 18.6 cycles per MFMA, 1.6 of them the DMA issue.
+typedef __attribute__((address_space(3))) const double *lds_cptr_t;
+constexpr int GB_MID = 2816;        // M0 points this many bytes into the 6 DMA targets of a wavefront; instruction offsets are +-GB_MID
+
+__device__ __forceinline__ void gb_read_unit(unsigned ra, unsigned rb, int j, BigFrag &f)
+{
+    lds_cptr_t ar = (lds_cptr_t)(uintptr_t)ra, br = (lds_cptr_t)(uintptr_t)rb;
+    if (j < 4) { f.a[2 * j] = ar[32 * j]; f.a[2 * j + 1] = ar[32 * j + 16]; }
+    else { const int u = 2 * (j - 4); f.b[u] = br[4 * u]; f.b[u + 1] = br[4 * u + 4]; }
+}
+
+// the six DMAs of one K-tile at once (the prologue only: in the loop they go one per MFMA group)
+#define GB_DMA6                                                                                                              \
+    "s_mov_b32 m0, %[m0]\n s_nop 0\n"                                                                                         \
+    "global_load_lds_dwordx4 %[v0], %[sa] offset:%[i0]\n global_load_lds_dwordx4 %[v1], %[sa] offset:%[i1]\n"               \
+    "global_load_lds_dwordx4 %[v2], %[sb] offset:%[i2]\n global_load_lds_dwordx4 %[v3], %[sa] offset:%[i3]\n"               \
+    "global_load_lds_dwordx4 %[v4], %[sa] offset:%[i4]\n global_load_lds_dwordx4 %[v5], %[sb] offset:%[i5]\n"
+#define GB_DMA6_OPS(M0V)                                                                                                     \
+    [m0] "s"(M0V), [v0] "v"(vq[0]), [v1] "v"(vq[1]), [v2] "v"(vq[2]), [v3] "v"(vq[3]), [v4] "v"(vq[4]), [v5] "v"(vq[5]), [sa] "s"(sa),  \
+        [sb] "s"(sb), [i0] "n"(0 - GB_MID), [i1] "n"(1024 - GB_MID), [i2] "n"(GB_LDA * 8 - GB_MID), [i3] "n"(GB_ROW * 8 - GB_MID),       \
+        [i4] "n"(GB_ROW * 8 + 1024 - GB_MID), [i5] "n"(GB_ROW * 8 + GB_LDA * 8 - GB_MID)
+
+template <int ABL>
+__global__ __launch_bounds__(GB_T, 1) void k_gemm_nt_big(BigOperands ops, double alpha, const BigItem *__restrict__ items,
+                                                          const int *__restrict__ wg_first, double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double gb_lds[];       // [GB_NBUF][DKT][GB_ROW]; the only LDS of the kernel: byte address 0
+    // a workgroup of the bulk owns one item; a workgroup of the tail owns a run of K-tiles that may end one tile and begin the next
+    for (int item = wg_first[blockIdx.x], item_end = wg_first[blockIdx.x + 1]; item < item_end; ++item) {
+    if (item != wg_first[blockIdx.x]) asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");   // (the ring is reused)
+    const BigItem it = items[item];
+    const unsigned long long stamp_c0 = (ABL & 8) ? __builtin_readcyclecounter() : 0, stamp_r0 = (ABL & 8) ? __builtin_amdgcn_s_memrealtime() : 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = (wave & 1) * 128, wj = (wave >> 1) * 64, l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3;
+    const int ntiles = (it.k_end - it.k_begin) / DKT;
+    // DMA: wavefront w moves k-columns 2w and 2w+1 of a K-tile: A rows 0-127, A rows 128-255, B rows 0-127 of each (6 instructions).
+    // Global address = scalar base (advanced by one K-tile per iteration, stopping at the last: the tail of the loop re-fetches that
+    // tile into slots nobody reads) + lane offset + instruction offset; the bases sit 4096 bytes low so no lane offset is negative.
+    const long lda = ops.ld[it.a_src], ldb = ops.ld[it.b_src];
+    const char *sa = (const char *)(ops.src[it.a_src] + it.a_row0 + (long)it.k_begin * lda) - 4096;
+    const char *sb = (const char *)(ops.src[it.b_src] + it.b_row0 + (long)it.k_begin * ldb) - 4096;
+    unsigned vq[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int k = 2 * wave + q / 3, part = q % 3;
+        const int row = part == 0 ? min(2 * lane, it.a_rows - 2) : part == 1 ? min(128 + 2 * lane, it.a_rows - 2) : min(2 * lane, it.b_rows - 2);
+        const int imm = (q / 3) * GB_ROW * 8 + (part == 0 ? 0 : part == 1 ? 1024 : GB_LDA * 8) - GB_MID;
+        vq[q] = (unsigned)(((long)k * (part < 2 ? lda : ldb) + row) * 8 + 4096 - imm);
+        asm volatile("" : "+v"(vq[q]));
+    }
+    const long step_a = (long)DKT * lda * 8, step_b = (long)DKT * ldb * 8;
+    unsigned m0v[GB_NBUF];
+#pragma unroll
+    for (int sl = 0; sl < GB_NBUF; ++sl) m0v[sl] = (unsigned)((sl * GB_SLOT + 2 * wave * GB_ROW) * 8 + GB_MID);
+    // LDS read addresses (bytes) of the two k-steps of every ring slot
+    unsigned ra[GB_NBUF][2], rb[GB_NBUF][2];
+#pragma unroll
+    for (int sl = 0; sl < GB_NBUF; ++sl)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ra[sl][h] = (unsigned)((sl * GB_SLOT + (4 * h + l4) * GB_ROW + wi + l15) * 8);
+            rb[sl][h] = (unsigned)((sl * GB_SLOT + (4 * h + l4) * GB_ROW + GB_LDA + wj + l3) * 8);
+            asm volatile("" : "+v"(ra[sl][h]), "+v"(rb[sl][h]));
+        }
+    double acc[8][16];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 16; ++b) acc[a][b] = 0.0;
+    // prologue: tiles 0, 1, 2 on their way (a K range shorter than that repeats its last tile)
+    int ahead = 0;                                                         // K-tiles the bases are ahead of k_begin
+#pragma unroll
+    for (int T = 0; T < GB_AHEAD; ++T) {
+        if (!(ABL & 1)) asm volatile(GB_DMA6 ::GB_DMA6_OPS(m0v[T]) : "memory");
+        if (ahead + 1 < ntiles) { sa += step_a; sb += step_b; ++ahead; }
+    }
+    asm volatile("s_waitcnt vmcnt(12)\n s_barrier" ::: "memory");       // tile 0 has landed, for every wavefront
+    BigFrag f0, f1;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) gb_read_unit(ra[0][0], rb[0][0], j, f0);
+    unsigned long long wait_top = 0;
+    // one K-tile; SL = its ring slot.  Returns false after the last.
+    auto ktile = [&](auto slot_tag, int t) {
+        constexpr int SL = decltype(slot_tag)::value, NX = (SL + 1) % GB_NBUF, FILL = (SL + GB_AHEAD) % GB_NBUF;
+        const unsigned long long w0 = (ABL & 8) ? __builtin_readcyclecounter() : 0;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0), where the compiler's own bookkeeping sees it
+        // tile t+1 has landed (tile t+2 may stay in flight); the reads of f0 are done; every wavefront is done with slot (t-1) % 4,
+        // which the DMAs of tile t+3 refill
+        if (ABL & 4) asm volatile("s_waitcnt vmcnt(6)\n s_mov_b32 m0, %0" ::"s"(m0v[FILL]) : "memory");
+        else if (ABL & 1) asm volatile("s_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)\n s_barrier\n s_mov_b32 m0, %0" ::"s"(m0v[FILL]) : "memory");
+        if (ABL & 8) wait_top += __builtin_readcyclecounter() - w0;
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 0 of tile t, the reads of k-step 1 under it
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u < 12 && (!(ABL & 2) || t == 0)) gb_read_unit(ra[SL][1], rb[SL][1], u, f1);
+            if (!(ABL & 1) && (u & 1) && u < 12) {                        // the six DMAs of tile t+3, one per odd group (M0 from the scalar point)
+                constexpr int imm[6] = {0 - GB_MID, 1024 - GB_MID, GB_LDA * 8 - GB_MID, GB_ROW * 8 - GB_MID, GB_ROW * 8 + 1024 - GB_MID,
+                                        GB_ROW * 8 + GB_LDA * 8 - GB_MID};
+                const int q = u >> 1;
+                asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(vq[q]), "s"(q % 3 == 2 ? sb : sa), "n"(imm[q]) : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            gb_mma_u(f0, u, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): f1 (read >= 32 MFMAs ago)
+        // k-step 1 of tile t, the reads of k-step 0 of tile t+1 under it (after the last tile: dead reads)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u < 12 && !(ABL & 2)) gb_read_unit(ra[NX][0], rb[NX][0], u, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            gb_mma_u(f1, u, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ahead + 1 < ntiles) { sa += step_a; sb += step_b; ++ahead; }     // (scalar: lands at the next tile's scalar point)
+    };
+    for (int t = 0; t < ntiles; t += GB_NBUF) {
+        ktile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 >= ntiles) break;
+        ktile(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 >= ntiles) break;
+        ktile(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 >= ntiles) break;
+        ktile(std::integral_constant<int, 3>{}, t + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the re-fetched last tiles)
+    if ((ABL & 8) && ops.stamps && threadIdx.x == 0) {          // (SML_GEMM_STAMPS: shader cycles and 100 MHz ticks of the K loop, per workgroup)
+        ops.stamps[4 * blockIdx.x] = __builtin_readcyclecounter() - stamp_c0;
+        ops.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        ops.stamps[4 * blockIdx.x + 2] = wait_top;
+        ops.stamps[4 * blockIdx.x + 3] = 0;
+    }
+    // lane l holds D(wi + 16 t + (l & 15), wj + 4 u + (l >> 4)): 16 consecutive lanes = 128 contiguous bytes of a column
+    if (it.dst) {
+        double *dst = partial + (size_t)(it.dst - 1) * GB_I * GB_J;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) dst[(size_t)(wj + 4 * u + l4) * GB_I + wi + 16 * t + l15] = acc[t][u];
+        continue;
+    }
+    // Every element of the output belongs to exactly one item of a launch, so a fire-and-forget atomic add gives the same sum as
+    // load + add + store, without a round trip to memory per column.
+    double *C = ops.out[it.c_out] + it.c_off;
+    const long ldc = ops.ldo[it.c_out];
+    const int room = it.si - (wi + l15);                                   // rows of this lane's column segments that exist: 16 t < room
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = wj + 4 * u + l4;
+        double *col = C + (long)j * ldc + wi + l15;
+        if (j < it.sj) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (16 * t < room) unsafeAtomicAdd(col + 16 * t, alpha * acc[t][u]);
+        }
+    }
+    }
+}
+
+// out tile += alpha * (piece_0 + piece_1 + ...) in that order: the K-split pieces of the tail tiles
+__global__ __launch_bounds__(256) void k_gemm_big_reduce(BigOperands ops, double alpha, const BigItem *__restrict__ tails,
+                                                          const double *__restrict__ partial)
+{
+    const BigItem it = tails[blockIdx.y];                                  // .dst = first piece's slot (1-based), .np = number of pieces
+    const int pieces = it.np;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int il = e % GB_I, jl = e / GB_I;
+    if (il >= it.si || jl >= it.sj) return;
+    double s = 0.0;
+    for (int p = 0; p < pieces; ++p) s = s + partial[(size_t)(it.dst - 1 + p) * GB_I * GB_J + e];
+    double *c = ops.out[it.c_out] + it.c_off + (long)jl * ops.ldo[it.c_out] + il;
+    *c = *c + alpha * s;
+}
+
 __global__ void k_symmetrize(double *__restrict__ c, int n)
 {   // upper <- lower^T, tile-wise through LDS so both the read and the write are contiguous
     __shared__ double t[32][33];
@@ -965,6 +1200,177 @@ int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, lon
 
 extern "C" {
 
+// The work list of one Gram update for the 256 x 128 kernel: every product of sml_train_accumulate as tiles of one launch.
+//   states x states^T (tiles that touch the lower triangle; row tiles aligned to the BOTTOM of the block: a short first row tile
+//   of n mod 256 rows meets one or two column tiles, a short last one would meet all of them), states x model^T, model x model^T
+//   -> C;  targets x model^T, targets x states^T -> B.
+// The bulk (a whole number of rounds of the chip's CUs) runs as full-K items that update the output directly; the ragged rest is
+// cut along K into as many pieces as fill one more round, whose partial products land in a scratch and are added to the output
+// in a fixed order (deterministic, unlike atomics).  Shipped shape (n = 5760, 132 model rows, 136 targets): 529 + 46 + 2 + 2 + 45
+// = 624 tiles = 2 rounds + 112 tiles in 2 pieces each.
+constexpr int GB_SUPER_I = 4, GB_SUPER_J = 8;
+struct BigPlan {
+    int n = 0, n_model = 0, n_out = 0, k = 0, ncu = 0;
+    int nitems = 0, ntails = 0, nwg = 0;
+    BigItem *d_items = nullptr, *d_tails = nullptr;
+    int *d_wg_first = nullptr;
+    double *d_partial = nullptr;
+    size_t cap_partial = 0;
+};
+
+static void big_product(std::vector<BigItem> &tiles, int a_src, int a_n, int b_src, int b_n, int c_out, long c_base, long ldc, bool lower, int K)
+{
+    // Row tiles from the bottom (the longest tile rows of a triangular product first), in super-tiles of GB_SUPER_I row tiles x
+    // GB_SUPER_J column tiles: 32 consecutive tiles of the list then read 4 x 256 + 8 x 128 operand rows between them instead of
+    // 32 x 384, and gemm_big_plan hands such runs to one XCD (one L2) each.
+    const int nrt = (a_n + GB_I - 1) / GB_I, nct = (b_n + GB_J - 1) / GB_J;
+    for (int R = 0; R < nrt; R += GB_SUPER_I)
+        for (int Cs = 0; Cs < nct; Cs += GB_SUPER_J)
+            for (int r = R; r < std::min(nrt, R + GB_SUPER_I); ++r) {
+                const int i_end = a_n - r * GB_I, i0 = std::max(0, i_end - GB_I);
+                for (int ct = Cs; ct < std::min(nct, Cs + GB_SUPER_J); ++ct) {
+                    const int j0 = ct * GB_J;
+                    if (lower && j0 >= i_end) continue;
+                    BigItem t{};
+                    t.a_src = a_src; t.a_row0 = i0; t.a_rows = a_n - i0;
+                    t.b_src = b_src; t.b_row0 = j0; t.b_rows = b_n - j0;
+                    t.c_out = c_out; t.c_off = c_base + i0 + (long)j0 * ldc;
+                    t.si = i_end - i0; t.sj = std::min(GB_J, b_n - j0);
+                    t.k_begin = 0; t.k_end = K; t.dst = 0;
+                    tiles.push_back(t);
+                }
+            }
+}
+
+// Workgroup w of a launch runs on XCD w % 8 (round-robin dispatch), 32 at a time per XCD.  Deal a list out so that XCD x works
+// through runs x, x + 8, x + 16 ... of 32 consecutive entries: entry e of the list goes to workgroup 8 * (32 * (run / 8) + e % 32) + run % 8.
+static std::vector<BigItem> xcd_deal(const std::vector<BigItem> &list)
+{
+    static const int on = getenv("SML_GEMM_XCD") ? atoi(getenv("SML_GEMM_XCD")) : 1;
+    const size_t n = list.size();
+    if (!on || n % 256) return list;              // (whole rounds only: a ragged list keeps its order)
+    std::vector<BigItem> out(n);
+    for (size_t e = 0; e < n; ++e) {
+        const size_t run = e / 32;
+        out[8 * (32 * (run / 8) + e % 32) + run % 8] = list[e];
+    }
+    return out;
+}
+
+static int gemm_big_plan(BigPlan &P, int n, int n_model, int n_out, int K)
+{
+    if (P.n == n && P.n_model == n_model && P.n_out == n_out && P.k == K && P.d_items) return SML_OK;
+    if (!P.ncu) {
+        int dev = 0;
+        SML_HIP(hipGetDevice(&dev));
+        SML_HIP(hipDeviceGetAttribute(&P.ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int n_aug = n + n_model;
+    std::vector<BigItem> tiles;
+    big_product(tiles, 0, n, 0, n, 0, (long)n_model + (long)n_model * n_aug, n_aug, true, K);
+    if (n_model) {
+        big_product(tiles, 0, n, 1, n_model, 0, n_model, n_aug, false, K);
+        big_product(tiles, 1, n_model, 1, n_model, 0, 0, n_aug, false, K);
+        big_product(tiles, 2, n_out, 1, n_model, 1, 0, n_out, false, K);
+    }
+    big_product(tiles, 2, n_out, 0, n, 1, (long)n_model * n_out, n_out, false, K);
+    const int total = (int)tiles.size();
+    static const int split_on = getenv("SML_GEMM_SPLIT") ? atoi(getenv("SML_GEMM_SPLIT")) : 1;
+    const int bulk = split_on ? (total / P.ncu) * P.ncu : total, rest = total - bulk;
+    std::vector<BigItem> items = xcd_deal(std::vector<BigItem>(tiles.begin(), tiles.begin() + bulk)), tails;
+    std::vector<int> wg_first;
+    for (int i = 0; i <= bulk; ++i) wg_first.push_back(i);
+    int nslots = 0;
+    if (rest > 0) {
+        // the tail: rest * ktiles K-tiles of work dealt out evenly, in order, to one more round of workgroups
+        const long ktiles = K / DKT, units = (long)rest * ktiles;
+        for (int r = 0; r < rest; ++r) { tails.push_back(tiles[bulk + r]); tails.back().np = 0; }
+        for (int c = 0; c < P.ncu; ++c) {
+            const long u0 = units * c / P.ncu, u1 = units * (c + 1) / P.ncu;
+            if (u1 <= u0) continue;
+            for (long r = u0 / ktiles; r <= (u1 - 1) / ktiles; ++r) {
+                BigItem q = tiles[bulk + r];
+                q.k_begin = (int)(std::max(u0, r * ktiles) - r * ktiles) * DKT;
+                q.k_end = (int)(std::min(u1, (r + 1) * ktiles) - r * ktiles) * DKT;
+                q.dst = ++nslots;
+                if (!tails[r].np++) tails[r].dst = q.dst;
+                items.push_back(q);
+            }
+            wg_first.push_back((int)items.size());
+        }
+    }
+    // (a plan in use by launches still in flight must not be freed under them)
+    SML_HIP(hipDeviceSynchronize());
+    if (P.d_items) (void)hipFree(P.d_items);
+    if (P.d_tails) (void)hipFree(P.d_tails);
+    if (P.d_wg_first) (void)hipFree(P.d_wg_first);
+    P.d_items = P.d_tails = nullptr;
+    P.d_wg_first = nullptr;
+    SML_HIP(hipMalloc((void **)&P.d_wg_first, wg_first.size() * sizeof(int)));
+    SML_HIP(hipMemcpy(P.d_wg_first, wg_first.data(), wg_first.size() * sizeof(int), hipMemcpyHostToDevice));
+    SML_HIP(hipMalloc((void **)&P.d_items, items.size() * sizeof(BigItem)));
+    SML_HIP(hipMalloc((void **)&P.d_tails, std::max<size_t>(tails.size(), 1) * sizeof(BigItem)));
+    const size_t need = std::max<size_t>((size_t)nslots, 1) * GB_I * GB_J * sizeof(double);
+    if (need > P.cap_partial) {
+        if (P.d_partial) (void)hipFree(P.d_partial);
+        P.d_partial = nullptr;
+        P.cap_partial = 0;
+        SML_HIP(hipMalloc((void **)&P.d_partial, need));
+        P.cap_partial = need;
+    }
+    SML_HIP(hipMemcpy(P.d_items, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice));
+    if (rest) SML_HIP(hipMemcpy(P.d_tails, tails.data(), tails.size() * sizeof(BigItem), hipMemcpyHostToDevice));
+    P.n = n; P.n_model = n_model; P.n_out = n_out; P.k = K;
+    P.nitems = (int)items.size(); P.ntails = rest; P.nwg = (int)wg_first.size() - 1;
+    return SML_OK;
+}
+
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// every product of one Gram update over the first K (a multiple of DKT) time columns, in one launch (+ the reduction of the tail)
+static int gemm_big_accumulate(const double *states, const double *model, const double *y, int n, int n_model, int n_out, int K, double *c, double *b,
+                               hipStream_t st)
+{
+    static BigPlan plan;                          // (one shape at a time: training runs one size class after another)
+    int rc;
+    if ((rc = gemm_big_plan(plan, n, n_model, n_out, K))) return rc;
+    BigOperands ops{};
+    ops.src[0] = states; ops.ld[0] = n;
+    ops.src[1] = model; ops.ld[1] = n_model;
+    ops.src[2] = y; ops.ld[2] = n_out;
+    ops.out[0] = c; ops.ldo[0] = n + n_model;
+    ops.out[1] = b; ops.ldo[1] = n_out;
+    static unsigned long long *d_stamps = nullptr;
+    if (getenv("SML_GEMM_STAMPS") && !d_stamps) SML_HIP(hipMalloc((void **)&d_stamps, 4 * 4096 * sizeof(unsigned long long)));
+    ops.stamps = d_stamps;
+    const size_t lds = (size_t)GB_NBUF * GB_SLOT * sizeof(double);
+    static const int abl = getenv("SML_GEMM_ABL") ? atoi(getenv("SML_GEMM_ABL")) : 0;   // (profiles/micro/gemm_phase_ablation.py)
+#define GB_LAUNCH(X)                                                                                                                  \
+    case X:                                                                                                                           \
+        SML_HIP(hipFuncSetAttribute((const void *)k_gemm_nt_big<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL(k_gemm_nt_big<X>, dim3((unsigned)plan.nwg), dim3(GB_T), lds, st, ops, 1.0, (const BigItem *)plan.d_items, (const int *)plan.d_wg_first, \
+                           plan.d_partial);                                                                                           \
+        break;
+    switch (abl | (d_stamps ? 8 : 0)) { GB_LAUNCH(0) GB_LAUNCH(1) GB_LAUNCH(2) GB_LAUNCH(3) GB_LAUNCH(4) GB_LAUNCH(7) GB_LAUNCH(8) default: return SML_ERR_ARG; }
+#undef GB_LAUNCH
+    SML_HIP(hipGetLastError());
+    if (ops.stamps) {
+        std::vector<unsigned long long> h(4 * (size_t)plan.nwg);
+        SML_HIP(hipMemcpy(h.data(), ops.stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
+        double cyc = 0, ticks = 0, wv = 0, wb = 0;
+        const int cnt = std::min(plan.nwg, 512);
+        for (int i = 0; i < cnt; ++i) { cyc += (double)h[4 * i]; ticks += (double)h[4 * i + 1]; wv += (double)h[4 * i + 2]; wb += (double)h[4 * i + 3]; }
+        fprintf(stderr, "[gemm_big] full-K items: %.0f shader cycles, %.1f us each (%.3f GHz); %.2f cycles per MFMA; per K-tile: %.0f cycles at the scalar point (incl. ~40 for the stamp itself)%.0s\n",
+                cyc / cnt, ticks / cnt / 100.0, cyc / ticks * 0.1, cyc / cnt / ((double)(K / DKT) * 256), wv / cnt / (K / DKT), wb / cnt / (K / DKT));
+    }
+    if (plan.ntails) {
+        hipLaunchKernelGGL(k_gemm_big_reduce, dim3(GB_I * GB_J / 256, plan.ntails), dim3(256), 0, st, ops, 1.0, (const BigItem *)plan.d_tails,
+                           (const double *)plan.d_partial);
+        SML_HIP(hipGetLastError());
+    }
+    return SML_OK;
+}
+
 int sml_train_accumulate(const double *states, const double *model, const double *y, int n, int n_model, int n_out, int m,
                          double *c, double *b, void *stream)
 {
@@ -973,6 +1379,17 @@ int sml_train_accumulate(const double *states, const double *model, const double
     hipStream_t st = sml::as_stream(stream);
     const int n_aug = n + n_model;
     int rc;
+    // Long products: all of them as one launch of the 256 x 128 kernel over the part of m that is a multiple of 8 (the rest of m,
+    // at most 7 columns, through the general path below).  Needs even row counts and 16-byte aligned columns for the LDS-DMA.
+    static const int big_on = getenv("SML_GEMM_BIG") ? atoi(getenv("SML_GEMM_BIG")) : 1;
+    if (big_on && m >= 512 && !(n & 1) && !(n_model & 1) && !(n_out & 1) && n >= GB_I && aligned16(states) && aligned16(y) && (!n_model || aligned16(model))) {
+        const int kb = (m / DKT) * DKT;
+        if ((rc = gemm_big_accumulate(states, model, y, n, n_model, n_out, kb, c, b, st))) return rc;
+        if (kb == m) return SML_OK;
+        states += (long)kb * n; y += (long)kb * n_out;
+        if (n_model) model += (long)kb * n_model;
+        m -= kb;
+    }
     // aug = [model ; states] is never materialised: the four (model|states) x (model|states) blocks of C and the two
     // blocks of B are separate launches on the original arrays.  Only tiles on/below the diagonal of C are updated.
     // The skinny products (132- and 136-row operands: 90 tiles each) would each cost a full tile latency (the K loop of
