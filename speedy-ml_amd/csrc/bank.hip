@@ -50,7 +50,7 @@ struct TrainSlot { double *states; int n; };      // a slot's states(n, .) buffe
 // REFERENCE's row order with the even (1-based) rows squared (src/mod_reservoir.f90:1133) -- stored from here, one launch less
 // per time column than a separate copy kernel.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
                                                      int parts, const double *__restrict__ u_all, int u_stride, int cur, int square_input,
                                                      int whole_blocks, const TrainSlot *__restrict__ train_slots, int train_col)
 {
@@ -64,10 +64,10 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
     if ((int)blockIdx.x < whole_blocks) { decode_block(blockIdx.x, 1, res_begin, res, part); parts = 1; }
     else decode_block((int)blockIdx.x - whole_blocks, parts, res_begin + whole_blocks, res, part);
     if (res >= res_end) return;
-    const ResDesc D = descs[res];
+    const ResDesc &D = descs[res];   // (by reference: a copy with x[cur] indexed at run time lives in scratch, 136 B per lane)
     if (!D.loaded) return;
-    const double *__restrict__ x = D.x[cur];
-    double *__restrict__ xn = D.x[cur ^ 1];
+    const double *__restrict__ x = cur ? D.x[1] : D.x[0];
+    double *__restrict__ xn = cur ? D.x[0] : D.x[1];
     const double *__restrict__ u = u_all + (size_t)res * u_stride;
     // stage [x ; u] with 16-byte loads (x is 256-byte aligned)
     const int n2 = D.n >> 1;
@@ -89,11 +89,11 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
     int s = part * NW + wave;
     // slice metadata is fetched one slice ahead (and, for the first slice, before [x ; u] is staged), so each slice costs
     // one exposed memory round trip (its entries) instead of two
-    int off_n = 0, end_n = 0, len_n = 0;
-    if (s < D.nslices) { off_n = D.slice_off[s]; end_n = D.slice_off[s + 1]; len_n = D.row_len[s * 64 + lane]; }
+    int off_n = 0, end_n = 0;
+    if (s < D.nslices) { off_n = D.slice_off[s]; end_n = D.slice_off[s + 1]; }
     for (; s < D.nslices; s += stride) {
-        const int off = off_n, width = (end_n - off_n) >> 6, len = len_n;
-        if (s + stride < D.nslices) { off_n = D.slice_off[s + stride]; end_n = D.slice_off[s + stride + 1]; len_n = D.row_len[(s + stride) * 64 + lane]; }
+        const int off = off_n, width = (end_n - off_n) >> 6;
+        if (s + stride < D.nslices) { off_n = D.slice_off[s + stride]; end_n = D.slice_off[s + stride + 1]; }
         const int r = s * 64 + lane;                      // device position == sorted position: contiguous stores
         const unsigned short *__restrict__ cp = D.sell_col + off + lane;
         const double *__restrict__ vp = D.sell_val + off + lane;
@@ -109,20 +109,35 @@ __global__ __launch_bounds__(THREADS) void k_update(const ResDesc *__restrict__ 
             cc[q] = 0; vv[q] = 0.0;
             if (q < width) { cc[q] = cp[q * 64]; vv[q] = vp[q * 64]; }      // width is wave-uniform
         }
+        // The gathers are unconditional and issued together (one LDS round trip per slice, not one per entry behind a divergent
+        // branch each): an entry past the row's length is the layout's padding (value +0.0, column 0), whose product is a zero
+        // of either sign, and acc -- which starts at +0.0 and therefore is never -0.0 -- plus a zero is acc, bit for bit
+        // (as long as x[0] is finite; a state that is not has tripped the range guard anyway).
+        // (two batches of four: eight gathered values at once cost 8 more registers than the 80 that 6 wavefronts per SIMD allow)
 #pragma unroll
-        for (int q = 0; q < WB; ++q)
-            if (q < len) acc += vv[q] * xu[cc[q]];
+        for (int h = 0; h < WB; h += 4) {
+            double xg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xg[q] = xu[cc[h + q]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += vv[h + q] * xg[q];
+        }
         for (int j = WB; j < width; j += 4) {                                // long rows (rare): four more per trip
             int c4[4];
-            double v4[4];
+            double v4[4], x4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { c4[q] = 0; v4[q] = 0.0; if (j + q < width) { c4[q] = cp[(j + q) * 64]; v4[q] = vp[(j + q) * 64]; } }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (j + q < len) acc += v4[q] * xu[c4[q]];
+            for (int q = 0; q < 4; ++q) x4[q] = xu[c4[q]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += v4[q] * x4[q];
         }
         if (r < D.n) {
+#ifdef SML_EXPERIMENT_NO_TANH                            // (profiles/micro/update_floor.sh: what the update costs without its tanh)
+            const double xt = acc;
+#else
             const double xt = tanh(acc);
+#endif
             const double v = (1.0 - D.leak) * (square_input ? x[r] : xu[r]) + D.leak * xt;
             xn[r] = v;
             if (train_slots) {
@@ -147,7 +162,7 @@ __global__ void k_store_state(const ResDesc *__restrict__ descs, const TrainSlot
     if (!D.loaded || !t.states) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.n) return;
-    const double v = D.x[cur][p];
+    const double v = (cur ? D.x[1] : D.x[0])[p];
     const int r = D.perm[p];                       // device position -> reference row (same parity as p)
     t.states[(size_t)col * D.n + r] = (r & 1) ? v * v : v;
 }
@@ -159,7 +174,7 @@ __global__ void k_zero_state(const ResDesc *__restrict__ descs, int nslots, int 
     const ResDesc &D = descs[slot];
     if (!D.loaded) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < D.n) D.x[cur][p] = 0.0;
+    if (p < D.n) (cur ? D.x[1] : D.x[0])[p] = 0.0;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -182,11 +197,11 @@ __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restric
     int res, grp;
     decode_block(blockIdx.x, parts, res_begin, res, grp);
     if (res >= res_end) return;
-    const ResDesc D = descs[res];
+    const ResDesc &D = descs[res];   // (by reference: a copy with x[cur] indexed at run time lives in scratch, 136 B per lane)
     if (!D.loaded) return;
     const int r0 = grp * R;
     if (r0 >= D.n_out) return;
-    const double *__restrict__ x = D.x[cur];
+    const double *__restrict__ x = cur ? D.x[1] : D.x[0];
     const double *__restrict__ lm = lm_all + (size_t)res * lm_stride;
     const size_t ld = (size_t)D.n_aug_pad;
     const double *wrow[R];
@@ -277,11 +292,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_readout_persist(const ResD
         int res, grp;
         decode_block((int)item, parts, res_begin, res, grp);
         if (res >= res_end) continue;
-        const ResDesc D = descs[res];
+        const ResDesc &D = descs[res];   // (by reference: a copy with x[cur] indexed at run time lives in scratch, 136 B per lane)
         if (!D.loaded) continue;
         const int r0 = grp * R;
         if (r0 >= D.n_out) continue;
-        const double *__restrict__ x = D.x[cur];
+        const double *__restrict__ x = cur ? D.x[1] : D.x[0];
         const double *__restrict__ lm = lm_all + (size_t)res * lm_stride;
         const size_t ld = (size_t)D.n_aug_pad;
         const double *wrow[R];
