@@ -52,11 +52,13 @@ def main():
     b = train.fortran_zeros(n_out, n_aug)
     for _ in range(3):
         train.chunking_matmul(states, model, y, c, b)
+    train.fit_chunk_hybrid(c, b, n, n_model, n_out)              # (allocates the workspace)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    w = train.fit_chunk_hybrid(c, b, n, n_model, n_out)
+    for _ in range(3):
+        w = train.fit_chunk_hybrid(c, b, n, n_model, n_out)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) / 3
     flops = (2.0 / 3.0) * n_aug ** 3 + 2.0 * n_aug ** 2 * n_out
     out["fit_5892"] = {"ms": dt * 1e3, "tflops": flops / dt / 1e12}
     reg = torch.diag(torch.cat([torch.full((n_model,), 1.0), torch.full((n,), 1e-6)])).to("cuda", torch.float64)
