@@ -57,6 +57,77 @@ __global__ __launch_bounds__(512) void k_phase(double *buf, int n_per_wg, int ph
     for (int i = threadIdx.x; i < n_per_wg; i += blockDim.x) cur[(size_t)wg * n_per_wg + i] = prev[(size_t)nb * n_per_wg + i] + 1.0;
 }
 
+// ---- XCD-hierarchical barrier (MI355X_MICROARCH.md, row barrier-xcd): the workgroups of one XCD meet on that XCD's counter (their
+// stores sit in the one L2 they share); the last of them -- the XCD's leader for this phase -- writes that L2 back (agent-scope
+// release), arrives on the top counter, waits for the other XCDs' leaders, invalidates (agent-scope acquire) and bumps the XCD's
+// generation word; every other workgroup polls its XCD's generation word and ends with its own agent-scope acquire (its CU's L1).
+// Which XCD a workgroup runs on is read from the hardware (HW_REG_XCC_ID), never derived from blockIdx; the populations are
+// counted in-kernel behind one flat barrier.  Every spin is bounded.
+struct XBar {
+    unsigned pop[8][32];          // workgroups on each XCD (one 128-byte line per word)
+    unsigned cnt[8][32];          // arrivals on each XCD, monotonic
+    unsigned gen[8][32];          // last phase released on each XCD
+    unsigned top[32];             // arrivals of XCD leaders, monotonic
+    unsigned flat[32];            // the one flat barrier behind the census
+    unsigned abort_flag[32];
+};
+#define RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define RLX_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define RLX_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__device__ __forceinline__ bool spin_until(unsigned *word, unsigned target, unsigned *abort_flag)
+{
+    for (long spins = 0; RLX_LOAD(word) < target; ++spins) {
+        if (spins > 4000000 || ((spins & 1023) == 1023 && RLX_LOAD(abort_flag))) { RLX_STORE(abort_flag, 1u); return false; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(512) void k_persistent_xcd(double *buf, int n_per_wg, int phases, XBar *xb)
+{
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    __shared__ unsigned s_xcc, s_pop, s_nx, s_ok;
+    if (threadIdx.x == 0) {
+        // census: which XCD am I on, how many of us are there, how many XCDs are in use
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;        // hwreg(HW_REG_XCC_ID, 0, 4)
+        RLX_ADD(&xb->pop[xcc][0], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        RLX_ADD(&xb->flat[0], 1u);
+        bool ok = spin_until(&xb->flat[0], (unsigned)nwg, &xb->abort_flag[0]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        unsigned nx = 0;
+        for (int x = 0; x < 8; ++x) nx += RLX_LOAD(&xb->pop[x][0]) > 0;
+        s_xcc = xcc; s_pop = RLX_LOAD(&xb->pop[xcc][0]); s_nx = nx; s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const unsigned xcc = s_xcc, pop = s_pop, nx = s_nx;
+    for (int ph = 0; ph < phases; ++ph) {
+        double *cur = buf + (size_t)(ph & 1) * nwg * n_per_wg, *prev = buf + (size_t)((ph + 1) & 1) * nwg * n_per_wg;
+        const int nb = (wg + nwg / 2 + 1) % nwg;
+        for (int i = threadIdx.x; i < n_per_wg; i += blockDim.x) cur[(size_t)wg * n_per_wg + i] = prev[(size_t)nb * n_per_wg + i] + 1.0;
+        __syncthreads();                                         // (s_waitcnt vmcnt(0): this workgroup's stores are in its L2)
+        if (threadIdx.x == 0) {
+            const unsigned p = (unsigned)ph + 1u;
+            bool ok = true;
+            if (RLX_ADD(&xb->cnt[xcc][0], 1u) + 1u == p * pop) {              // the XCD's last arrival leads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                RLX_ADD(&xb->top[0], 1u);
+                ok = spin_until(&xb->top[0], p * nx, &xb->abort_flag[0]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                RLX_STORE(&xb->gen[xcc][0], p);
+            } else {
+                ok = spin_until(&xb->gen[xcc][0], p, &xb->abort_flag[0]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+    }
+}
+
 int main()
 {
     const int nwg = 256, n_per_wg = 2048, phases = 104;
@@ -76,6 +147,23 @@ int main()
         CK(hipMemcpy(out.data(), buf + (size_t)((phases - 1) & 1) * nwg * n_per_wg, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
         bool good = true; for (double v : out) good = good && v == (double)phases;
         printf("persistent: %d phases %.1f us = %.2f us per phase  abort=%u  values %s\n", phases, ms * 1e3, ms * 1e3 / phases, h[1], good ? "ok" : "WRONG");
+        {   // the same phases behind the XCD-hierarchical barrier
+            static XBar *xb = nullptr;
+            if (!xb) CK(hipMalloc(&xb, sizeof(XBar)));
+            CK(hipMemset(buf, 0, sizeof(double) * 2 * nwg * n_per_wg));
+            CK(hipMemset(xb, 0, sizeof(XBar)));
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_persistent_xcd, dim3(nwg), dim3(512), 0, 0, buf, n_per_wg, phases, xb);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            XBar hx; CK(hipMemcpy(&hx, xb, sizeof hx, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(out.data(), buf + (size_t)((phases - 1) & 1) * nwg * n_per_wg, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
+            good = true; for (double v : out) good = good && v == (double)phases;
+            printf("xcd barrier: %d phases %.1f us = %.2f us per phase  abort=%u  values %s  workgroups per XCD:", phases, ms * 1e3, ms * 1e3 / phases,
+                   hx.abort_flag[0], good ? "ok" : "WRONG");
+            for (int x = 0; x < 8; ++x) printf(" %u", hx.pop[x][0]);
+            printf("\n");
+        }
         CK(hipMemset(buf, 0, sizeof(double) * 2 * nwg * n_per_wg));
         CK(hipEventRecord(e0));
         for (int ph = 0; ph < phases; ++ph) hipLaunchKernelGGL(k_phase, dim3(nwg), dim3(512), 0, 0, buf, n_per_wg, ph);
