@@ -468,6 +468,109 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
     }
 }
 
+// The ONE-wavefront form of k_gridtend_physics (sml_dyn_select_physics_form(2)): both chains in sequence by one wavefront per 64
+// columns, 476 registers (220 of them AGPRs used as spill space) and 56 B of scratch at -O3.  Round 1 saw a kernel of this shape --
+// an uncommitted intermediate of the cut into chain functions -- give non-repeatable NaNs at -O3 and dropped it for the two-wave
+// form.  Rebuilt here from the committed chain functions it is repeatable and bit-identical to the two-launch and two-wave forms
+// (tests/test_physics_gpu.py::test_fused_forms_agree_bit_for_bit; so is a variant without launch bounds, 128 registers + 1600 B of
+// scratch, tried and removed), so the round-1 failure was in that intermediate source, not a defect of the compiler that survives
+// in the tree.  It stays selectable as the subject of that test and of profiles/micro/fused_determinism.py.
+__global__ __launch_bounds__(64) void k_gridtend_physics_onewave(DevHoriz H, LevelTables L, const double *__restrict__ G, double *__restrict__ O,
+                                                                  smlphys::PhysLev PL, smlphys::PhysDev PD, smlphys::PhysIn PG, int lradsw, int want_diag)
+{
+    __shared__ double park[smlphys::PARK_DOUBLES];
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 64 + lane;
+        smlphys::Column c;
+        smlphys::column_load(PG, p, c);                  // issued with the loads of the dynamics below: one exposed round trip
+        const int j = p / IX;
+        smlphys::LA tt = smlphys::park_array(park, smlphys::P_TT, lane), qt = smlphys::park_array(park, smlphys::P_QT, lane);   // 1-based levels
+        double ug[KX], vg[KX], tg[KX], vorg[KX], divg[KX], trg[KX], puv[KX], sigdt[KXP], sigm[KXP];
+        const double cor = H.coriol[j];
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            vorg[k] = G[(size_t)(F_VOR + k) * GR + p] + cor;
+            divg[k] = G[(size_t)(F_DIV + k) * GR + p];
+            tg[k] = G[(size_t)(F_T + k) * GR + p];
+            trg[k] = G[(size_t)(F_TR + k) * GR + p];
+            ug[k] = G[(size_t)(32 + k) * GR + p];
+            vg[k] = G[(size_t)(40 + k) * GR + p];
+        }
+        double px = G[(size_t)48 * GR + p], py = G[(size_t)49 * GR + p];
+        double umean = 0.0, vmean = 0.0, dmean = 0.0;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            umean = umean + ug[k] * L.dhs[k];
+            vmean = vmean + vg[k] * L.dhs[k];
+            dmean = dmean + divg[k] * L.dhs[k];
+        }
+        O[(size_t)72 * GR + p] = -umean * px - vmean * py;
+        sigdt[0] = 0.0; sigm[0] = 0.0;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {          // the reference's loop runs to kx and so overwrites the zero it put at kxp
+            sigdt[k + 1] = sigdt[k] - L.dhs[k] * (puv[k] + divg[k] - dmean);
+            sigm[k + 1] = sigm[k] - L.dhs[k] * puv[k];
+        }
+        double tgg[KX];
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - L.tref[k];
+        px = RGAS * px;
+        py = RGAS * py;
+        double tmp[KXP];
+        tmp[0] = 0.0; tmp[KX] = 0.0;
+        // zonal wind
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX - 1; ++k) O[(size_t)k * GR + p] = vg[k] * vorg[k] - tgg[k] * px - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        const double u_dyn = vg[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * px - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
+        // meridional wind
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX - 1; ++k) O[(size_t)(8 + k) * GR + p] = -ug[k] * vorg[k] - tgg[k] * py - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        const double v_dyn = -ug[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * py - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
+        // temperature
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (L.tref[k] - L.tref[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX; ++k)
+            tt[k + 1] = tgg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k] + L.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k])
+                                           + L.tref3[k] * (sigm[k + 1] + sigm[k]) + L.akap * (tg[k] * puv[k] - tgg[k] * dmean);
+        // tracer (specific humidity): no vertical advection across the two uppermost interfaces (:196-203)
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
+        tmp[1] = 0.; tmp[2] = 0.;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) qt[k + 1] = trg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        // flux products (:241-246, :262-267)
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            O[(size_t)(48 + k) * GR + p] = 0.5 * (ug[k] * ug[k] + vg[k] * vg[k]);
+            O[(size_t)(16 + k) * GR + p] = -ug[k] * tgg[k];
+            O[(size_t)(24 + k) * GR + p] = -vg[k] * tgg[k];
+            O[(size_t)(32 + k) * GR + p] = -ug[k] * trg[k];
+            O[(size_t)(40 + k) * GR + p] = -vg[k] * trg[k];
+        }
+            smlphys::column_thermo(PL, c);
+        int iptop, icnv;
+        double precnv, precls;
+        smlphys::chain_moist(PL, PD, c, p, want_diag, park, lane, iptop, icnv, precnv, precls);
+        double pt[smlphys::NLP], pq[smlphys::NLP];
+        smlphys::vdifsc(PL, c, icnv, pt, pq);
+        {   // the radiation chain, by the same wavefront (its own copy of the column, as wave 1 has it)
+            smlphys::Column c2;
+            smlphys::RadIn r;
+            smlphys::column_load(PG, p, c2);
+            smlphys::radiation_load(PD, p, lradsw, park, lane, r);
+            smlphys::column_thermo(PL, c2);
+            smlphys::chain_radiation(PL, PD, c2, r, p, lradsw, want_diag, park, lane, lradsw ? precnv : 0., lradsw ? precls : 0., lradsw ? iptop : 0);
+        }
+        smlphys::chain_pbl_and_store(PL, c, p, icnv, park, lane, O, 0, 8, 56, 64, u_dyn, v_dyn, pt, pq);
+}
+
 // iogrid(30)'s physical-range guard (src/ppo_iogrid.f90:563-577: |u| <= 150, |v| <= 120, 160 <= T <= 330, -6 <= q <= 30 on the
 // grid fields obtained from the truncated spectral state) evaluated on the inverse set of the window's FIRST time step, which holds
 // exactly those fields (T, q, u, v of time level 1): the hand-off then needs no 33-field inverse set of its own.  NaN trips it.
@@ -1190,6 +1293,10 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
     if (d->phys && g_physics_fused) {      // dyn_grtend.f90:80-225 in one launch: grid-point tendencies + phypar
         const double *pg = d->batch_grid + (size_t)NB_SPEC * GR;
         smlphys::PhysIn in{pg, pg + (size_t)GR, pg + (size_t)2 * GR, pg + (size_t)10 * GR, pg + (size_t)18 * GR, pg + (size_t)26 * GR};
+        if (g_physics_fused == 2)
+            hipLaunchKernelGGL(k_gridtend_physics_onewave, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
+                               d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag);
+        else
         hipLaunchKernelGGL(k_gridtend_physics, dim3(GR / 64), dim3(128), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
                            d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag);
     } else {
@@ -1539,7 +1646,7 @@ int sml_dyn_set_lradsw(sml_dyn *d, int lradsw)
 
 int sml_dyn_select_physics_form(int fused)
 {
-    g_physics_fused = fused ? 1 : 0;
+    g_physics_fused = fused == 2 ? 2 : fused ? 1 : 0;      // 2: the one-wavefront fused form (experiment / regression subject)
     return SML_OK;
 }
 

@@ -201,9 +201,10 @@ def device_window(st, phis, surf, nsteps):
     return out, dyn, ph
 
 
-def test_fused_two_wave_step_equals_two_launch_form():
-    """k_gridtend_physics (wave 0: dynamics + moist + diffusion chain, wave 1: radiation + surface chain) against k_gridtend followed
-    by the one-wave k_physics: identical bits after stepone + 7 steps (short-wave and non-short-wave steps), and repeatable."""
+def test_fused_forms_agree_bit_for_bit():
+    """The three forms of grtend's grid-point part + phypar -- two launches (k_gridtend, k_physics), one two-wavefront launch (the
+    default) and one one-wavefront launch -- leave identical bits after stepone + 7 steps (short-wave and other steps), and each
+    fused form repeats itself.  The one-wavefront form is the shape that was non-repeatable at -O3 in round 1."""
     from make_physics_golden import coupled_inputs
     from speedy_ml_amd.dynamics import Dynamics
     _, st, phis, surf = coupled_inputs(seed=4)
@@ -211,6 +212,10 @@ def test_fused_two_wave_step_equals_two_launch_form():
         Dynamics.select_physics_form(False)
         two, _, ph_two = device_window(st, phis, surf, 7)
         diag_two = {k: ph_two.diag(k).copy() for k in ("olr", "precnv", "iptop", "ssrd", "shf")}
+        Dynamics.select_physics_form(2)
+        single, _, ph_single = device_window(st, phis, surf, 7)
+        single_again, _, _ = device_window(st, phis, surf, 7)
+        diag_single = {k: ph_single.diag(k).copy() for k in diag_two}
         Dynamics.select_physics_form(True)
         one, _, ph_one = device_window(st, phis, surf, 7)
         again, _, _ = device_window(st, phis, surf, 7)
@@ -220,8 +225,11 @@ def test_fused_two_wave_step_equals_two_launch_form():
         assert np.all(np.isfinite(one[k]))
         assert np.array_equal(one[k], two[k]), k
         assert np.array_equal(one[k], again[k]), k
+        assert np.array_equal(single[k], two[k]), k
+        assert np.array_equal(single[k], single_again[k]), k
     for k, v in diag_two.items():
         assert np.array_equal(ph_one.diag(k), v), k
+        assert np.array_equal(diag_single[k], v), k
 
 
 def test_window_with_physics_matches_reference_fixture():
