@@ -66,11 +66,13 @@ def main():
     out["fit_5892"]["backward_error"] = float(resid.norm() / b.norm())
     # eight ridge solves in flight (one size class): amortised time per reservoir
     cs = [c.clone() for _ in range(8)]
+    train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out)          # (grows the workspace to 8 systems)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out)
+    for _ in range(2):
+        train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out)
     torch.cuda.synchronize()
-    dt8 = time.perf_counter() - t0
+    dt8 = (time.perf_counter() - t0) / 2
     out["fit_5892_batched8"] = {"ms_total": dt8 * 1e3, "ms_per_system": dt8 * 1e3 / 8, "tflops": 8 * flops / dt8 / 1e12}
     print(json.dumps(out))
 

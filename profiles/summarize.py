@@ -18,7 +18,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12     # 10 timed + 2 warm-up
 
 
 def short(name):
-    for key in ("k_readout", "k_update", "k_gridtend_physics", "k_physics", "k_gridtend", "k_spectral", "k_grid", "k_spec", "k_uvvds", "k_gather", "k_scatter", "k_gemm_nt_dma", "k_gemm_acc"):
+    for key in ("k_readout", "k_update", "k_gridtend_physics", "k_physics", "k_gridtend", "k_spectral", "k_grid", "k_spec", "k_uvvds", "k_gather", "k_scatter", "k_gemm_nt_big", "k_gemm_big_reduce", "k_gemm_nt_dma", "k_gemm_acc"):
         if key in name:
             return key
     return None

@@ -89,6 +89,10 @@ def lib():
         getattr(L, name).restype = C.c_void_p
         getattr(L, name).argtypes = [C.c_void_p]
     _lib = L
+    # The ridge solver keeps streams (one of them CU-masked) and scratch between calls; give them back while the HIP runtime is
+    # still up (rocprofv3 crashes at process exit when a CU-masked stream is still alive: seen with --kernel-trace on ROCm 7.2).
+    import atexit
+    atexit.register(L.sml_train_release_workspace)
     return L
 
 

@@ -47,3 +47,8 @@ def fit_chunk_hybrid_batched(cs, bs, n, n_model, n_out, beta_res=0.001, beta_mod
     check(_lib.lib().sml_train_fit_batched(count, tc, tb, n, n_model, n_out, C.c_double(beta_res), C.c_double(beta_model),
                                            C.c_double(prior_val), int(using_prior), tw, vp(stream)))
     return wouts
+
+
+def release_workspace():
+    """Free the ridge solver's device scratch and streams (sml_train_release_workspace); the next fit allocates them again."""
+    check(_lib.lib().sml_train_release_workspace())
