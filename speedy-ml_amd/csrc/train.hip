@@ -10,10 +10,18 @@
 //                accumulator's lane index runs along i, the contiguous direction of the column-major C: every
 //                16-lane group stores 128 contiguous bytes.  For the symmetric update only tiles on or below the
 //                diagonal are computed; sml_train_fit mirrors them once before factorising.
-//   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on [A | B] so that the forward
-//                substitution of the right-hand sides rides along: panel (one workgroup, pivot search by
-//                workgroup reduction) -> row interchanges outside the panel -> U12 = L11^-1 A12 -> trailing update
-//                with k_gemm_acc (alpha = -1) ; then a blocked back substitution.
+//   k_gemm_nt_dma : the same product with operands row-contiguous in k (the Gram updates, the LU's trailing updates): operand
+//                tiles go global -> LDS by LDS-DMA, four ring slots, three K-tiles ahead.
+//   k_gemm_nt_big : the long Gram updates (m >= 512): 256x128 tile, one workgroup per CU, all products of an update in one
+//                balanced work list (see the kernel: 76 % of the fp64 MFMA spec).
+//   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on the row-major system [A^T+reg | B^T+prior], so
+//                that the forward substitution of the right-hand sides rides along.  128-column panels, factored recursively:
+//                8-column register-resident leaves (k_lu_leaf: one barrier per pivot) and k_lu_panel_update for the rest of
+//                the panel; one composite row permutation per panel (k_lu_perm_src, k_lu_swap_gather); U12 by k_lu_trsm_scatter;
+//                trailing update with k_gemm_nt_dma (alpha = -1), the next panel's strip first (look-ahead on two streams, the
+//                trailing stream CU-masked so that the leaf always finds a free CU); blocked back substitution
+//                (k_lu_trsm_upper, k_lu_backsub_update).  Up to FIT_BATCH systems advance in lockstep through one chain of
+//                launches (grid dimension z).
 // All matrices are column-major fp64, as in the reference.
 #include <cstdlib>
 #include <vector>
