@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=120, help="timed hybrid steps (120 = the 30 days of BASELINE config 3)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="hybrid", choices=["hybrid", "sweep", "ml_only"],
                     help="sweep = reservoir predict sweep only; ml_only = the reference's ML-only forecast loop (predict_ml + exchange, no "
                          "SPEEDY); development aids, the driver uses the default")

@@ -358,3 +358,43 @@ def test_ml_only_step_stage_parity(oracle):
                 u[sz.sst_start - 1:sz.sst_end] = (o.tile_input2d(NREG, s, Ggs, in2d) - mean[35]) / std[35]
             u[sz.tisr_start - 1:sz.tisr_end] = (o.tile_input2d(NREG, s, Ggt, in2d) - mean[33]) / std[33]
             assert np.array_equal(fb1[s, :b.d], u), (step, s)
+
+
+def test_full_size_bank_first_step_sampled_against_oracle():
+    """BASELINE config 3 at full size: all 1152 reservoirs with N_res ~ 6000 in one bank (the bench's bank), one hybrid step.
+    Sampled slots of every size class (poles, interior sea and land, the wrap-around columns, first and last region) against the
+    oracle's predict at full size: new reservoir state, un-standardised outvec, and that region's footprint in the scattered
+    hybrid state G."""
+    from _oracle import Oracle
+    o = Oracle()
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    m = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=None, pipeline=False, physics=True)
+    torch.cuda.synchronize()
+    seen, sample = set(), [0, NREG - 1]
+    for r in range(NREG):                               # one region per (n, d) class, plus a region at each end of a latitude row
+        b = m.bank.host_copies[r][0]
+        if (b.n, b.d) not in seen:
+            seen.add((b.n, b.d))
+            sample.append(r)
+    sample += [47, 48, 95, 576, 577, 1103]
+    sample = sorted(set(sample))
+    assert len(seen) >= 3
+    fb0 = m.feedback.cpu().numpy().copy()
+    lm0 = m.local_model.cpu().numpy().copy()
+    x0 = {s: m.bank.get_state(s) for s in sample}
+    m.step(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert int(m.safe.item()) == 1
+    for s in sample:
+        b, mean, std, stat = m.bank.host_copies[s]
+        assert b.n >= 5760
+        win = np.zeros((b.n, b.d), order="F")
+        win[np.arange(b.n), b.win_cols - 1] = b.win_vals
+        xw, out = o.predict_raw(b.n, b.d, b.n_model, b.n_out, b.rows, b.cols, b.vals, win, b.wout, 1.0,
+                                fb0[s, :b.d].copy(), lm0[s, :b.n_model].copy(), x0[s])
+        g = o.initializedomain(NREG, s)
+        out = o.unstandardize_res(g, mean, std, out)
+        assert np.max(np.abs(m.bank.get_state(s) - xw)) <= 1e-13, s
+        got = m.bank.get_outvec(s)[:b.n_out]
+        assert np.max(np.abs(got - out) / np.maximum(np.abs(out), 1.0)) <= 1e-11, s
