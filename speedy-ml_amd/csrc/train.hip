@@ -17,10 +17,10 @@
 //   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on the row-major system [A^T+reg | B^T+prior], so
 //                that the forward substitution of the right-hand sides rides along.  128-column panels, factored recursively:
 //                8-column register-resident leaves (k_lu_leaf: one barrier per pivot) and k_lu_panel_update for the rest of
-//                the panel; one composite row permutation per panel (k_lu_perm_src, k_lu_swap_gather); U12 by k_lu_trsm_scatter;
+//                the panel; one composite row permutation per panel (k_lu_perm_src, k_lu_swap_gather); U12 by k_lu_trsm_rl<true>;
 //                trailing update with k_gemm_nt_dma (alpha = -1), the next panel's strip first (look-ahead on two streams, the
 //                trailing stream CU-masked so that the leaf always finds a free CU); blocked back substitution
-//                (k_lu_trsm_upper, k_lu_backsub_update).  Up to FIT_BATCH systems advance in lockstep through one chain of
+//                (k_lu_trsm_rl<false>, k_lu_backsub_update).  Up to FIT_BATCH systems advance in lockstep through one chain of
 //                launches (grid dimension z).
 // All matrices are column-major fp64, as in the reference.
 #include <cstdlib>
@@ -526,7 +526,7 @@ __global__ void k_symmetrize_diag(double *__restrict__ c, int n)
 //             k_lu_panel_update : rank-8 update of the panel's remaining columns, all CUs ]
 //   G: k_lu_panel_finish (U11 -> W, the composite permutation of the panel's 128 interchanges), k_lu_swap_gather (the <= 256
 //      affected rows of W's right-hand columns gathered into a scratch through that permutation: no dependent chain of 128 swaps),
-//      k_lu_trsm_scatter (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
+//      k_lu_trsm_rl<true> (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
 //      K = 128: FIRST the next panel's 128 columns (+ k_lu_strip_to_panel, which hands them to P), THEN the rest, which runs
 //      beside the next panel's leaf chain (look-ahead).
 // The previous form (32-wide panel in one workgroup that walked the panel through memory for every sub-panel, one dependent
@@ -946,150 +946,132 @@ __global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict
     tmp[(long)idx * ld + j] = w[(long)src[idx] * ld + j];
 }
 
-// U12 = L11^-1 A12 for 64 columns per workgroup of four wavefronts, A12 read from the gathered rows; the displaced rows (positions
-// 128.. whose row lies below the panel's top block) are written back to W on the way.  Rows in blocks of 8; within a block
-// wavefront w owns rows 2w, 2w+1: the rectangular part (every earlier x once, through LDS) runs on all four SIMDs, the 8 x 8
-// triangle is repeated by every wavefront.  The block's rows of L are staged in LDS; their loads are issued two blocks ahead and
-// parked in registers, so no global load sits in the dependent chain.  Per entry the subtractions run over ascending k (fused
-// multiply-adds).
-constexpr int TR_T = 256;
-__global__ __launch_bounds__(TR_T) void k_lu_trsm_scatter(const double *__restrict__ P, long np, double *__restrict__ w, long ld, int K0, int nbp, int c0,
-                                                           int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls)
+// The two triangular solves of a 128-row block, right-looking over blocks of 8 rows, for 64 columns per workgroup (lane = column):
+//   LOWER: X = L11^-1 A (unit lower; A = the gathered rows tmp; X -> rows K0.. of W; the displaced rows go back to W on the way)
+//   UPPER: X = U11^-1 Y (division by the diagonal; Y, X = rows K0.. of the right-hand-side columns of W)
+// Eight wavefronts; wavefront w keeps row 8 b + w of every block b in registers (16 values per lane).  Per block: the 8 rows go
+// through LDS (one barrier, double-buffered), EVERY wavefront solves the 8 x 8 triangle for itself (no second exchange), stores
+// its own row and applies the block's 8 solutions to the rows it still holds.  The triangle (all of L11 or U11, 128 KB) sits in
+// LDS row-major, so a row's 8 coefficients of a block are two 32-byte broadcast reads.  Per entry the multiply-subtracts are fused
+// and run over ascending k (LOWER) / descending k (UPPER) -- block by block and within a block -- exactly as in the left-looking
+// kernels of the first version (37 / 46 us per launch: two barriers and a dependent LDS round trip per 8 rows, every earlier
+// solution re-read by every row; a displaced row's load behind a branch each), so the bits are the same.  Now 31 / 34 us: bound by
+// the LDS itself -- a broadcast read still returns 512 bytes, and a workgroup makes 12 700 of them (8 128 coefficients once, the
+// 8 x 8 triangles by all eight wavefronts).  Coefficients through scalar loads from global memory instead: 90 us (every batch of
+// eight waits for a scalar-cache round trip).
+constexpr int TRL_T = 512, TRL_LD = LU_NBO + 1;               // (row stride 129: the column-major L lands in LDS rows without 64-way bank conflicts)
+constexpr size_t TRL_LDS = sizeof(double) * ((size_t)LU_NBO * TRL_LD + 2 * 8 * 64);
+template <bool LOWER>
+__global__ __launch_bounds__(TRL_T) void k_lu_trsm_rl(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
+                                                       int nbp, int c0, int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls,
+                                                       long tri_stride)
 {
-    P += ls.p * blockIdx.y; w += ls.w * blockIdx.y; ipiv += ls.ipiv * blockIdx.y; tmp += ls.tmp * blockIdx.y;
-    __shared__ double xs[LU_NBO][64];
-    __shared__ double Lt[2][8][LU_NBO];
-    __shared__ double sx[8][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) double trl_lds[];
+    double *T = trl_lds;                                      // T[i * TRL_LD + k] = L(i,k) / U(i,k) of the block (zero outside the triangle's extent)
+    double(*sx)[8][64] = reinterpret_cast<double(*)[8][64]>(trl_lds + (size_t)LU_NBO * TRL_LD);
+    tri += tri_stride * blockIdx.y; w += ls.w * blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = c0 + blockIdx.x * 64 + lane;
     const bool ok = j < ncols;
-    for (int i = wv; i < nbp; i += 4) {
-        const int p = ipiv[K0 + i];
-        if (p >= K0 + nbp && ok) w[(long)p * ld + j] = tmp[(long)(LU_NBO + i) * ld + j];
+    if (LOWER) {
+        ipiv += ls.ipiv * blockIdx.y; tmp += ls.tmp * blockIdx.y;
+        // (all pivots and all displaced rows loaded before the first store: a branch around each load costs a memory round trip
+        // per row, 16 in a row)
+        int pv[LU_NBO / 8];
+        double dv[LU_NBO / 8];
+#pragma unroll
+        for (int q = 0; q < LU_NBO / 8; ++q) pv[q] = 8 * q + wv < nbp ? ipiv[K0 + 8 * q + wv] : -1;
+#pragma unroll
+        for (int q = 0; q < LU_NBO / 8; ++q) dv[q] = ok ? tmp[(long)(LU_NBO + 8 * q + wv) * ld + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < LU_NBO / 8; ++q)
+            if (pv[q] >= K0 + nbp && ok) w[(long)pv[q] * ld + j] = dv[q];
     }
-    const double *L = P + K0;                                 // L(i,k) = L[k*np + i], i,k relative to the panel's top block
-    // element e = threadIdx.x + 256 m of block ib: k = e >> 3, r = e & 7 -> L(ib + r, k), k < ib + 8 (8 consecutive rows contiguous)
-    double pre[4];
-    auto stage_load = [&](int ib) {
+    // stage the triangle: element (i, k) at tri[i * tri_ld_i + k * tri_ld_k]; the contiguous direction runs along the threads;
+    // eight loads in flight per thread
+    for (int e0 = threadIdx.x; e0 < LU_NBO * LU_NBO; e0 += TRL_T * 8) {
+        double v[8];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int e = threadIdx.x + TR_T * m, k = e >> 3, r = e & 7;
-            pre[m] = (ib < nbp && k < ib + 8 && ib + r < nbp && k < nbp) ? L[(long)k * np + ib + r] : 0.0;
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + TRL_T * u;
+            int i, k;
+            if (LOWER) { i = e & (LU_NBO - 1); k = e >> 7; }  // L is column-major in the panel buffer: i contiguous
+            else { k = e & (LU_NBO - 1); i = e >> 7; }        // U is row-major in W: k contiguous
+            const bool in = i < nbp && k < nbp && (LOWER ? k < i : k >= i);
+            v[u] = in ? tri[(long)i * tri_ld_i + (long)k * tri_ld_k] : 0.0;
         }
-    };
-    auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int e = threadIdx.x + TR_T * m, k = e >> 3, r = e & 7;
-            Lt[buf][r][k] = pre[m];
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + TRL_T * u;
+            const int i = LOWER ? (e & (LU_NBO - 1)) : (e >> 7), k = LOWER ? (e >> 7) : (e & (LU_NBO - 1));
+            T[i * TRL_LD + k] = v[u];
         }
-    };
-    stage_load(0);
-    stage_store(0);
-    stage_load(8);
-    const int r0 = 2 * wv, r1 = r0 + 1;
-    double s0 = (ok && r0 < nbp) ? tmp[(long)r0 * ld + j] : 0.0, s1 = (ok && r1 < nbp) ? tmp[(long)r1 * ld + j] : 0.0;
-    for (int ib = 0, b = 0; ib < nbp; ib += 8, b ^= 1) {
-        __syncthreads();                                      // Lt[b] staged; the previous block's x are in xs
-        stage_store(b ^ 1);                                   // block ib + 8 (loaded one iteration ago)
-        stage_load(ib + 16);
-        const double s0n = (ok && ib + 8 + r0 < nbp) ? tmp[(long)(ib + 8 + r0) * ld + j] : 0.0;
-        const double s1n = (ok && ib + 8 + r1 < nbp) ? tmp[(long)(ib + 8 + r1) * ld + j] : 0.0;
-        const double *l0 = Lt[b][r0], *l1 = Lt[b][r1];
-#pragma unroll 8
-        for (int k = 0; k < ib; ++k) {
-            const double xk = xs[k][lane];
-            s0 = __builtin_fma(-l0[k], xk, s0);
-            s1 = __builtin_fma(-l1[k], xk, s1);
-        }
-        sx[r0][lane] = s0;
-        sx[r1][lane] = s1;
-        __syncthreads();
-        double x[8];
+    }
+    // this wavefront's rows: block b -> row 8 b + wv
+    double a[LU_NBO / 8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            double v = sx[r][lane];
+    for (int b = 0; b < LU_NBO / 8; ++b) {
+        const int i = 8 * b + wv;
+        a[b] = (ok && i < nbp) ? (LOWER ? tmp[(long)i * ld + j] : w[(long)(K0 + i) * ld + j]) : 0.0;
+    }
+    __syncthreads();
+    const int nblk = (nbp + 7) / 8;
+    // fully unrolled over the 16 blocks: a[] is indexed at compile time and each block updates exactly the rows that remain
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < r) v = __builtin_fma(-Lt[b][r][ib + k], x[k], v);
-            x[r] = v;
-            if (r == r0 || r == r1) {                         // uniform per wavefront
-                xs[ib + r][lane] = v;
-                if (ok && ib + r < nbp) w[(long)(K0 + ib + r) * ld + j] = v;
+    for (int t = 0; t < LU_NBO / 8; ++t) {
+        const int b = LOWER ? t : LU_NBO / 8 - 1 - t, ib = 8 * b;
+        if (b < nblk) {                                       // (uniform; a short last block of the matrix has fewer)
+            sx[t & 1][wv][lane] = a[b];
+            __syncthreads();
+            double x[8];
+            const double *tb = T + ib * TRL_LD + ib;          // the block's 8 x 8 triangle
+            if (LOWER) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    double v = sx[t & 1][r][lane];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < r) v = __builtin_fma(-tb[r * TRL_LD + k], x[k], v);
+                    x[r] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 7; r >= 0; --r) {
+                    double v = sx[t & 1][r][lane];
+#pragma unroll
+                    for (int k = 7; k >= 0; --k)
+                        if (k > r) v = __builtin_fma(-tb[r * TRL_LD + k], x[k], v);
+                    const double dg = tb[r * TRL_LD + r];
+                    v = ib + r < nbp ? v / dg : 0.0;          // (rows past a short last block are padding)
+                    x[r] = v;
+                }
+            }
+            {   // this wavefront's row of the block is final
+                double xm = 0.0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) xm = r == wv ? x[r] : xm;
+                if (ok && ib + wv < nbp) w[(long)(K0 + ib + wv) * ld + j] = xm;
+            }
+            // the block's 8 solutions applied to the rows this wavefront still holds
+#pragma unroll
+            for (int q = 0; q < LU_NBO / 8; ++q) {
+                if (LOWER ? q > b : q < b) {
+                    const double *row = T + (8 * q + wv) * TRL_LD + ib;
+                    double cf[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cf[k] = row[k];
+                    double v = a[q];
+                    if (LOWER) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v = __builtin_fma(-cf[k], x[k], v);
+                    } else {
+#pragma unroll
+                        for (int k = 7; k >= 0; --k) v = __builtin_fma(-cf[k], x[k], v);
+                    }
+                    a[q] = v;
+                }
             }
         }
-        s0 = s0n;
-        s1 = s1n;
-    }
-}
-
-// back substitution block: X_kb = U_kk^-1 Y_kb for 64 right-hand side columns per workgroup, the same four-wavefront scheme
-// bottom-up.  U is row-major in W (a read-only region here: columns < n_aug), so a block's rows are staged along k.  Per entry
-// the subtractions run over descending k and the diagonal is divided by, as dtrsm('L','U','N','N') does.
-__global__ __launch_bounds__(TR_T) void k_lu_trsm_upper(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls)
-{
-    y += ls.w * blockIdx.y; U += ls.w * blockIdx.y;
-    __shared__ double xs[LU_NBO][64];
-    __shared__ double Ut[2][8][LU_NBO];
-    __shared__ double sx[8][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
-    const bool ok = j < nrhs;
-    // element e = threadIdx.x + 256 m of block ib: r = e >> 7, k = e & 127 -> U(ib + r, k), k >= ib (identity rows past nb)
-    double pre[4];
-    auto stage_load = [&](int ib) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int e = threadIdx.x + TR_T * m, r = e >> 7, k = e & (LU_NBO - 1);
-            pre[m] = (ib >= 0 && k >= ib && ib + r < nb && k < nb) ? U[(long)(ib + r) * ld + k] : (k == ib + r ? 1.0 : 0.0);
-        }
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int e = threadIdx.x + TR_T * m, r = e >> 7, k = e & (LU_NBO - 1);
-            Ut[buf][r][k] = pre[m];
-        }
-    };
-    const int ib_last = ((nb - 1) / 8) * 8;
-    stage_load(ib_last);
-    stage_store(0);
-    stage_load(ib_last - 8);
-    const int r0 = 2 * wv, r1 = r0 + 1;
-    double s0 = (ok && ib_last + r0 < nb) ? y[(long)(K0 + ib_last + r0) * ld + j] : 0.0;
-    double s1 = (ok && ib_last + r1 < nb) ? y[(long)(K0 + ib_last + r1) * ld + j] : 0.0;
-    for (int ib = ib_last, b = 0; ib >= 0; ib -= 8, b ^= 1) {
-        __syncthreads();
-        stage_store(b ^ 1);
-        stage_load(ib - 16);
-        const double s0n = (ok && ib >= 8) ? y[(long)(K0 + ib - 8 + r0) * ld + j] : 0.0;
-        const double s1n = (ok && ib >= 8) ? y[(long)(K0 + ib - 8 + r1) * ld + j] : 0.0;
-        const double *u0 = Ut[b][r0], *u1 = Ut[b][r1];
-#pragma unroll 8
-        for (int k = nb - 1; k >= ib + 8; --k) {
-            const double xk = xs[k][lane];
-            s0 = __builtin_fma(-u0[k], xk, s0);
-            s1 = __builtin_fma(-u1[k], xk, s1);
-        }
-        sx[r0][lane] = s0;
-        sx[r1][lane] = s1;
-        __syncthreads();
-        double x[8];
-#pragma unroll
-        for (int r = 7; r >= 0; --r) {
-            double v = sx[r][lane];
-#pragma unroll
-            for (int k = 7; k >= 0; --k)
-                if (k > r) v = __builtin_fma(-Ut[b][r][ib + k], x[k], v);
-            v = v / Ut[b][r][ib + r];
-            x[r] = v;
-            if (r == r0 || r == r1) {
-                if (ib + r < nb) xs[ib + r][lane] = v;
-                if (ok && ib + r < nb) y[(long)(K0 + ib + r) * ld + j] = v;
-            }
-        }
-        s0 = s0n;
-        s1 = s1n;
     }
 }
 
@@ -1368,8 +1350,9 @@ static int gemm_big_accumulate(const double *states, const double *model, const 
         double cyc = 0, ticks = 0, wv = 0, wb = 0;
         const int cnt = std::min(plan.nwg, 512);
         for (int i = 0; i < cnt; ++i) { cyc += (double)h[4 * i]; ticks += (double)h[4 * i + 1]; wv += (double)h[4 * i + 2]; wb += (double)h[4 * i + 3]; }
-        fprintf(stderr, "[gemm_big] full-K items: %.0f shader cycles, %.1f us each (%.3f GHz); %.2f cycles per MFMA; per K-tile: %.0f cycles at the scalar point (incl. ~40 for the stamp itself)%.0s\n",
-                cyc / cnt, ticks / cnt / 100.0, cyc / ticks * 0.1, cyc / cnt / ((double)(K / DKT) * 256), wv / cnt / (K / DKT), wb / cnt / (K / DKT));
+        fprintf(stderr, "[gemm_big] full-K items: %.0f shader cycles, %.1f us each (%.3f GHz); %.2f cycles per MFMA; per K-tile: %.0f cycles at the scalar point (incl. ~40 for the stamp itself)\n",
+                cyc / cnt, ticks / cnt / 100.0, cyc / ticks * 0.1, cyc / cnt / ((double)(K / DKT) * 256), wv / cnt / (K / DKT));
+        (void)wb;
     }
     if (plan.ntails) {
         hipLaunchKernelGGL(k_gemm_big_reduce, dim3(GB_I * GB_J / 256, plan.ntails), dim3(256), 0, st, ops, 1.0, (const BigItem *)plan.d_tails,
@@ -1569,6 +1552,12 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     const long ld = lu_pad16(ncols), np = lu_pad16(n_aug);
     const LuStride ls = S.ls;
     int rc;
+    static bool trl_attr = false;
+    if (!trl_attr) {
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_rl<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRL_LDS));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_rl<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRL_LDS));
+        trl_attr = true;
+    }
     for (int i = 0; i < nb; ++i)
         if ((rc = sml_train_symmetrize(c[first + i], n_aug, (void *)S.sg))) return rc;
     SML_HIP(hipMemsetAsync(S.info, 0, sizeof(int) * nb, S.sg));
@@ -1605,7 +1594,9 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         const int c0 = K0 + nbp;
         hipLaunchKernelGGL(k_lu_perm_src, dim3(nb), dim3(256), 0, S.sg, K0, nbp, S.ipiv, S.src, ls);
         hipLaunchKernelGGL(k_lu_swap_gather, dim3((ncols - c0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, S.sg, S.w, ld, c0, ncols, nbp, S.src, S.tmp, ls);
-        hipLaunchKernelGGL(k_lu_trsm_scatter, dim3((ncols - c0 + 63) / 64, nb), dim3(TR_T), 0, S.sg, Pk, np, S.w, ld, K0, nbp, c0, ncols, S.ipiv, S.tmp, ls);
+        // L(i,k) = Pk[K0 + i + k * np]
+        hipLaunchKernelGGL(k_lu_trsm_rl<true>, dim3((ncols - c0 + 63) / 64, nb), dim3(TRL_T), TRL_LDS, S.sg, Pk + K0, np, 1L, S.w, ld, K0, nbp, c0, ncols,
+                               S.ipiv, S.tmp, ls, ls.p);
         SML_HIP(hipGetLastError());
         if (c0 < n_aug) {
             const int nbn = std::min(LU_NBO, n_aug - c0);
@@ -1628,7 +1619,9 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     }
     for (int K0 = ((n_aug - 1) / LU_NBO) * LU_NBO; K0 >= 0; K0 -= LU_NBO) {
         const int nbk = std::min(LU_NBO, n_aug - K0);
-        hipLaunchKernelGGL(k_lu_trsm_upper, dim3((n_out + 63) / 64, nb), dim3(TR_T), 0, S.sg, S.w + n_aug, S.w + (long)K0 * ld + K0, ld, K0, nbk, n_out, ls);
+        // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns n_aug .. n_aug + n_out of W
+        hipLaunchKernelGGL(k_lu_trsm_rl<false>, dim3((n_out + 63) / 64, nb), dim3(TRL_T), TRL_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0, nbk,
+                               n_aug, n_aug + n_out, (const int *)nullptr, (const double *)nullptr, ls, ls.w);
         if (K0 > 0)
             hipLaunchKernelGGL(k_lu_backsub_update, dim3((K0 + BS_ROWS - 1) / BS_ROWS, nb), dim3(256), bs_lds, S.sg, S.w + n_aug, S.w, ld, K0, nbk, n_out, ls);
         SML_HIP(hipGetLastError());
