@@ -1200,7 +1200,7 @@ extern "C" {
 // = 624 tiles = 2 rounds + 112 tiles in 2 pieces each.
 constexpr int GB_SUPER_I = 4, GB_SUPER_J = 8;
 struct BigPlan {
-    int n = 0, n_model = 0, n_out = 0, k = 0, ncu = 0;
+    int n = 0, n_model = 0, n_out = 0, k = 0, ncu = 0, dev = -1;
     int nitems = 0, ntails = 0, nwg = 0;
     BigItem *d_items = nullptr, *d_tails = nullptr;
     int *d_wg_first = nullptr;
@@ -1321,8 +1321,22 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static int gemm_big_accumulate(const double *states, const double *model, const double *y, int n, int n_model, int n_out, int K, double *c, double *b,
                                hipStream_t st)
 {
-    static BigPlan plan;                          // (one shape at a time: training runs one size class after another)
+    // A few plans are kept (shape + K + device): a training pass alternates between its full flushes and a ragged last one, and a
+    // plan change costs a device synchronisation.  The least recently used one is rebuilt when a fifth shape turns up.
+    static BigPlan plans[4];
+    static unsigned long stamp[4] = {0, 0, 0, 0}, tick = 0;
+    int dev = 0;
+    SML_HIP(hipGetDevice(&dev));
+    int slot = -1, lru = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (plans[i].d_items && plans[i].dev == dev && plans[i].n == n && plans[i].n_model == n_model && plans[i].n_out == n_out && plans[i].k == K) slot = i;
+        if (stamp[i] < stamp[lru]) lru = i;
+    }
+    if (slot < 0) slot = lru;
+    stamp[slot] = ++tick;
+    BigPlan &plan = plans[slot];
     int rc;
+    if (plan.dev != dev) { plan.ncu = 0; plan.n = 0; plan.dev = dev; }
     if ((rc = gemm_big_plan(plan, n, n_model, n_out, K))) return rc;
     BigOperands ops{};
     ops.src[0] = states; ops.ld[0] = n;
