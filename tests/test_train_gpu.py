@@ -128,6 +128,39 @@ def test_full_size_gram_against_torch_fp64(m):
     assert float((b - bref).abs().max()) <= 1e-12 * float(bref.abs().max())
 
 
+@pytest.mark.parametrize("n,n_model,n_out,m", [
+    (256, 0, 8, 512),        # the smallest shape the 256 x 128 kernel takes: one SYRK row tile, no model block
+    (640, 132, 136, 520),    # n mod 256 = 128: a short first row tile; m mod 8 = 0
+    (700, 132, 136, 1029),   # n not a multiple of 128; 5 left-over columns of m go through the general kernel
+    (1500, 4, 2, 776),       # tiny skinny blocks, ragged everything
+    (254, 2, 2, 600),        # n < 256: stays on the 128 x 128 kernel
+])
+def test_long_gram_shapes_and_determinism(n, n_model, n_out, m):
+    """The one-launch Gram update (256 x 128 tiles, all products in one work list, K-split tail) on ragged shapes against torch
+    fp64, accumulating twice into the same C and B; a second run from zero must give the same bits (the tail is reduced in a fixed
+    order and every output element is owned by one work item)."""
+    torch.manual_seed(n + m)
+    n_aug = n + n_model
+    states = torch.randn((m, n), dtype=torch.float64, device="cuda")
+    model = torch.randn((m, max(n_model, 1)), dtype=torch.float64, device="cuda")[:, :n_model].contiguous()
+    y = torch.randn((m, n_out), dtype=torch.float64, device="cuda")
+    runs = []
+    for _ in range(2):
+        c = train.fortran_zeros(n_aug, n_aug)
+        b = train.fortran_zeros(n_out, n_aug)
+        train.chunking_matmul(states, model if n_model else None, y, c, b)
+        train.chunking_matmul(states, model if n_model else None, y, c, b)
+        train.symmetrize(c)
+        runs.append((c.clone(), b.clone()))
+    aug = torch.cat([model, states], dim=1) if n_model else states
+    cref = 2.0 * (aug.T @ aug)
+    bref = 2.0 * (aug.T @ y)
+    c, b = runs[0]
+    assert float((c - cref).abs().max()) <= 1e-12 * float(cref.abs().max())
+    assert float((b - bref).abs().max()) <= 1e-12 * float(bref.abs().max())
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
 def test_device_training_pass_matches_oracle(oracle):
     """K7 on the device (reservoir recurrence + batch flushes into the MFMA Gram update) for two reservoirs of different
     size in one bank, against the oracle's restatement of reservoir_layer_chunking_hybrid."""
