@@ -159,6 +159,7 @@ class HybridRank:
         self.timestep_hours = 6
         self.t = 0
         self._safe_ring, self._safe_ev, self._safe_n, self._aborted = None, None, 0, False
+        self.stop_on_unsafe = True            # (False only for load emulation: a rank's share of the regions without its peers' outvecs)
         self._phase_on, self._phase_log = False, []
         if mode == "ml_only":
             # the reference's ml_only run (src/parallelmain.f90:229-231, src/mpires.f90:566,588): predict_ml, the same exchange,
@@ -426,7 +427,7 @@ class HybridRank:
             self.ex.gather(self.G, None, stream=stream)          # feedback only: there is no forecast to tile
             return
         if not self.pipeline:
-            if self.aborted():                                           # run_speedy == .false. ends the forecast loop
+            if self.stop_on_unsafe and self.aborted():                   # run_speedy == .false. ends the forecast loop
                 return False                                             # (src/mpires.f90:744, src/parallelmain.f90:269-271)
             ph = self._phase_events(stream) if self._phase_on else None
             self.bank.predict(stream=stream)
