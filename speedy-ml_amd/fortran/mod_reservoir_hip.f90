@@ -1,3 +1,8 @@
+! The PER-CALL binding of round 1 (one reservoir per bank, x and outvec on the host): a minimal patch for a tree that keeps the
+! reference's own mod_reservoir and only swaps the bodies below.  The drop-in with the reference's module names, argument lists
+! and derived types -- what program main compiles against unchanged -- is mod_reservoir.f90 / mpires.f90 / resdomain.f90 /
+! mod_utilities.f90 / mod_slab_ocean_reservoir.f90 in this directory (INTEGRATION.md section 2b).
+!
 ! Drop-in bodies for the prediction hot path of the reference's mod_reservoir / mod_linalg, forwarding to the
 ! MI355X library.  Same subroutine names and argument meaning as the reference:
 !     mklsparse(reservoir)                      src/mod_linalg.f90:10-25     (build the device-resident operator)
