@@ -725,10 +725,13 @@ __device__ __forceinline__ void radiation_load(const PhysDev &D, int p, int lrad
             for (int b = 1; b <= 4; ++b) r.tau2[k][b] = D.tau2[((size_t)(b - 1) * KX + (k - 1)) * GR + p];
             tt_rsw[k] = D.tt_rsw[(size_t)(k - 1) * GR + p];
         }
-        r.stratc[1] = D.stratc[p];
-        r.stratc[2] = D.stratc[GR + p];
-        r.ssrd = D.ssrd[p];
     }
+    // (unconditionally -- a short-wave step overwrites them: stored only in the else branch, the compiler turned the three stores
+    // into stores at a selected address and the struct went to scratch, 40 B per lane with five waited-for scratch loads)
+    r.stratc[0] = 0.;
+    r.stratc[1] = D.stratc[p];
+    r.stratc[2] = D.stratc[GR + p];
+    r.ssrd = D.ssrd[p];
 }
 
 // phypar 2 (:102-118): convection and large-scale condensation; ttend = ttend + tt_cnv + tt_lsc (same for q)
