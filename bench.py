@@ -218,11 +218,15 @@ def training_block(with_cpu):
                                "batched8": {"ms_per_system": dt8 * 1e3 / 8, "tflops": 8 * flops_lu / dt8 / 1e12,
                                             "frac": 8 * flops_lu / dt8 / 1e12 / PEAK}}
     del cs
-    # the training pass (reservoir_layer_chunking_hybrid, :1067-1175) of 8 resident full-size reservoirs: 4 batches of the shipped size
-    nres, batch, discard = 8, 98, 40
-    T = discard + 4 * batch
+    # the training pass (reservoir_layer_chunking_hybrid, :1067-1175) of resident full-size reservoirs: one pass of the shipped
+    # configuration = 20 batches of 98 columns (traininglength 12000 h / 6 passes / timestep 6)
+    # 32 resident reservoirs: the recurrence's one launch per time column is a fixed cost shared by the residents (per reservoir and
+    # batch 0.22 / 0.15 / 0.12 / 0.10 ms at 8 / 16 / 32 / 64, profiles/micro/train_pass_time.py; training.py trains in groups of 64)
+    nres, batch, discard = 32, 98, 40
+    nbatch = 20
+    T = discard + nbatch * batch
     bank = ReservoirBank(nres)
-    rs = [make_reservoir(n=n, d=d, n_model=n_model, n_out=n_out, seed=20240954 + i) for i in range(nres)]
+    rs = [make_reservoir(n=n, d=d, n_model=n_model, n_out=n_out, seed=20240954 + i) for i in range(4)] * (nres // 4)   # (values do not matter for the timing)
     for i, r in enumerate(rs):
         bank.load(i, r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, r.mean, r.std, None)
     noisy = torch.randn((T, nres, 576), dtype=torch.float64, device=dev) * 0.5
@@ -232,7 +236,7 @@ def training_block(with_cpu):
     bs8 = [train.fortran_zeros(n_out, n_aug) for _ in range(nres)]
     bank.train_pass(noisy, discard, batch, models, targs, cs8, bs8)
     dtp = timed(lambda: bank.train_pass(noisy, discard, batch, models, targs, cs8, bs8), 2)
-    per_batch = dtp / (4 * nres)
+    per_batch = dtp / (nbatch * nres)
     shipped_batches = 120                                                              # traininglength 12000 h, timestep 6, 20 batches per pass
     per_res = shipped_batches * per_batch + dt8 / 8
     out["train_pass"] = {"ms_per_reservoir_batch": per_batch * 1e3, "resident_reservoirs": nres, "batch_size": batch,

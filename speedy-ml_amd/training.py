@@ -109,7 +109,7 @@ def train_reservoirs(bank, specs, traininglength, discardlength, timestep, beta_
     return out
 
 
-def shard_plan(rank, world, number_of_regions, group=8):
+def shard_plan(rank, world, number_of_regions, group=64):
     """The regions rank `rank` of `world` trains, in bank-sized groups: processor_decomposition (src/res_domain.f90:31-62) exactly as
     program main's training loop uses it (src/parallelmain.f90:82-128), cut into groups of `group` reservoirs that are resident
     (and factorised) together.  Training has no collective: the ranks' region sets are disjoint and cover all regions."""
@@ -117,7 +117,7 @@ def shard_plan(rank, world, number_of_regions, group=8):
     return [regions[i:i + group] for i in range(0, len(regions), group)]
 
 
-def train_sharded(rank, world, number_of_regions, build, traininglength, discardlength, timestep, group=8, out_dir=None, trial="trial",
+def train_sharded(rank, world, number_of_regions, build, traininglength, discardlength, timestep, group=64, out_dir=None, trial="trial",
                   **ridge):
     """program main's training loop for one rank (src/parallelmain.f90:82-128): every region of shard_plan(rank, world, ...) is built
     (`build(region)` -> dict with n, d, n_model, n_out, rows, cols, vals, win, mean, std, out_stat and the train_reservoirs spec keys
