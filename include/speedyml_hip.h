@@ -497,7 +497,7 @@ int sml_gen_res(int n, int k, double radius, uint64_t seed, int32_t *rows, int32
  * =================================================================================================== */
 /* C(n_aug,n_aug) += aug*aug^T and B(n_out,n_aug) += Y*aug^T with aug = [model ; states], fp64 MFMA.
  * All device, column-major as in the reference: states (n,m), model (n_model,m), y (n_out,m).
- * Long products (m >= 512, even n / n_model / n_out, 16-byte aligned arrays) run as ONE launch of 256 x 128 tiles over all five
+ * Long products (m >= 256, even n / n_model / n_out, 16-byte aligned arrays) run as ONE launch of 256 x 128 tiles over all five
  * products; its workgroups add into C and B with device-memory fp64 atomics, so c_dev and b_dev must be ordinary (coarse-grained)
  * hipMalloc allocations -- as every buffer of this library is -- not host-pinned or managed memory. */
 int sml_train_accumulate(const double *states_dev, const double *model_dev, const double *y_dev,

@@ -12,7 +12,7 @@
 //                diagonal are computed; sml_train_fit mirrors them once before factorising.
 //   k_gemm_nt_dma : the same product with operands row-contiguous in k (the Gram updates, the LU's trailing updates): operand
 //                tiles go global -> LDS by LDS-DMA, four ring slots, three K-tiles ahead.
-//   k_gemm_nt_big : the long Gram updates (m >= 512): 256x128 tile, one workgroup per CU, all products of an update in one
+//   k_gemm_nt_big : the long Gram updates (m >= 256): 256x128 tile, one workgroup per CU, all products of an update in one
 //                balanced work list (see the kernel: 76 % of the fp64 MFMA spec).
 //   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on the row-major system [A^T+reg | B^T+prior], so
 //                that the forward substitution of the right-hand sides rides along.  128-column panels, factored recursively:
@@ -1386,8 +1386,11 @@ int sml_train_accumulate(const double *states, const double *model, const double
     int rc;
     // Long products: all of them as one launch of the 256 x 128 kernel over the part of m that is a multiple of 8 (the rest of m,
     // at most 7 columns, through the general path below).  Needs even row counts and 16-byte aligned columns for the LDS-DMA.
+    // From m = 256 on: at m = 392 (a four-batch flush of the training pass) 0.41 against 0.43 ms for the general path, at 784 the
+    // same 0.64; shorter products are bound by the traffic of C either way and keep the reference's one-batch granularity.
     static const int big_on = getenv("SML_GEMM_BIG") ? atoi(getenv("SML_GEMM_BIG")) : 1;
-    if (big_on && m >= 512 && !(n & 1) && !(n_model & 1) && !(n_out & 1) && n >= GB_I && aligned16(states) && aligned16(y) && (!n_model || aligned16(model))) {
+    static const int big_min_m = getenv("SML_GEMM_BIG_MIN_M") ? atoi(getenv("SML_GEMM_BIG_MIN_M")) : 256;
+    if (big_on && m >= big_min_m && !(n & 1) && !(n_model & 1) && !(n_out & 1) && n >= GB_I && aligned16(states) && aligned16(y) && (!n_model || aligned16(model))) {
         const int kb = (m / DKT) * DKT;
         if ((rc = gemm_big_accumulate(states, model, y, n, n_model, n_out, kb, c, b, st))) return rc;
         if (kb == m) return SML_OK;
