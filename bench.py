@@ -213,11 +213,16 @@ def training_block(with_cpu):
     cs = [c.clone() for _ in range(8)]
     train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out)                     # grows the workspace to 8 systems
     dt8 = timed(lambda: train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out), 2)
+    cs16 = cs + [c.clone() for _ in range(8)]
+    train.fit_chunk_hybrid_batched(cs16, [b] * 16, n, n_model, n_out)
+    dt16 = timed(lambda: train.fit_chunk_hybrid_batched(cs16, [b] * 16, n, n_model, n_out), 2)
     out["ridge_solve_5892"] = {"ms": dt1 * 1e3, "tflops": flops_lu / dt1 / 1e12, "frac": flops_lu / dt1 / 1e12 / PEAK,
                                "normwise_backward_error": berr,
                                "batched8": {"ms_per_system": dt8 * 1e3 / 8, "tflops": 8 * flops_lu / dt8 / 1e12,
-                                            "frac": 8 * flops_lu / dt8 / 1e12 / PEAK}}
-    del cs
+                                            "frac": 8 * flops_lu / dt8 / 1e12 / PEAK},
+                               "batched16": {"ms_per_system": dt16 * 1e3 / 16, "tflops": 16 * flops_lu / dt16 / 1e12,
+                                             "frac": 16 * flops_lu / dt16 / 1e12 / PEAK}}
+    del cs, cs16
     # the training pass (reservoir_layer_chunking_hybrid, :1067-1175) of resident full-size reservoirs: one pass of the shipped
     # configuration = 20 batches of 98 columns (traininglength 12000 h / 6 passes / timestep 6)
     # 32 resident reservoirs: the recurrence's one launch per time column is a fixed cost shared by the residents (per reservoir and
@@ -238,10 +243,10 @@ def training_block(with_cpu):
     dtp = timed(lambda: bank.train_pass(noisy, discard, batch, models, targs, cs8, bs8), 2)
     per_batch = dtp / (nbatch * nres)
     shipped_batches = 120                                                              # traininglength 12000 h, timestep 6, 20 batches per pass
-    per_res = shipped_batches * per_batch + dt8 / 8
+    per_res = shipped_batches * per_batch + dt16 / 16
     out["train_pass"] = {"ms_per_reservoir_batch": per_batch * 1e3, "resident_reservoirs": nres, "batch_size": batch,
                          "reservoirs_per_s_shipped_config": 1.0 / per_res,
-                         "note": "shipped config: 120 batches of m = 98 per reservoir (12000 h, 6 interleaved passes) + one ridge solve (batched 8)"}
+                         "note": "shipped config: 120 batches of m = 98 per reservoir (12000 h, 6 interleaved passes) + one ridge solve (16 systems in lockstep)"}
     bank.close()
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

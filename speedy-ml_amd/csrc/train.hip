@@ -1655,7 +1655,7 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
 // singular (sml_last_error names the first).
 // The scratch of a batch (per system: the row-major system, two panel buffers, the gathered rows: ~310 MB at n_aug = 5892) and its
 // streams are kept between calls: allocating them took 12 ms of a 43 ms call.  sml_train_release_workspace frees them.
-constexpr int FIT_BATCH = 8;
+constexpr int FIT_BATCH = 16;            // (8 / 16 / 32 systems in lockstep: 7.3 / 6.3 / 6.5 ms per 5892-row system, profiles/micro/fit_batch_sizes.py)
 static LuSys g_lu;
 static int g_lu_n = 0, g_lu_cols = 0;
 
@@ -1673,7 +1673,8 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
     for (int i = 0; i < count; ++i) SML_REQUIRE(c[i] && b[i] && wout[i], "sml_train_fit_batched: null system %d", i);
     hipStream_t st = sml::as_stream(stream);
     const int n_aug = n + n_model, ncols = n_aug + n_out;
-    const int nbmax = std::min(count, FIT_BATCH);
+    static const int fit_batch = getenv("SML_FIT_BATCH") ? std::max(1, atoi(getenv("SML_FIT_BATCH"))) : FIT_BATCH;
+    const int nbmax = std::min(count, fit_batch);
     int rc = SML_OK;
     if (g_lu_n != n_aug || g_lu_cols != ncols || g_lu.nbatch < nbmax) {
         sml_train_release_workspace();
