@@ -267,7 +267,7 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict_
 // Measured, one Gram update of the shipped shape (n = 5760, 132 model rows, 136 targets, m = 2920; profiles/gram_only.py):
 // 1.81 ms = 59.9 TF/s of executed flops (lower-triangle 128-blocks + skinny blocks) = 76 % of the 78.6 TF/s fp64 MFMA spec, against
 // 2.50 ms = 43.3 TF/s for k_gemm_nt_dma + side streams; 16.6 cycles per MFMA inside the K loop (16.0 = the instruction's length;
-// SML_GEMM_STAMPS=1), matrix pipe busy 87.7 % of the launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r2_gram_pmc.json; the rest is the
+// SML_GEMM_STAMPS=1), matrix pipe busy 88 % of the launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r2_gram_pmc.json; the rest is the
 // K loop's 4 %, prologue / epilogue of 624 tiles and the last round).  History of this kernel, same update: DMA issue and LDS
 // reads as blocks in front of the MFMAs 2.7 ms; reads and DMAs threaded through the MFMAs 2.22; all products in one list 1.98; no
 // vector ALU work in the loop and one scalar point per K-tile 1.84; the six DMAs in separate groups 1.80; tail dealt out by K-tiles
