@@ -42,6 +42,7 @@ struct sml_bank {
     bool descs_dirty = true;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_readout;
+    std::vector<std::pair<double *, size_t>> train_states;     // per slot: the training pass's states buffer, kept between passes
 };
 
 namespace sml {

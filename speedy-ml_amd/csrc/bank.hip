@@ -758,6 +758,8 @@ int sml_bank_destroy(sml_bank *b)
     for (auto &r : b->res) free_slot(r);
     (void)hipFree(b->d_descs); (void)hipFree(b->d_feedback); (void)hipFree(b->d_local_model); (void)hipFree(b->d_outvec); (void)hipFree(b->d_partial);
     if (b->d_counter) (void)hipFree(b->d_counter);
+    for (auto &t : b->train_states)
+        if (t.first) (void)hipFree(t.first);
     delete b;
     return SML_OK;
 }
@@ -994,22 +996,27 @@ int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int 
     int group = forced_group > 0 ? forced_group : std::max(1, std::min(16, 2048 / batch));
     while (group > 1 && per_batch_bytes * group > ((size_t)16 << 30)) --group;
     std::vector<TrainSlot> ts(b->capacity, TrainSlot{nullptr, 0});
-    std::vector<double *> owned;
     int nmax = 0;
+    // (the states buffers stay with the bank between passes: a pass per 20 batches would otherwise allocate and free
+    // 72 MB per resident reservoir every time)
+    b->train_states.resize(b->capacity, std::make_pair((double *)nullptr, (size_t)0));
     for (int s = 0; s < b->capacity; ++s) {
         const ResDesc &D = b->res[s].desc;
         if (!D.loaded || !c_dev[s] || !b_dev[s] || !targets_dev[s]) continue;
-        double *p = nullptr;
-        if (hipMalloc((void **)&p, (size_t)D.n * batch * group * sizeof(double)) != hipSuccess) {
-            for (double *q : owned) (void)hipFree(q);
-            return sml::fail(SML_ERR_HIP, "sml_bank_train_pass: out of device memory for the states buffers");
+        const size_t need = (size_t)D.n * batch * group * sizeof(double);
+        auto &buf = b->train_states[s];
+        if (buf.second < need) {
+            if (buf.first) (void)hipFree(buf.first);
+            buf = std::make_pair((double *)nullptr, (size_t)0);
+            if (hipMalloc((void **)&buf.first, need) != hipSuccess)
+                return sml::fail(SML_ERR_HIP, "sml_bank_train_pass: out of device memory for the states buffers");
+            buf.second = need;
         }
-        owned.push_back(p);
-        ts[s] = TrainSlot{p, D.n};
+        ts[s] = TrainSlot{buf.first, D.n};
         nmax = std::max(nmax, D.n);
     }
     TrainSlot *d_ts = nullptr;
-    auto cleanup = [&]() { for (double *q : owned) (void)hipFree(q); if (d_ts) (void)hipFree(d_ts); };
+    auto cleanup = [&]() { if (d_ts) (void)hipFree(d_ts); };
     if ((rc = sml::dev_upload(&d_ts, ts.data(), ts.size()))) { cleanup(); return rc; }
     const dim3 sgrid((nmax + 255) / 256, b->capacity);
     const size_t step = (size_t)b->capacity * b->max_d;
