@@ -226,7 +226,7 @@ def training_block(with_cpu):
     # the training pass (reservoir_layer_chunking_hybrid, :1067-1175) of resident full-size reservoirs: one pass of the shipped
     # configuration = 20 batches of 98 columns (traininglength 12000 h / 6 passes / timestep 6)
     # 32 resident reservoirs: the recurrence's one launch per time column is a fixed cost shared by the residents (per reservoir and
-    # batch 0.22 / 0.15 / 0.12 / 0.10 ms at 8 / 16 / 32 / 64, profiles/micro/train_pass_time.py; training.py trains in groups of 64)
+    # batch 0.18 / 0.13 / 0.10 / 0.09 ms at 8 / 16 / 32 / 64, profiles/micro/train_pass_time.py; training.py trains in groups of 64)
     nres, batch, discard = 32, 98, 40
     nbatch = 20
     T = discard + nbatch * batch
