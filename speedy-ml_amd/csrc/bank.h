@@ -32,6 +32,7 @@ struct HostRes {
 
 struct sml_bank {
     int capacity = 0, max_d = 0, max_n_model = 0, max_n_out = 0;
+    int ncu = 0;                    // compute units of the device this bank lives on (launch shapes follow it)
     int cur = 0;
     int max_nd = 0;                 // LDS doubles needed by k_update
     int max_n_out_loaded = 1;       // largest n_out among loaded slots (sizes the readout grid)

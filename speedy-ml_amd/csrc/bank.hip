@@ -543,14 +543,12 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     // everywhere 0.132 (its second round is half empty), 3..8 parts 0.164..0.265, 1024 x 1 0.164, 256 x 4 0.18.
     static const int cfg = getenv("SML_UPD_CFG") ? atoi(getenv("SML_UPD_CFG")) : -1;
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
-    static int slots = 0;
-    if (!slots) {
-        hipDeviceProp_t prop;
+    if (!b->ncu) {
         int dev = 0;
         SML_HIP(hipGetDevice(&dev));
-        SML_HIP(hipGetDeviceProperties(&prop, dev));
-        slots = 3 * prop.multiProcessorCount;
+        SML_HIP(hipDeviceGetAttribute(&b->ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
+    const int slots = 3 * b->ncu;
     int threads = 512, parts = 2, whole = 0;
     if (cfg == 1) { threads = 1024; parts = 1; }
     else if (cfg == 2) { threads = 256; parts = 4; }
@@ -565,7 +563,7 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     const int nblocks = whole + (nres8 - whole) * parts;
     const size_t lds = (size_t)b->max_nd * sizeof(double);
     SML_REQUIRE(lds <= 160 * 1024, "reservoir too large for the LDS-staged update (n+d=%d)", b->max_nd);
-    static bool attr_set = false;
+    static bool attr_set = false;                            // (one process drives one GPU: the attribute is set once per process)
     if (!attr_set) {
         SML_HIP(hipFuncSetAttribute((const void *)k_update<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SML_HIP(hipFuncSetAttribute((const void *)k_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -606,14 +604,12 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
     if (flags & (8 | 16)) {
         // persistent work-queue variants (sml_bank_readout_part): bit 3 = bounded footprint, resets the queue;
         // bit 4 = full-occupancy drain of the same queue (no reset)
-        static int ncu = 0;
-        if (!ncu) {
-            hipDeviceProp_t prop;
+        if (!b->ncu) {
             int dev = 0;
             SML_HIP(hipGetDevice(&dev));
-            SML_HIP(hipGetDeviceProperties(&prop, dev));
-            ncu = prop.multiProcessorCount;
+            SML_HIP(hipDeviceGetAttribute(&b->ncu, hipDeviceAttributeMultiprocessorCount, dev));
         }
+        const int ncu = b->ncu;
         if (!b->d_counter) { SML_HIP(hipMalloc((void **)&b->d_counter, 256)); SML_HIP(hipMemset(b->d_counter, 0xff, 256)); }
         const int parts = (b->max_n_out_loaded + 17 - 1) / 17;
         const unsigned total = (unsigned)(nres8 * parts);
