@@ -116,6 +116,7 @@ program test_main_loop
       deallocate(g, f, gidx, stat, want)
     end do
   end do
+  call slab_check(nfail)
   if (nfail == 0) then
     print *, 'main loop parity OK'
   else
@@ -124,6 +125,51 @@ program test_main_loop
   end if
 
 contains
+
+  ! ---- check (4): mod_slab_ocean_reservoir's predict_slab_ml (src/mod_slab_ocean_reservoir.f90:1318-1363) on a small ML-only ocean
+  ! reservoir against the same step written out on the host: x <- tanh(A x + W_in u), even entries squared, W_out x~, every output
+  ! un-standardised with the SST statistics ----
+  subroutine slab_check(nfail)
+    use mod_utilities, only : reservoir_type, grid_type
+    use mod_slab_ocean_reservoir, only : load_slab_reservoir, predict_slab_ml
+    integer, intent(inout) :: nfail
+    type(reservoir_type) :: r
+    type(grid_type) :: g
+    integer, parameter :: n = 256, d = 16, no = 8, kk = 1536
+    real(kind=dp), allocatable :: x(:), y(:), xa(:), want(:), u(:)
+    real(kind=dp) :: rnd(kk)
+    integer :: e
+    r%n = n; r%reservoir_numinputs = d; r%k = kk; r%chunk_size_speedy = 0; r%chunk_size_prediction = no; r%leakage = 1.0_dp
+    r%hip_slot = 0
+    allocate(r%rows(kk), r%cols(kk), r%vals(kk), r%win(n, d), r%wout(no, n), r%feedback(d), r%outvec(no), x(n), u(kk))
+    call random_number(rnd); r%rows = 1 + int(rnd * n); r%rows = min(r%rows, n)
+    call random_number(rnd); r%cols = 1 + int(rnd * n); r%cols = min(r%cols, n)
+    call random_number(r%vals); r%vals = (r%vals - 0.5_dp) * 0.3_dp
+    call random_number(r%win); r%win = (r%win - 0.5_dp) * 0.6_dp
+    call random_number(r%wout); r%wout = (r%wout - 0.5_dp) * 0.1_dp
+    call random_number(r%feedback); r%feedback = r%feedback - 0.5_dp
+    call random_number(x); x = (x - 0.5_dp) * 0.4_dp
+    allocate(g%mean(36), g%std(36))
+    call random_number(g%mean); call random_number(g%std); g%std = 0.5_dp + g%std
+    g%sst_mean_std_idx = 36
+    ! the host's own step
+    allocate(y(n), xa(n), want(no))
+    y = 0.0_dp
+    do e = 1, kk
+      y(r%rows(e)) = y(r%rows(e)) + r%vals(e) * x(r%cols(e))
+    end do
+    y = tanh(y + matmul(r%win, r%feedback))
+    xa = y
+    xa(2:n:2) = xa(2:n:2) ** 2
+    want = matmul(r%wout, xa) * g%std(36) + g%mean(36)
+    call load_slab_reservoir(r, g, 1, .false.)
+    call predict_slab_ml(r, res%model_parameters, g, x)
+    if (maxval(abs(x - y)) > 1.0e-13_dp .or. maxval(abs(r%outvec - want)) > 1.0e-11_dp * maxval(abs(want))) then
+      print *, 'FAIL (4): predict_slab_ml', maxval(abs(x - y)), maxval(abs(r%outvec - want)); nfail = nfail + 1
+    else
+      print *, 'slab predict_slab_ml: state', maxval(abs(x - y)), ' outvec', maxval(abs(r%outvec - want)) / maxval(abs(want))
+    end if
+  end subroutine
 
   subroutine fetch_inputs(slot, fb, lm)
     integer(c_int), intent(in) :: slot

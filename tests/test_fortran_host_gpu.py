@@ -27,7 +27,7 @@ def test_fortran_module_api_runs_program_mains_loop():
     names and argument lists, speedy-ml_amd/fortran/*.f90) driven by the prediction part of the reference's program main
     (src/parallelmain.f90:140-272) for two time steps with all 1152 regions on one rank: fortran/test_main_loop.f90 checks the batched
     predict behind the per-region predict calls against a per-region predict, the next feedback against the host-side tiling of the
-    global state, and run_speedy.  (About two minutes: the synthetic stand-ins of the ERA5 readers generate 2304 region-windows.)"""
+    global state, run_speedy, and mod_slab_ocean_reservoir's predict_slab_ml against the same step written out in Fortran on the host.  (About two minutes: the synthetic stand-ins of the ERA5 readers generate 2304 region-windows.)"""
     exe = os.path.join(FDIR, "test_main_loop")
     if not os.path.exists(exe):
         assert shutil.which("amdflang") or os.path.exists("/opt/rocm/bin/amdflang"), "no prebuilt driver and no amdflang"
