@@ -318,7 +318,8 @@ __device__ __forceinline__ void gb_read_unit(unsigned ra, unsigned rb, int j, Bi
     else { const int u = 2 * (j - 4); f.b[u] = br[4 * u]; f.b[u + 1] = br[4 * u + 4]; }
 }
 
-// the six DMAs of one K-tile at once (the prologue only: in the loop they go one per MFMA group)
+// the six DMAs of one K-tile at once (the prologue only: in the loop they go one per MFMA group).  M0 is a register the compiler
+// reserves and sets itself before each of its own uses (none in this kernel's loop), so writing it here needs no clobber.
 #define GB_DMA6                                                                                                              \
     "s_mov_b32 m0, %[m0]\n s_nop 0\n"                                                                                         \
     "global_load_lds_dwordx4 %[v0], %[sa] offset:%[i0]\n global_load_lds_dwordx4 %[v1], %[sa] offset:%[i1]\n"               \
@@ -358,17 +359,18 @@ __global__ __launch_bounds__(GB_T, 1) void k_gemm_nt_big(BigOperands ops, double
         asm volatile("" : "+v"(vq[q]));
     }
     const long step_a = (long)DKT * lda * 8, step_b = (long)DKT * ldb * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)gb_lds;          // LDS byte address of the ring (0: the kernel's only LDS)
     unsigned m0v[GB_NBUF];
 #pragma unroll
-    for (int sl = 0; sl < GB_NBUF; ++sl) m0v[sl] = (unsigned)((sl * GB_SLOT + 2 * wave * GB_ROW) * 8 + GB_MID);
+    for (int sl = 0; sl < GB_NBUF; ++sl) m0v[sl] = lds0 + (unsigned)((sl * GB_SLOT + 2 * wave * GB_ROW) * 8 + GB_MID);
     // LDS read addresses (bytes) of the two k-steps of every ring slot
     unsigned ra[GB_NBUF][2], rb[GB_NBUF][2];
 #pragma unroll
     for (int sl = 0; sl < GB_NBUF; ++sl)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            ra[sl][h] = (unsigned)((sl * GB_SLOT + (4 * h + l4) * GB_ROW + wi + l15) * 8);
-            rb[sl][h] = (unsigned)((sl * GB_SLOT + (4 * h + l4) * GB_ROW + GB_LDA + wj + l3) * 8);
+            ra[sl][h] = lds0 + (unsigned)((sl * GB_SLOT + (4 * h + l4) * GB_ROW + wi + l15) * 8);
+            rb[sl][h] = lds0 + (unsigned)((sl * GB_SLOT + (4 * h + l4) * GB_ROW + GB_LDA + wj + l3) * 8);
             asm volatile("" : "+v"(ra[sl][h]), "+v"(rb[sl][h]));
         }
     double acc[8][16];
