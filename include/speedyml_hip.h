@@ -499,7 +499,8 @@ int sml_gen_res(int n, int k, double radius, uint64_t seed, int32_t *rows, int32
  * All device, column-major as in the reference: states (n,m), model (n_model,m), y (n_out,m).
  * Long products (m >= 256, even n / n_model / n_out, 16-byte aligned arrays) run as ONE launch of 256 x 128 tiles over all five
  * products; its workgroups add into C and B with device-memory fp64 atomics, so c_dev and b_dev must be ordinary (coarse-grained)
- * hipMalloc allocations -- as every buffer of this library is -- not host-pinned or managed memory. */
+ * hipMalloc allocations -- as every buffer of this library is -- not host-pinned or managed memory.  Calls share one scratch for the
+ * K-split tail, so concurrent calls must be on ONE stream (as the reference's single-threaded rank issues them). */
 int sml_train_accumulate(const double *states_dev, const double *model_dev, const double *y_dev,
                          int n, int n_model, int n_out, int m, double *c_dev, double *b_dev, void *stream);
 /* reservoir_layer_chunking_hybrid (src/mod_reservoir.f90:1067-1175) for EVERY loaded slot of a bank, one pass over T
