@@ -1556,10 +1556,10 @@ static int launch_leaf(LuSys &S, int nb, long np, int n, int K0, int c, int lw, 
 }
 
 // trailing update W[c0.., j0..j1) -= L21 U12 (row-major C: the contiguous column index j is the MFMA kernel's i)
-static int lu_trailing(LuSys &S, int nb, long ld, long np, int n_aug, int K0, int nbp, int j0, int j1, const double *Pk)
+static int lu_trailing(LuSys &S, int nb, long ld, long np, int n_aug, int K0, int nbp, int j0, int j1, const double *Pk, hipStream_t st)
 {
     const int c0 = K0 + nbp;
-    return gemm_nt(S.w + (long)K0 * ld + j0, ld, Pk + c0, np, S.w + (long)c0 * ld + j0, ld, j1 - j0, n_aug - c0, nbp, -1.0, 0, S.sg, lu_dma(), /*padded=*/true,
+    return gemm_nt(S.w + (long)K0 * ld + j0, ld, Pk + c0, np, S.w + (long)c0 * ld + j0, ld, j1 - j0, n_aug - c0, nbp, -1.0, 0, st, lu_dma(), /*padded=*/true,
                    nb, GemmBatch{S.ls.w, S.ls.p, S.ls.w});
 }
 
@@ -1590,15 +1590,20 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     hipLaunchKernelGGL(k_build_system, dim3((unsigned)((ld + 255) / 256), n_aug, nb), dim3(256), 0, S.sg, S.c_list, S.b_list, S.w, ld, n_aug, n_model, n_out,
                        reg_model, reg_res, prior_diag, ls);
     SML_HIP(hipGetLastError());
-    auto strip_to_panel = [&](int K0, int nbp, double *P) {
-        hipLaunchKernelGGL(k_lu_strip_to_panel, dim3((n_aug - K0 + 31) / 32, (nbp + 31) / 32, nb), dim3(256), 0, S.sg, S.w, ld, P, np, n_aug, K0, nbp, ls);
+    auto strip_to_panel = [&](int K0, int nbp, double *P, hipStream_t st) {
+        hipLaunchKernelGGL(k_lu_strip_to_panel, dim3((n_aug - K0 + 31) / 32, (nbp + 31) / 32, nb), dim3(256), 0, st, S.w, ld, P, np, n_aug, K0, nbp, ls);
     };
-    strip_to_panel(0, std::min(LU_NBO, n_aug), S.p[0]);
+    // Streams: everything the NEXT leaf waits for -- the panel's own chain, then the interchanges, U12 and the next panel's strip --
+    // is one in-order sequence on S.sp; only the rest of the trailing update goes to the CU-masked S.sg, behind an event.  (With
+    // the interchanges / U12 / strip on S.sg, as before, the chain crossed streams twice per panel, and a cross-stream dependency that
+    // is not yet satisfied when it is reached costs 13-15 us: 1.3 ms per solve.)  S.sp waits for S.sg only where the wait is long over:
+    // panel k+1's interchanges touch the columns panel k's trailing update wrote a leaf chain earlier.
+    strip_to_panel(0, std::min(LU_NBO, n_aug), S.p[0], S.sg);
     SML_HIP(hipEventRecord(S.ev_strip, S.sg));
+    SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));           // (once: build_system and the first strip are on S.sg)
     for (int K0 = 0, k = 0; K0 < n_aug; K0 += LU_NBO, ++k) {
         const int nbp = std::min(LU_NBO, n_aug - K0);
         double *Pk = S.p[k & 1];
-        SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));
         for (int cc = K0, lw = 0; cc < K0 + nbp; cc += lw) {
             lw = std::min(leaf_width(n_aug - cc), K0 + nbp - cc);
             if ((rc = launch_leaf(S, nb, np, n_aug, K0, cc, lw, nbp))) return rc;
@@ -1608,26 +1613,32 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
                                    nbp, ls);
         }
         SML_HIP(hipGetLastError());
-        SML_HIP(hipEventRecord(S.ev_panel, S.sp));
-        SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+        if (k > 0) SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));       // panel k-1's trailing update (and U11 copy) has finished
         const int c0 = K0 + nbp;
-        hipLaunchKernelGGL(k_lu_perm_src, dim3(nb), dim3(256), 0, S.sg, K0, nbp, S.ipiv, S.src, ls);
-        hipLaunchKernelGGL(k_lu_swap_gather, dim3((ncols - c0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, S.sg, S.w, ld, c0, ncols, nbp, S.src, S.tmp, ls);
+        hipLaunchKernelGGL(k_lu_perm_src, dim3(nb), dim3(256), 0, S.sp, K0, nbp, S.ipiv, S.src, ls);
+        hipLaunchKernelGGL(k_lu_swap_gather, dim3((ncols - c0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, S.sp, S.w, ld, c0, ncols, nbp, S.src, S.tmp, ls);
         // L(i,k) = Pk[K0 + i + k * np]
-        hipLaunchKernelGGL(k_lu_trsm_rl<true>, dim3((ncols - c0 + 63) / 64, nb), dim3(TRL_T), TRL_LDS, S.sg, Pk + K0, np, 1L, S.w, ld, K0, nbp, c0, ncols,
+        hipLaunchKernelGGL(k_lu_trsm_rl<true>, dim3((ncols - c0 + 63) / 64, nb), dim3(TRL_T), TRL_LDS, S.sp, Pk + K0, np, 1L, S.w, ld, K0, nbp, c0, ncols,
                                S.ipiv, S.tmp, ls, ls.p);
         SML_HIP(hipGetLastError());
+        // U12 of this panel is in W: the rest of the trailing update may start (beside the strip's product, which it slows from 33 to
+        // 50 us; started after the strip instead it overlaps that much more of the next leaf chain: 28.4 against 28.2 ms per solve)
+        SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+        SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
         if (c0 < n_aug) {
             const int nbn = std::min(LU_NBO, n_aug - c0);
-            if ((rc = lu_trailing(S, nb, ld, np, n_aug, K0, nbp, c0, c0 + nbn, Pk))) return rc;       // the next panel's columns first
-            strip_to_panel(c0, nbn, S.p[(k + 1) & 1]);
+            if ((rc = lu_trailing(S, nb, ld, np, n_aug, K0, nbp, c0, c0 + nbn, Pk, S.sp))) return rc;   // the next panel's columns, in the chain
+            strip_to_panel(c0, nbn, S.p[(k + 1) & 1], S.sp);
             SML_HIP(hipGetLastError());
-            SML_HIP(hipEventRecord(S.ev_strip, S.sg));
-            if ((rc = lu_trailing(S, nb, ld, np, n_aug, K0, nbp, c0 + nbn, ncols, Pk))) return rc;    // the rest runs beside the next leaf chain
+            if ((rc = lu_trailing(S, nb, ld, np, n_aug, K0, nbp, c0 + nbn, ncols, Pk, S.sg))) return rc;  // the rest beside the next leaf chain
         }
         hipLaunchKernelGGL(k_lu_u11_to_w, dim3((nbp + 31) / 32, (nbp + 31) / 32, nb), dim3(256), 0, S.sg, Pk, np, S.w, ld, K0, nbp, ls);
         SML_HIP(hipGetLastError());
+        SML_HIP(hipEventRecord(S.ev_strip, S.sg));                          // (reused: "S.sg is done with panel k")
     }
+    // the back substitution runs on S.sg: behind everything S.sp did
+    SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+    SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
     // back substitution on the right-hand sides (columns n_aug .. ncols of W)
     SML_REQUIRE(n_out <= BS_CG * 8, "sml_train_fit: n_out = %d exceeds the %d right-hand sides of the back substitution kernel", n_out, BS_CG * 8);
     const size_t bs_lds = (size_t)(LU_NBO * BS_CG * 8 + BS_ROWS * LU_NBO) * sizeof(double);
