@@ -1452,6 +1452,7 @@ struct LuSys {                 // scratch and streams of one batch of factorisat
     double **wout_list = nullptr;
     hipStream_t sp = nullptr, sg = nullptr;
     hipEvent_t ev_panel = nullptr, ev_strip = nullptr;
+    bool confined = false;         // the panel stream has the reserved CUs to itself (single solves: see lu_sys_alloc)
     LuStride ls{};
 };
 
@@ -1495,14 +1496,25 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
     // (all of its registers), and behind an unmasked GEMM grid it waited for one to drain (measured: 250 us instead of 30).
     {
         static const int reserve_env = getenv("SML_LU_RESERVE") ? atoi(getenv("SML_LU_RESERVE")) : -1;
-        const int reserve = reserve_env >= 0 ? reserve_env : std::max(16, 2 * nbatch);
+        static const int confine_env = getenv("SML_LU_CONFINE") ? atoi(getenv("SML_LU_CONFINE")) : 1;
+        static const int layout_env = getenv("SML_LU_MASK_LAYOUT") ? atoi(getenv("SML_LU_MASK_LAYOUT")) : 0;
+        // A single solve: the panel stream is confined to the reserved CUs and does only what fits there (leaves, panel updates and
+        // the NEXT panel's 128 columns); what it writes it reads back from the same L2s instead of through a memory system the
+        // trailing update keeps busy.  Batches keep the unconfined panel stream: their strip work is nbatch times larger.
+        s.confined = confine_env && nbatch == 1;
+        const int reserve = reserve_env >= 0 ? reserve_env : s.confined ? 32 : std::max(16, 2 * nbatch);
         int dev = 0, ncu = 0;
         SML_HIP(hipGetDevice(&dev));
         SML_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         if (reserve > 0 && reserve < ncu) {
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+            auto reserved = [&](int cu) { return layout_env == 0 ? cu < reserve : (cu % 8 == 0 && cu / 8 < reserve); };
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u), pm((ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu; ++i) (reserved(i) ? pm : mask)[i / 32] |= 1u << (i % 32);
             SML_HIP(hipExtStreamCreateWithCUMask(&s.sg, (uint32_t)mask.size(), mask.data()));
+            if (s.confined) {
+                (void)hipStreamDestroy(s.sp);
+                SML_HIP(hipExtStreamCreateWithCUMask(&s.sp, (uint32_t)pm.size(), pm.data()));
+            }
         } else
             SML_HIP(hipStreamCreateWithFlags(&s.sg, hipStreamNonBlocking));
     }
@@ -1616,15 +1628,28 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         if (k > 0) SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));       // panel k-1's trailing update (and U11 copy) has finished
         const int c0 = K0 + nbp;
         hipLaunchKernelGGL(k_lu_perm_src, dim3(nb), dim3(256), 0, S.sp, K0, nbp, S.ipiv, S.src, ls);
-        hipLaunchKernelGGL(k_lu_swap_gather, dim3((ncols - c0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, S.sp, S.w, ld, c0, ncols, nbp, S.src, S.tmp, ls);
-        // L(i,k) = Pk[K0 + i + k * np]
-        hipLaunchKernelGGL(k_lu_trsm_rl<true>, dim3((ncols - c0 + 63) / 64, nb), dim3(TRL_T), TRL_LDS, S.sp, Pk + K0, np, 1L, S.w, ld, K0, nbp, c0, ncols,
-                               S.ipiv, S.tmp, ls, ls.p);
+        // interchanges and U12 (L(i,k) = Pk[K0 + i + k * np]): in the chain for the columns of the next panel only when the panel stream
+        // is confined (cs .. ce), for all columns otherwise; the other columns follow on S.sg
+        const int ce = (S.confined && c0 < n_aug) ? c0 + std::min(LU_NBO, n_aug - c0) : ncols;    // (exactly the columns lu_trailing updates on S.sp)
+        auto gather_and_u12 = [&](int j0, int j1, hipStream_t st) {
+            if (j1 <= j0) return;
+            hipLaunchKernelGGL(k_lu_swap_gather, dim3((j1 - j0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, st, S.w, ld, j0, j1, nbp, S.src, S.tmp, ls);
+            hipLaunchKernelGGL(k_lu_trsm_rl<true>, dim3((j1 - j0 + 63) / 64, nb), dim3(TRL_T), TRL_LDS, st, Pk + K0, np, 1L, S.w, ld, K0, nbp, j0, j1, S.ipiv,
+                               S.tmp, ls, ls.p);
+        };
+        if (S.confined) {                                                    // S.sg needs the permutation; it is long done with panel k-1
+            SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+            SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+            gather_and_u12(ce, ncols, S.sg);
+        }
+        gather_and_u12(c0, ce, S.sp);
         SML_HIP(hipGetLastError());
         // U12 of this panel is in W: the rest of the trailing update may start (beside the strip's product, which it slows from 33 to
         // 50 us; started after the strip instead it overlaps that much more of the next leaf chain: 28.4 against 28.2 ms per solve)
-        SML_HIP(hipEventRecord(S.ev_panel, S.sp));
-        SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+        if (!S.confined) {
+            SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+            SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+        }
         if (c0 < n_aug) {
             const int nbn = std::min(LU_NBO, n_aug - c0);
             if ((rc = lu_trailing(S, nb, ld, np, n_aug, K0, nbp, c0, c0 + nbn, Pk, S.sp))) return rc;   // the next panel's columns, in the chain
