@@ -960,7 +960,8 @@ __global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict
 // solution re-read by every row; a displaced row's load behind a branch each), so the bits are the same.  Now 31 / 34 us: bound by
 // the LDS itself -- a broadcast read still returns 512 bytes, and a workgroup makes 12 700 of them (8 128 coefficients once, the
 // 8 x 8 triangles by all eight wavefronts).  Coefficients through scalar loads from global memory instead: 90 us (every batch of
-// eight waits for a scalar-cache round trip).
+// eight waits for a scalar-cache round trip); coefficients kept in registers spread over the lanes and fetched with v_readlane
+// pairs (768 LDS reads instead of 12 700): 31 us again, now bound by the vector ALU (two v_readlane and their SGPR hazard per FMA).
 constexpr int TRL_T = 512, TRL_LD = LU_NBO + 1;               // (row stride 129: the column-major L lands in LDS rows without 64-way bank conflicts)
 constexpr size_t TRL_LDS = sizeof(double) * ((size_t)LU_NBO * TRL_LD + 2 * 8 * 64);
 template <bool LOWER>
