@@ -1502,7 +1502,7 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
         // A single solve: the panel stream is confined to the reserved CUs and does only what fits there (leaves, panel updates and
         // the NEXT panel's 128 columns); what it writes it reads back from the same L2s instead of through a memory system the
         // trailing update keeps busy.  Batches keep the unconfined panel stream: their strip work is nbatch times larger.
-        s.confined = confine_env && nbatch == 1;
+        s.confined = confine_env == 2 || (confine_env && nbatch == 1);
         const int reserve = reserve_env >= 0 ? reserve_env : s.confined ? 64 : std::max(16, 2 * nbatch);   // (confined: 32 / 48 / 64 / 96 CUs -> 27.2 / 27.5 / 26.9 / 26.9 ms)
         int dev = 0, ncu = 0;
         SML_HIP(hipGetDevice(&dev));
