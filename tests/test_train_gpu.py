@@ -2,6 +2,8 @@
 
 Tolerances: Gram matrices 1e-12 relative to their max-abs (pin R^T R / R^T Y to 1e-12); W_out entrywise
 1e-8 when well conditioned, otherwise by the backward error of the regularised system (cond * eps bounds the entries)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -159,6 +161,22 @@ def test_long_gram_shapes_and_determinism(n, n_model, n_out, m):
     assert float((c - cref).abs().max()) <= 1e-12 * float(cref.abs().max())
     assert float((b - bref).abs().max()) <= 1e-12 * float(bref.abs().max())
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_single_solve_stream_layouts_agree_bitwise(tmp_path):
+    """A single ridge solve confines its panel chain to reserved CUs and sends the interchanges / U12 of the far columns to the
+    trailing stream; batches (and SML_LU_CONFINE=0) keep everything on one chain.  Same arithmetic, different stream ordering: the
+    weights must agree bit for bit (a missing dependency between the two streams shows up here), for a system with a ragged last
+    panel and right-hand sides that straddle it."""
+    import subprocess, sys
+    outs = []
+    for confine in ("1", "0"):
+        f = tmp_path / f"w{confine}.npy"
+        env = dict(os.environ, SML_LU_CONFINE=confine)
+        subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_fit_dump.py"), str(f), "1500"], check=True, env=env, timeout=600)
+        outs.append(np.load(f))
+    assert np.all(np.isfinite(outs[0]))
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_device_training_pass_matches_oracle(oracle):
