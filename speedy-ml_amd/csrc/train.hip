@@ -43,27 +43,29 @@ constexpr int BM = 128, BN = 128, KT = 16, LDS_LD = 144, GT = 256;
 // 128-byte stores into the column-major C.  A wavefront owns 64 x 64 of C = 4 x 16 such tiles (128 accumulator VGPRs).
 struct WavePos { int wi, wj, l15, l4, l3; };
 
+// (UN = J tiles of 4 per wavefront: 16 = the 64 x 64 wavefront tile; 8 = 64 (I) x 32 (J), a 128 x 64 workgroup tile)
+template <int UN = 16>
 __device__ __forceinline__ WavePos wave_pos()
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return {(wave & 1) * 64, (wave >> 1) * 64, lane & 15, lane >> 4, lane & 3};
+    return {(wave & 1) * 64, (wave >> 1) * 4 * UN, lane & 15, lane >> 4, lane & 3};
 }
 
-template <int KTILE>
-__device__ __forceinline__ void mma_ktile(const double (*As)[LDS_LD], const double (*Bs)[LDS_LD], const WavePos &w, double (&acc)[4][16])
+template <int KTILE, int UN = 16>
+__device__ __forceinline__ void mma_ktile(const double (*As)[LDS_LD], const double (*Bs)[LDS_LD], const WavePos &w, double (&acc)[4][UN])
 {
     // All 20 operand reads of a k-step are issued before its 64 MFMAs (profiles/micro/mfma_f64_pattern.hip: this shape
     // sustains 71-74 TFLOP/s with the operands re-read from LDS every k-step; splitting the B fragment in halves to save
     // registers put a wait in front of every 32 MFMAs and ran at 29 TFLOP/s).
 #pragma unroll
     for (int kk = 0; kk < KTILE; kk += 4) {
-        double af[4], bf[16];
+        double af[4], bf[UN];
 #pragma unroll
         for (int t = 0; t < 4; ++t) af[t] = As[kk + w.l4][w.wi + 16 * t + w.l15];       // A(I0 + 4 blk + j, k): MFMA "B" operand
 #pragma unroll
-        for (int u = 0; u < 16; ++u) bf[u] = Bs[kk + w.l4][w.wj + 4 * u + w.l3];        // B(J0 + i, k): MFMA "A" operand
+        for (int u = 0; u < UN; ++u) bf[u] = Bs[kk + w.l4][w.wj + 4 * u + w.l3];        // B(J0 + i, k): MFMA "A" operand
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bf[u], af[t], acc[t][u], 0, 0, 0);
@@ -72,11 +74,12 @@ __device__ __forceinline__ void mma_ktile(const double (*As)[LDS_LD], const doub
 
 // lane l holds C(I0 + 16 t + (l & 15), J0 + 4 u + (l >> 4)).  C += alpha * acc as a read-modify-write in chunks of 16
 // elements per lane: the 16 loads of a chunk are issued together (one exposed round trip per chunk, not per element).
+template <int UN = 16>
 __device__ __forceinline__ void store_tile(double *__restrict__ C, long ldc, int M, int N, int i0, int j0, const WavePos &w, double alpha,
-                                           const double (&acc)[4][16])
+                                           const double (&acc)[4][UN])
 {
 #pragma unroll
-    for (int u0 = 0; u0 < 16; u0 += 4) {
+    for (int u0 = 0; u0 < UN; u0 += 4) {
         double cv[4][4];
 #pragma unroll
         for (int uu = 0; uu < 4; ++uu) {
@@ -202,6 +205,7 @@ __device__ __forceinline__ void tri_tile(int L, int &ti, int &tj)
     tj = L - (int)((long)ti * (ti + 1) / 2);
 }
 
+template <int UN>
 __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
                                                         double *__restrict__ C, long ldc, int M, int N, int K, double alpha, int mode, int Mr, int Nr,
                                                         GemmBatch gb)
@@ -213,16 +217,17 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict_
     int ti, tj;
     if (mode == 0) { ti = blockIdx.x; tj = blockIdx.y; }
     else tri_tile((int)blockIdx.x, ti, tj);
-    const int i0 = ti * BM, j0 = tj * BN;
-    const WavePos w = wave_pos();
+    // (UN = 8: 64 rows of B per workgroup; the DMA still moves 128 -- the second half is the next tile's, clamped like any row past N)
+    const int i0 = ti * BM, j0 = tj * (8 * UN);
+    const WavePos w = wave_pos<UN>();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ra = min(i0 + 2 * lane, Mr - 2), rb = min(j0 + 2 * lane, Nr - 2);
     const double *pa = A + ra, *pb = B + rb;
-    double acc[4][16];
+    double acc[4][UN];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 16; ++b) acc[a][b] = 0.0;
+        for (int b = 0; b < UN; ++b) acc[a][b] = 0.0;
 
     // each wave moves 2 of the 8 k-columns of each operand: 4 DMAs per wave per K-tile
     auto issue = [&](int slot, int k0) {
@@ -243,9 +248,9 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict_
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();        // every wave's share of tile t is in LDS; everyone is done with slot (t-1)%4
         if (t + AHEAD < ntiles) issue((t + AHEAD) % NBUF, (t + AHEAD) * DKT);
-        mma_ktile<DKT>(S[t % NBUF][0], S[t % NBUF][1], w, acc);
+        mma_ktile<DKT, UN>(S[t % NBUF][0], S[t % NBUF][1], w, acc);
     }
-    store_tile(C, ldc, M, N, i0, j0, w, alpha, acc);
+    store_tile<UN>(C, ldc, M, N, i0, j0, w, alpha, acc);
 }
 
 // ---- Gram update with 256 x 128 tiles: four wavefronts of 128 (I) x 64 (J) each, ONE workgroup per CU ----
@@ -964,20 +969,20 @@ __global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict
 // pairs (768 LDS reads instead of 12 700): 31 us again, now bound by the vector ALU (two v_readlane and their SGPR hazard per FMA).
 constexpr int TRL_T = 512, TRL_LD = LU_NBO + 1;               // (row stride 129: the column-major L lands in LDS rows without 64-way bank conflicts)
 constexpr size_t TRL_LDS = sizeof(double) * ((size_t)LU_NBO * TRL_LD + 2 * 8 * 64);
+extern __shared__ __attribute__((aligned(16))) double lu_dyn_lds[];      // (the one dynamic LDS block of the LU kernels below)
 template <bool LOWER>
-__global__ __launch_bounds__(TRL_T) void k_lu_trsm_rl(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
-                                                       int nbp, int c0, int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls,
-                                                       long tri_stride)
+__device__ __forceinline__ void lu_trsm_rl_body(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
+                                                int nbp, int c0, int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls,
+                                                long tri_stride, int bx, int by)
 {
-    extern __shared__ __attribute__((aligned(16))) double trl_lds[];
-    double *T = trl_lds;                                      // T[i * TRL_LD + k] = L(i,k) / U(i,k) of the block (zero outside the triangle's extent)
-    double(*sx)[8][64] = reinterpret_cast<double(*)[8][64]>(trl_lds + (size_t)LU_NBO * TRL_LD);
-    tri += tri_stride * blockIdx.y; w += ls.w * blockIdx.y;
+    double *T = lu_dyn_lds;                                   // T[i * TRL_LD + k] = L(i,k) / U(i,k) of the block (zero outside the triangle's extent)
+    double(*sx)[8][64] = reinterpret_cast<double(*)[8][64]>(lu_dyn_lds + (size_t)LU_NBO * TRL_LD);
+    tri += tri_stride * by; w += ls.w * by;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = c0 + blockIdx.x * 64 + lane;
+    const int j = c0 + bx * 64 + lane;
     const bool ok = j < ncols;
     if (LOWER) {
-        ipiv += ls.ipiv * blockIdx.y; tmp += ls.tmp * blockIdx.y;
+        ipiv += ls.ipiv * by; tmp += ls.tmp * by;
         // (all pivots and all displaced rows loaded before the first store: a branch around each load costs a memory round trip
         // per row, 16 in a row)
         int pv[LU_NBO / 8];
@@ -1078,6 +1083,14 @@ __global__ __launch_bounds__(TRL_T) void k_lu_trsm_rl(const double *__restrict__
     }
 }
 
+template <bool LOWER>
+__global__ __launch_bounds__(TRL_T) void k_lu_trsm_rl(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
+                                                       int nbp, int c0, int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls,
+                                                       long tri_stride)
+{
+    lu_trsm_rl_body<LOWER>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, tmp, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // back substitution update: Y(i, :) -= sum_k U(i, K0 + k) X(K0 + k, :) for the rows i < K0 above a solved block (K = nb <= 128,
 // nrhs <= 136 right-hand sides).  A skinny product (136 columns) of one K-tile: on the MFMA kernel it costs a whole 128 x 128 x 128
 // tile's latency (41 us) for two column tiles, one of them 94 % empty.  Here the block of X (<= 139 KB) is staged in LDS once per
@@ -1085,15 +1098,18 @@ __global__ __launch_bounds__(TRL_T) void k_lu_trsm_rl(const double *__restrict__
 // is the cost of a workgroup, so fewer and taller workgroups win: 15 rows per workgroup took 39 us per launch), and each thread
 // keeps 8 outputs of two rows: 16 fused multiply-adds per 6 LDS reads.
 constexpr int BS_ROWS = 24, BS_CG = 17;                       // 12 row pairs x 17 column groups of 8 = 204 threads
-__global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls)
+// The rows [row0, min(row0 + BS_ROWS, row_end)) are this workgroup's; the first 256 threads of the workgroup do the work (the body
+// also runs inside the 512-thread k_lu_backsub_step).
+__device__ __forceinline__ void lu_backsub_update_body(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls,
+                                                       int row0, int row_end, int by)
 {
-    y += ls.w * blockIdx.y; U += ls.w * blockIdx.y;
-    extern __shared__ __attribute__((aligned(16))) double bs_lds[];
-    double *xs = bs_lds;                                      // [nb][BS_CG * 8]
-    double *us = bs_lds + LU_NBO * BS_CG * 8;                 // [BS_ROWS][LU_NBO]
+    y += ls.w * by; U += ls.w * by;
+    double *xs = lu_dyn_lds;                                  // [nb][BS_CG * 8]
+    double *us = lu_dyn_lds + LU_NBO * BS_CG * 8;             // [BS_ROWS][LU_NBO]
     const int tid = threadIdx.x;
     constexpr int XW = BS_CG * 8;
     // (loads in batches of 17 / 12 per thread: a one-element-per-iteration loop waited for every load before the next, 54 us)
+    if (tid < 256)
     for (int e0 = 0; e0 < nb * XW; e0 += 256 * 17) {
         double v[17];
 #pragma unroll
@@ -1107,13 +1123,12 @@ __global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ 
             if (e < nb * XW) xs[e] = v[m];
         }
     }
-    const int row0 = blockIdx.x * BS_ROWS;
-    {
+    if (tid < 256) {
         double v[12];
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
             const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
-            v[m] = (k < nb && row0 + r < K0) ? U[(long)(row0 + r) * ld + K0 + k] : 0.0;
+            v[m] = (k < nb && row0 + r < row_end) ? U[(long)(row0 + r) * ld + K0 + k] : 0.0;
         }
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
@@ -1124,8 +1139,8 @@ __global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ 
     __syncthreads();
     const int rp = tid / BS_CG, g = tid % BS_CG;              // row pair, column group
     const int r = 2 * rp;
-    if (rp >= BS_ROWS / 2 || row0 + r >= K0) return;
-    const bool two = row0 + r + 1 < K0;
+    if (tid >= 256 || rp >= BS_ROWS / 2 || row0 + r >= row_end) return;
+    const bool two = row0 + r + 1 < row_end;
     double acc0[8], acc1[8];
     double *yp0 = y + (long)(row0 + r) * ld + g * 8, *yp1 = yp0 + ld;
 #pragma unroll
@@ -1152,6 +1167,76 @@ __global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ 
         }
 }
 
+// rows [row_lo, row_hi) of the right-hand sides, BS_ROWS per workgroup
+__global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls,
+                                                            int row_lo, int row_hi)
+{
+    lu_backsub_update_body(y, U, ld, K0, nb, nrhs, ls, row_lo + (int)blockIdx.x * BS_ROWS, row_hi, (int)blockIdx.y);
+}
+
+// The same update for the 128 rows right above a solved block only -- the rows the next triangular solve waits for.  There the cost
+// of k_lu_backsub_update is a workgroup's latency (all of X staged by each of 6 workgroups: 31 us), so this launch is cut the other
+// way: 32 rows x 16 right-hand sides per workgroup (48 KB staged in one round trip), two outputs per thread, same descending-k
+// fused multiply-subtracts.
+constexpr int BN_ROWS = 32, BN_COLS = 16;
+__global__ __launch_bounds__(256) void k_lu_backsub_near(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, int row_lo,
+                                                          LuStride ls)
+{
+    y += ls.w * blockIdx.z; U += ls.w * blockIdx.z;
+    __shared__ double us[BN_ROWS][LU_NBO + 1];
+    __shared__ __attribute__((aligned(16))) double xs[LU_NBO][BN_COLS];
+    const int tid = threadIdx.x;
+    const int r0 = row_lo + blockIdx.x * BN_ROWS, c0 = blockIdx.y * BN_COLS;
+    double uv[16], xv[8];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
+        uv[m] = (k < nb && r0 + r < K0) ? U[(long)(r0 + r) * ld + K0 + k] : 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int e = tid + 256 * m, k = e >> 4, o = e & (BN_COLS - 1);
+        xv[m] = (k < nb && c0 + o < nrhs) ? y[(long)(K0 + k) * ld + c0 + o] : 0.0;
+    }
+    const int row = tid & (BN_ROWS - 1), cp = tid >> 5;        // 32 rows x 8 column pairs
+    const bool rok = r0 + row < K0;
+    const int col = c0 + 2 * cp;
+    double *yp = y + (long)(r0 + row) * ld + col;
+    double acc0 = (rok && col < nrhs) ? yp[0] : 0.0, acc1 = (rok && col + 1 < nrhs) ? yp[1] : 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int e = tid + 256 * m;
+        us[e >> 7][e & (LU_NBO - 1)] = uv[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int e = tid + 256 * m;
+        xs[e >> 4][e & (BN_COLS - 1)] = xv[m];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = LU_NBO - 1; k >= 0; --k) {                   // (k >= nb: zeros)
+        const double u = us[row][k];
+        acc0 = __builtin_fma(-u, xs[k][2 * cp], acc0);
+        acc1 = __builtin_fma(-u, xs[k][2 * cp + 1], acc1);
+    }
+    if (rok && col < nrhs) yp[0] = acc0;
+    if (rok && col + 1 < nrhs) yp[1] = acc1;
+}
+
+// One step of the back substitution as ONE launch: the first ntr workgroups solve the block at Kt (k_lu_trsm_rl<false>), the others
+// apply the block solved in the step before (at Ku = Kt + 128) to the rows above Kt -- the two are independent once the rows of the
+// block at Kt have had that update (k_lu_backsub_update on those 128 rows, the launch before this one), and one after the other
+// on one stream they took 34 + 38 us per step.
+__global__ __launch_bounds__(TRL_T) void k_lu_backsub_step(double *__restrict__ w, long ld, int n_aug, int nrhs, int Kt, int nbt, int Ku, int nbu, int ntr,
+                                                            LuStride ls)
+{
+    if ((int)blockIdx.x < ntr)
+        lu_trsm_rl_body<false>(w + (long)Kt * ld + Kt, 1L, ld, w, ld, Kt, nbt, n_aug, n_aug + nrhs, nullptr, nullptr, ls, ls.w, (int)blockIdx.x, (int)blockIdx.y);
+    else
+        lu_backsub_update_body(w + n_aug, w, ld, Ku, nbu, nrhs, ls, ((int)blockIdx.x - ntr) * BS_ROWS, Kt, (int)blockIdx.y);
+}
+
 template <bool A_KC, bool B_KC>
 int gemm(const double *A, long sai, long sak, const double *B, long sbj, long sbk, double *C, long ldc, int M, int N, int K,
          double alpha, int lower_only, hipStream_t st, int nbatch = 1, GemmBatch gb = GemmBatch{0, 0, 0})
@@ -1167,7 +1252,7 @@ int gemm(const double *A, long sai, long sak, const double *B, long sbj, long sb
 // alignment conditions hold), general kernel on the tail.
 // padded: both operands may be read one row past M / N (the LU's buffers are padded to 16 rows / columns).
 int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int M, int N, int K, double alpha, int lower_only,
-            hipStream_t st, bool force_dma = false, bool padded = false, int nbatch = 1, GemmBatch gb = GemmBatch{0, 0, 0})
+            hipStream_t st, bool force_dma = false, bool padded = false, int nbatch = 1, GemmBatch gb = GemmBatch{0, 0, 0}, bool half_j = false)
 {
     if (M <= 0 || N <= 0 || K <= 0) return SML_OK;
     auto ok = [](const double *p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0; };
@@ -1178,10 +1263,13 @@ int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, lon
     if (ok(A, lda) && ok(B, ldb) && M >= 2 && N >= 2 && !(Mr & 1) && !(Nr & 1) && (K >= 512 || (force_dma && K >= DKT))) {
         kmain = (K / DKT) * DKT;
         const int nbi = (M + BM - 1) / BM, nbj = (N + BN - 1) / BN;
-        if (!lower_only || nbi != nbj)
-            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi, nbj, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0, Mr, Nr, gb);
+        if (half_j && !lower_only)      // 128 x 64 tiles: twice the workgroups, half the MFMA stream each (a product of few tiles is one tile's latency)
+            hipLaunchKernelGGL(k_gemm_nt_dma<8>, dim3(nbi, (N + 63) / 64, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0, Mr, Nr, gb);
+        else if (!lower_only || nbi != nbj)
+            hipLaunchKernelGGL(k_gemm_nt_dma<16>, dim3(nbi, nbj, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0, Mr, Nr, gb);
         else
-            hipLaunchKernelGGL(k_gemm_nt_dma, dim3(nbi * (nbi + 1) / 2, 1, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 1, Mr, Nr, gb);
+            hipLaunchKernelGGL(k_gemm_nt_dma<16>, dim3(nbi * (nbi + 1) / 2, 1, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 1, Mr, Nr,
+                               gb);
         SML_HIP(hipGetLastError());
     }
     if (kmain < K)
@@ -1572,8 +1660,10 @@ static int launch_leaf(LuSys &S, int nb, long np, int n, int K0, int c, int lw, 
 static int lu_trailing(LuSys &S, int nb, long ld, long np, int n_aug, int K0, int nbp, int j0, int j1, const double *Pk, hipStream_t st)
 {
     const int c0 = K0 + nbp;
+    static const bool half_env = getenv("SML_LU_STRIP_HALF") ? atoi(getenv("SML_LU_STRIP_HALF")) != 0 : true;
+    const bool half_j = half_env && nb == 1 && j1 - j0 <= LU_NBO;          // the strip's product of a single solve: in the leaf chain
     return gemm_nt(S.w + (long)K0 * ld + j0, ld, Pk + c0, np, S.w + (long)c0 * ld + j0, ld, j1 - j0, n_aug - c0, nbp, -1.0, 0, st, lu_dma(), /*padded=*/true,
-                   nb, GemmBatch{S.ls.w, S.ls.p, S.ls.w});
+                   nb, GemmBatch{S.ls.w, S.ls.p, S.ls.w}, half_j);
 }
 
 // enqueue the ridge solves of systems [first, first + nb) (no host synchronisation): everything is ordered on S.sg / S.sp
@@ -1668,19 +1758,48 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     // back substitution on the right-hand sides (columns n_aug .. ncols of W)
     SML_REQUIRE(n_out <= BS_CG * 8, "sml_train_fit: n_out = %d exceeds the %d right-hand sides of the back substitution kernel", n_out, BS_CG * 8);
     const size_t bs_lds = (size_t)(LU_NBO * BS_CG * 8 + BS_ROWS * LU_NBO) * sizeof(double);
-    static bool bs_attr = false;
+    static bool bs_attr = false, bs_attr2 = false;
     if (!bs_attr) {
         SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
         bs_attr = true;
     }
-    for (int K0 = ((n_aug - 1) / LU_NBO) * LU_NBO; K0 >= 0; K0 -= LU_NBO) {
-        const int nbk = std::min(LU_NBO, n_aug - K0);
-        // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns n_aug .. n_aug + n_out of W
-        hipLaunchKernelGGL(k_lu_trsm_rl<false>, dim3((n_out + 63) / 64, nb), dim3(TRL_T), TRL_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0, nbk,
-                               n_aug, n_aug + n_out, (const int *)nullptr, (const double *)nullptr, ls, ls.w);
-        if (K0 > 0)
-            hipLaunchKernelGGL(k_lu_backsub_update, dim3((K0 + BS_ROWS - 1) / BS_ROWS, nb), dim3(256), bs_lds, S.sg, S.w + n_aug, S.w, ld, K0, nbk, n_out, ls);
-        SML_HIP(hipGetLastError());
+    static const bool bs_split = getenv("SML_LU_BACKSUB_SPLIT") ? atoi(getenv("SML_LU_BACKSUB_SPLIT")) != 0 : true;
+    if (!bs_attr2) {
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRL_LDS)));
+        bs_attr2 = true;
+    }
+    // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns n_aug .. n_aug + n_out of W
+    const int ntr = (n_out + 63) / 64;
+    auto solve_block = [&](int K0) {
+        hipLaunchKernelGGL(k_lu_trsm_rl<false>, dim3(ntr, nb), dim3(TRL_T), TRL_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
+                           std::min(LU_NBO, n_aug - K0), n_aug, n_aug + n_out, (const int *)nullptr, (const double *)nullptr, ls, ls.w);
+    };
+    auto update_rows = [&](int K0, int lo, int hi) {          // rows lo .. hi -= U(., block at K0) X(block at K0)
+        hipLaunchKernelGGL(k_lu_backsub_update, dim3((hi - lo + BS_ROWS - 1) / BS_ROWS, nb), dim3(256), bs_lds, S.sg, S.w + n_aug, S.w, ld, K0,
+                           std::min(LU_NBO, n_aug - K0), n_out, ls, lo, hi);
+    };
+    const int K_last = ((n_aug - 1) / LU_NBO) * LU_NBO;
+    if (!bs_split) {
+        for (int K0 = K_last; K0 >= 0; K0 -= LU_NBO) {
+            solve_block(K0);
+            if (K0 > 0) update_rows(K0, 0, K0);
+            SML_HIP(hipGetLastError());
+        }
+    } else {
+        // per step: the 128 rows of the next block get the update first (they are what the chain waits for), then ONE launch solves
+        // that block and updates the rows above it
+        solve_block(K_last);
+        for (int K0 = K_last; K0 > 0; K0 -= LU_NBO) {
+            const int Kn = K0 - LU_NBO;
+            hipLaunchKernelGGL(k_lu_backsub_near, dim3(LU_NBO / BN_ROWS, (n_out + BN_COLS - 1) / BN_COLS, nb), dim3(256), 0, S.sg, S.w + n_aug, S.w, ld, K0,
+                               std::min(LU_NBO, n_aug - K0), n_out, Kn, ls);
+            if (Kn > 0)
+                hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntr + (Kn + BS_ROWS - 1) / BS_ROWS, nb), dim3(TRL_T), std::max(bs_lds, TRL_LDS), S.sg, S.w, ld, n_aug,
+                                   n_out, Kn, LU_NBO, K0, std::min(LU_NBO, n_aug - K0), ntr, ls);
+            else
+                solve_block(0);
+            SML_HIP(hipGetLastError());
+        }
     }
     const long tw = (long)n_aug * n_out;
     hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256), nb), dim3(256), 0, S.sg, S.w, ld, S.wout_list, n_aug, n_out, ls);
