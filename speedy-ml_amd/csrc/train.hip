@@ -17,7 +17,7 @@
 //   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on the row-major system [A^T+reg | B^T+prior], so
 //                that the forward substitution of the right-hand sides rides along.  128-column panels, factored recursively:
 //                8-column register-resident leaves (k_lu_leaf: one barrier per pivot) and k_lu_panel_update for the rest of
-//                the panel; one composite row permutation per panel (k_lu_perm_src, k_lu_swap_gather); U12 by k_lu_trsm_rl<true>;
+//                the panel; one composite row permutation per panel (k_lu_perm_src), applied as U12 is formed by k_lu_trsm_rl<true>;
 //                trailing update with k_gemm_nt_dma (alpha = -1), the next panel's strip first (look-ahead on two streams, the
 //                trailing stream CU-masked so that the leaf always finds a free CU); blocked back substitution
 //                (k_lu_trsm_rl<false>, k_lu_backsub_update).  Up to FIT_BATCH systems advance in lockstep through one chain of
@@ -531,8 +531,8 @@ __global__ void k_symmetrize_diag(double *__restrict__ c, int n)
 //                           one global read and one global write of the leaf, two barriers per pivot.  The same workgroup
 //                           applies each interchange to the panel's other columns and finishes U (8 x 120) of the leaf's rows.
 //             k_lu_panel_update : rank-8 update of the panel's remaining columns, all CUs ]
-//   G: k_lu_panel_finish (U11 -> W, the composite permutation of the panel's 128 interchanges), k_lu_swap_gather (the <= 256
-//      affected rows of W's right-hand columns gathered into a scratch through that permutation: no dependent chain of 128 swaps),
+//   G: k_lu_perm_src (the composite permutation of the panel's 128 interchanges on the <= 256 rows they touch: no dependent chain of
+//      128 swaps, and no separate pass over W -- the triangular solve reads its rows through it),
 //      k_lu_trsm_rl<true> (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
 //      K = 128: FIRST the next panel's 128 columns (+ k_lu_strip_to_panel, which hands them to P), THEN the rest, which runs
 //      beside the next panel's leaf chain (look-ahead).
@@ -546,7 +546,7 @@ constexpr int LU_LEAF = 8;     // columns factorised in registers by one workgro
 // The LU kernels factorise a BATCH of equally sized systems in lockstep: one grid dimension indexes the system, every scratch array
 // is a stack of per-system slabs (LuStride).  One chain of launches then serves all of them; eight separate chains on eight
 // stream pairs were multiplexed onto the runtime's four hardware queues and ran no faster than one after another (measured).
-struct LuStride { long w, p, tmp; int ipiv; };
+struct LuStride { long w, p; int ipiv; };
 
 __global__ void k_build_system(const double *const *__restrict__ c_list, const double *const *__restrict__ b_list, double *__restrict__ w, long ld, int n_aug,
                                int n_model, int n_out, double reg_model, double reg_res, double prior_diag, LuStride ls)
@@ -939,22 +939,9 @@ __global__ __launch_bounds__(256) void k_lu_perm_src(int K0, int nbp, const int 
     src[idx] = x;
 }
 
-// tmp[idx][j] = W[src(idx)][j] for the columns j >= c0 to the right of the panel: the rows as they will read after the panel's
-// interchanges.  Nothing is written into W here, so no ordering between positions is needed and no column walks a dependent
-// chain of 128 swaps.
-__global__ __launch_bounds__(256) void k_lu_swap_gather(const double *__restrict__ w, long ld, int c0, int ncols, int nbp, const int *__restrict__ src,
-                                                         double *__restrict__ tmp, LuStride ls)
-{
-    w += ls.w * blockIdx.z; src += 2 * LU_NBO * blockIdx.z; tmp += ls.tmp * blockIdx.z;
-    const int j = c0 + blockIdx.x * 256 + threadIdx.x;
-    int idx = blockIdx.y;
-    if (idx >= nbp) idx += LU_NBO - nbp;                      // second half of the position list starts at 128
-    if (j >= ncols) return;
-    tmp[(long)idx * ld + j] = w[(long)src[idx] * ld + j];
-}
-
 // The two triangular solves of a 128-row block, right-looking over blocks of 8 rows, for 64 columns per workgroup (lane = column):
-//   LOWER: X = L11^-1 A (unit lower; A = the gathered rows tmp; X -> rows K0.. of W; the displaced rows go back to W on the way)
+//   LOWER: X = L11^-1 A (unit lower; A = the rows of W as the panel's interchanges leave them; X -> rows K0.. of W; the displaced rows
+//          go back to W on the way)
 //   UPPER: X = U11^-1 Y (division by the diagonal; Y, X = rows K0.. of the right-hand-side columns of W)
 // Eight wavefronts; wavefront w keeps row 8 b + w of every block b in registers (16 values per lane).  Per block: the 8 rows go
 // through LDS (one barrier, double-buffered), EVERY wavefront solves the 8 x 8 triangle for itself (no second exchange), stores
@@ -972,7 +959,7 @@ constexpr size_t TRL_LDS = sizeof(double) * ((size_t)LU_NBO * TRL_LD + 2 * 8 * 6
 extern __shared__ __attribute__((aligned(16))) double lu_dyn_lds[];      // (the one dynamic LDS block of the LU kernels below)
 template <bool LOWER>
 __device__ __forceinline__ void lu_trsm_rl_body(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
-                                                int nbp, int c0, int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls,
+                                                int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
                                                 long tri_stride, int bx, int by)
 {
     double *T = lu_dyn_lds;                                   // T[i * TRL_LD + k] = L(i,k) / U(i,k) of the block (zero outside the triangle's extent)
@@ -981,19 +968,27 @@ __device__ __forceinline__ void lu_trsm_rl_body(const double *__restrict__ tri, 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = c0 + bx * 64 + lane;
     const bool ok = j < ncols;
+    // LOWER: the rows come straight out of W through the panel's composite permutation (src, k_lu_perm_src): position idx < 128 is
+    // row K0 + idx, position 128 + t the row ipiv[K0 + t] that pivot t displaced.  A column belongs to one lane, but its rows to all
+    // eight wavefronts: every read of W is complete before the first store (the counted wait in front of the barrier).
+    int pv[LU_NBO / 8];
+    double dv[LU_NBO / 8];
+    double a[LU_NBO / 8];                                     // this wavefront's rows: block b -> row 8 b + wv
     if (LOWER) {
-        ipiv += ls.ipiv * by; tmp += ls.tmp * by;
-        // (all pivots and all displaced rows loaded before the first store: a branch around each load costs a memory round trip
-        // per row, 16 in a row)
-        int pv[LU_NBO / 8];
-        double dv[LU_NBO / 8];
+        ipiv += ls.ipiv * by; src += 2 * LU_NBO * by;
 #pragma unroll
         for (int q = 0; q < LU_NBO / 8; ++q) pv[q] = 8 * q + wv < nbp ? ipiv[K0 + 8 * q + wv] : -1;
 #pragma unroll
-        for (int q = 0; q < LU_NBO / 8; ++q) dv[q] = ok ? tmp[(long)(LU_NBO + 8 * q + wv) * ld + j] : 0.0;
+        for (int q = 0; q < LU_NBO / 8; ++q) {
+            const int sr = 8 * q + wv < nbp ? src[LU_NBO + 8 * q + wv] : K0;
+            dv[q] = ok ? w[(long)sr * ld + j] : 0.0;
+        }
+    }
 #pragma unroll
-        for (int q = 0; q < LU_NBO / 8; ++q)
-            if (pv[q] >= K0 + nbp && ok) w[(long)pv[q] * ld + j] = dv[q];
+    for (int b = 0; b < LU_NBO / 8; ++b) {
+        const int i = 8 * b + wv;
+        const int sr = LOWER ? (i < nbp ? src[i] : K0) : K0 + i;
+        a[b] = (ok && i < nbp) ? w[(long)sr * ld + j] : 0.0;
     }
     // stage the triangle: element (i, k) at tri[i * tri_ld_i + k * tri_ld_k]; the contiguous direction runs along the threads;
     // eight loads in flight per thread
@@ -1015,14 +1010,13 @@ __device__ __forceinline__ void lu_trsm_rl_body(const double *__restrict__ tri, 
             T[i * TRL_LD + k] = v[u];
         }
     }
-    // this wavefront's rows: block b -> row 8 b + wv
-    double a[LU_NBO / 8];
-#pragma unroll
-    for (int b = 0; b < LU_NBO / 8; ++b) {
-        const int i = 8 * b + wv;
-        a[b] = (ok && i < nbp) ? (LOWER ? tmp[(long)i * ld + j] : w[(long)(K0 + i) * ld + j]) : 0.0;
-    }
+    if (LOWER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (LOWER) {
+#pragma unroll
+        for (int q = 0; q < LU_NBO / 8; ++q)
+            if (pv[q] >= K0 + nbp && ok) w[(long)pv[q] * ld + j] = dv[q];
+    }
     const int nblk = (nbp + 7) / 8;
     // fully unrolled over the 16 blocks: a[] is indexed at compile time and each block updates exactly the rows that remain
 #pragma unroll
@@ -1085,10 +1079,10 @@ __device__ __forceinline__ void lu_trsm_rl_body(const double *__restrict__ tri, 
 
 template <bool LOWER>
 __global__ __launch_bounds__(TRL_T) void k_lu_trsm_rl(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
-                                                       int nbp, int c0, int ncols, const int *__restrict__ ipiv, const double *__restrict__ tmp, LuStride ls,
+                                                       int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
                                                        long tri_stride)
 {
-    lu_trsm_rl_body<LOWER>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, tmp, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
+    lu_trsm_rl_body<LOWER>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, src, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // back substitution update: Y(i, :) -= sum_k U(i, K0 + k) X(K0 + k, :) for the rows i < K0 above a solved block (K = nb <= 128,
@@ -1535,7 +1529,7 @@ int sml_train_symmetrize(double *c, int n_aug, void *stream)
 // ---- host side of the LU ----
 struct LuSys {                 // scratch and streams of one batch of factorisations
     int nbatch = 0;
-    double *w = nullptr, *p[2] = {nullptr, nullptr}, *tmp = nullptr;
+    double *w = nullptr, *p[2] = {nullptr, nullptr};
     int *ipiv = nullptr, *info = nullptr, *src = nullptr;
     const double **c_list = nullptr, **b_list = nullptr;      // device arrays of the callers' pointers
     double **wout_list = nullptr;
@@ -1549,7 +1543,6 @@ static void lu_sys_free(LuSys &s)
 {
     if (s.w) (void)hipFree(s.w);
     for (int i = 0; i < 2; ++i) if (s.p[i]) (void)hipFree(s.p[i]);
-    if (s.tmp) (void)hipFree(s.tmp);
     if (s.ipiv) (void)hipFree(s.ipiv);
     if (s.info) (void)hipFree(s.info);
     if (s.src) (void)hipFree(s.src);
@@ -1570,10 +1563,9 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
 {
     const long ld = lu_pad16(ncols), np = lu_pad16(n_aug);
     s.nbatch = nbatch;
-    s.ls = LuStride{(long)n_aug * ld, (long)LU_NBO * np, 2L * LU_NBO * ld, n_aug};
+    s.ls = LuStride{(long)n_aug * ld, (long)LU_NBO * np, n_aug};
     SML_HIP(hipMalloc((void **)&s.w, (size_t)nbatch * s.ls.w * sizeof(double)));
     for (int i = 0; i < 2; ++i) SML_HIP(hipMalloc((void **)&s.p[i], (size_t)nbatch * s.ls.p * sizeof(double)));
-    SML_HIP(hipMalloc((void **)&s.tmp, (size_t)nbatch * s.ls.tmp * sizeof(double)));
     SML_HIP(hipMalloc((void **)&s.ipiv, (size_t)nbatch * n_aug * sizeof(int)));
     SML_HIP(hipMalloc((void **)&s.info, (size_t)nbatch * sizeof(int)));
     SML_HIP(hipMalloc((void **)&s.src, (size_t)nbatch * 2 * LU_NBO * sizeof(int)));
@@ -1724,9 +1716,8 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         const int ce = (S.confined && c0 < n_aug) ? c0 + std::min(LU_NBO, n_aug - c0) : ncols;    // (exactly the columns lu_trailing updates on S.sp)
         auto gather_and_u12 = [&](int j0, int j1, hipStream_t st) {
             if (j1 <= j0) return;
-            hipLaunchKernelGGL(k_lu_swap_gather, dim3((j1 - j0 + 255) / 256, 2 * nbp, nb), dim3(256), 0, st, S.w, ld, j0, j1, nbp, S.src, S.tmp, ls);
             hipLaunchKernelGGL(k_lu_trsm_rl<true>, dim3((j1 - j0 + 63) / 64, nb), dim3(TRL_T), TRL_LDS, st, Pk + K0, np, 1L, S.w, ld, K0, nbp, j0, j1, S.ipiv,
-                               S.tmp, ls, ls.p);
+                               S.src, ls, ls.p);
         };
         if (S.confined) {                                                    // S.sg needs the permutation; it is long done with panel k-1
             SML_HIP(hipEventRecord(S.ev_panel, S.sp));
@@ -1772,7 +1763,7 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     const int ntr = (n_out + 63) / 64;
     auto solve_block = [&](int K0) {
         hipLaunchKernelGGL(k_lu_trsm_rl<false>, dim3(ntr, nb), dim3(TRL_T), TRL_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
-                           std::min(LU_NBO, n_aug - K0), n_aug, n_aug + n_out, (const int *)nullptr, (const double *)nullptr, ls, ls.w);
+                           std::min(LU_NBO, n_aug - K0), n_aug, n_aug + n_out, (const int *)nullptr, (const int *)nullptr, ls, ls.w);
     };
     auto update_rows = [&](int K0, int lo, int hi) {          // rows lo .. hi -= U(., block at K0) X(block at K0)
         hipLaunchKernelGGL(k_lu_backsub_update, dim3((hi - lo + BS_ROWS - 1) / BS_ROWS, nb), dim3(256), bs_lds, S.sg, S.w + n_aug, S.w, ld, K0,
@@ -1811,7 +1802,7 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
 // launches (the grid's batch dimension), so the latency-bound leaf chain is paid once per batch and the trailing updates of all of
 // them fill the chip together.  c/b/wout are host arrays of device pointers.  Synchronises; returns SML_ERR_NUMERIC if any system is
 // singular (sml_last_error names the first).
-// The scratch of a batch (per system: the row-major system, two panel buffers, the gathered rows: ~310 MB at n_aug = 5892) and its
+// The scratch of a batch (per system: the row-major system, two panel buffers: ~300 MB at n_aug = 5892) and its
 // streams are kept between calls: allocating them took 12 ms of a 43 ms call.  sml_train_release_workspace frees them.
 constexpr int FIT_BATCH = 16;            // (8 / 16 / 32 systems in lockstep: 7.3 / 6.3 / 6.5 ms per 5892-row system, profiles/micro/fit_batch_sizes.py)
 static LuSys g_lu;
