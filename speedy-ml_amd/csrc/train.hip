@@ -17,10 +17,10 @@
 //   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on the row-major system [A^T+reg | B^T+prior], so
 //                that the forward substitution of the right-hand sides rides along.  128-column panels, factored recursively:
 //                8-column register-resident leaves (k_lu_leaf: one barrier per pivot) and k_lu_panel_update for the rest of
-//                the panel; one composite row permutation per panel (k_lu_perm_src), applied as U12 is formed by k_lu_trsm_rl<true>;
+//                the panel; one composite row permutation per panel (k_lu_perm_src), applied as U12 is formed by k_lu_trsm_mfma<true>;
 //                trailing update with k_gemm_nt_dma (alpha = -1), the next panel's strip first (look-ahead on two streams, the
 //                trailing stream CU-masked so that the leaf always finds a free CU); blocked back substitution
-//                (k_lu_trsm_rl<false>, k_lu_backsub_update).  Up to FIT_BATCH systems advance in lockstep through one chain of
+//                (k_lu_trsm_mfma<false>, k_lu_backsub_near, k_lu_backsub_step).  Up to FIT_BATCH systems advance in lockstep through one chain of
 //                launches (grid dimension z).
 // All matrices are column-major fp64, as in the reference.
 #include <cstdlib>
@@ -533,7 +533,7 @@ __global__ void k_symmetrize_diag(double *__restrict__ c, int n)
 //             k_lu_panel_update : rank-8 update of the panel's remaining columns, all CUs ]
 //   G: k_lu_perm_src (the composite permutation of the panel's 128 interchanges on the <= 256 rows they touch: no dependent chain of
 //      128 swaps, and no separate pass over W -- the triangular solve reads its rows through it),
-//      k_lu_trsm_rl<true> (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
+//      k_lu_trsm_mfma<true> (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
 //      K = 128: FIRST the next panel's 128 columns (+ k_lu_strip_to_panel, which hands them to P), THEN the rest, which runs
 //      beside the next panel's leaf chain (look-ahead).
 // The previous form (32-wide panel in one workgroup that walked the panel through memory for every sub-panel, one dependent
@@ -939,150 +939,158 @@ __global__ __launch_bounds__(256) void k_lu_perm_src(int K0, int nbp, const int 
     src[idx] = x;
 }
 
-// The two triangular solves of a 128-row block, right-looking over blocks of 8 rows, for 64 columns per workgroup (lane = column):
-//   LOWER: X = L11^-1 A (unit lower; A = the rows of W as the panel's interchanges leave them; X -> rows K0.. of W; the displaced rows
-//          go back to W on the way)
-//   UPPER: X = U11^-1 Y (division by the diagonal; Y, X = rows K0.. of the right-hand-side columns of W)
-// Eight wavefronts; wavefront w keeps row 8 b + w of every block b in registers (16 values per lane).  Per block: the 8 rows go
-// through LDS (one barrier, double-buffered), EVERY wavefront solves the 8 x 8 triangle for itself (no second exchange), stores
-// its own row and applies the block's 8 solutions to the rows it still holds.  The triangle (all of L11 or U11, 128 KB) sits in
-// LDS row-major, so a row's 8 coefficients of a block are two 32-byte broadcast reads.  Per entry the multiply-subtracts are fused
-// and run over ascending k (LOWER) / descending k (UPPER) -- block by block and within a block -- exactly as in the left-looking
-// kernels of the first version (37 / 46 us per launch: two barriers and a dependent LDS round trip per 8 rows, every earlier
-// solution re-read by every row; a displaced row's load behind a branch each), so the bits are the same.  Now 31 / 34 us: bound by
-// the LDS itself -- a broadcast read still returns 512 bytes, and a workgroup makes 12 700 of them (8 128 coefficients once, the
-// 8 x 8 triangles by all eight wavefronts).  Coefficients through scalar loads from global memory instead: 90 us (every batch of
-// eight waits for a scalar-cache round trip); coefficients kept in registers spread over the lanes and fetched with v_readlane
-// pairs (768 LDS reads instead of 12 700): 31 us again, now bound by the vector ALU (two v_readlane and their SGPR hazard per FMA).
-constexpr int TRL_T = 512, TRL_LD = LU_NBO + 1;               // (row stride 129: the column-major L lands in LDS rows without 64-way bank conflicts)
-constexpr size_t TRL_LDS = sizeof(double) * ((size_t)LU_NBO * TRL_LD + 2 * 8 * 64);
+constexpr int TRL_T = 512;                                    // threads of the back substitution's combined step kernel
 extern __shared__ __attribute__((aligned(16))) double lu_dyn_lds[];      // (the one dynamic LDS block of the LU kernels below)
+// ---- the two triangular solves of a 128-row block, on the matrix cores ----
+//   LOWER: X = L11^-1 A (unit lower; A = the rows of W as the panel's interchanges leave them, read through k_lu_perm_src's composite
+//          permutation -- no separate gather pass; X -> rows K0.. of W; the displaced rows go back to W on the way)
+//   UPPER: X = U11^-1 Y (Y, X = rows K0.. of the right-hand-side columns of W)
+// A wavefront owns 16 columns and ALL 128 rows of them, in the accumulator layout of v_mfma_f64_4x4x4 (lane = 16 i + c: row 4 q + i of
+// quad q, column c; 32 quads = 32 registers), so wavefronts never exchange anything: no barrier after the staging of the triangle.
+// Per quad: x = (the quad's 4 x 4 triangle)^-1 a as ONE MFMA -- the 32 small inverses are formed once per workgroup by substitution
+// on unit vectors (UPPER: with true divisions by the pivots) -- then every remaining quad gets its update as ONE MFMA: the solved
+// quad is already in the B-operand layout, and the A operand (-L or -U, 4 x 4, negated at staging so that the MFMA's multiply-ADD
+// subtracts) is one 16-address LDS read, not 16 broadcasts: 528 MFMAs + 528 reads per wavefront, a dependent chain of two MFMAs per
+// quad.  Order of the subtractions per entry: quads ascending (LOWER) / descending (UPPER); inside a quad the MFMA's own order.
+// Row stride 133: the A read (addresses i * 133 + k, i, k < 4) and the staging of the column-major L (lanes along i) are both
+// conflict-free.
+// History.  First version (left-looking vector kernels, two barriers and an LDS round trip per 8 rows): 37 / 46 us per launch.
+// Right-looking over 8-row blocks, eight wavefronts each keeping one row per block and solving every 8 x 8 triangle for itself:
+// 31 / 34 us, bound by the LDS (12 700 broadcast reads per workgroup, each returning 512 bytes); coefficients through scalar loads
+// instead: 90 us; through v_readlane: 31 us (vector ALU).  This layout with the quad solved across the lane groups by ds_bpermute
+// steps: 40 us (four dependent LDS round trips per quad); with a uniform `q < nq` branch around every MFMA: 53 us (each MFMA behind
+// its own LDS round trip).  Now 34-37 us cold / 24 us when launched twice in a row: ~10 us of a launch is the instruction fetch
+// of 40 KB of straight-line code, the rest mostly the three memory round trips in front of the MFMAs (permutation, rows, triangle).
+// Backward error of the 5892-row ridge solve of a driven reservoir: 2.92e-17 with these solves, 2.91e-17 with substitution
+// throughout, 1.79e-17 for LAPACK on the host (tests/test_train_gpu.py prints it).
+constexpr int TRM_LD = 133;
+constexpr size_t TRM_LDS = sizeof(double) * ((size_t)LU_NBO * TRM_LD + 2 * LU_NBO + 16 * (LU_NBO / 4));
 template <bool LOWER>
-__device__ __forceinline__ void lu_trsm_rl_body(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
-                                                int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
-                                                long tri_stride, int bx, int by)
+__device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
+                                                  int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
+                                                  long tri_stride, int bx, int by)
 {
-    double *T = lu_dyn_lds;                                   // T[i * TRL_LD + k] = L(i,k) / U(i,k) of the block (zero outside the triangle's extent)
-    double(*sx)[8][64] = reinterpret_cast<double(*)[8][64]>(lu_dyn_lds + (size_t)LU_NBO * TRL_LD);
+    double *T = lu_dyn_lds;                                   // T[i * TRM_LD + k] = -L(i,k), k < i / -U(i,k), k > i; zero elsewhere
+    double *dg = T + (size_t)LU_NBO * TRM_LD, *rdg = dg + LU_NBO;
     tri += tri_stride * by; w += ls.w * by;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = c0 + bx * 64 + lane;
+    const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = nthr >> 6;
+    const int ri = lane >> 4, cc = lane & 15;
+    const int j = c0 + (bx * nwv + wave) * 16 + cc;
     const bool ok = j < ncols;
-    // LOWER: the rows come straight out of W through the panel's composite permutation (src, k_lu_perm_src): position idx < 128 is
-    // row K0 + idx, position 128 + t the row ipiv[K0 + t] that pivot t displaced.  A column belongs to one lane, but its rows to all
-    // eight wavefronts: every read of W is complete before the first store (the counted wait in front of the barrier).
-    int pv[LU_NBO / 8];
-    double dv[LU_NBO / 8];
-    double a[LU_NBO / 8];                                     // this wavefront's rows: block b -> row 8 b + wv
-    if (LOWER) {
-        ipiv += ls.ipiv * by; src += 2 * LU_NBO * by;
+    constexpr int NQ = LU_NBO / 4;
+    // The triangle goes through registers in batches of 32 loads per thread (one batch with 512 threads, two with 256); the first
+    // batch is in flight while the rows are fetched (with 8 loads per batch a 256-thread workgroup paid eight round trips).
+    constexpr int SB = 32;
+    double v[SB];
+    auto stage_load = [&](int e0) {
 #pragma unroll
-        for (int q = 0; q < LU_NBO / 8; ++q) pv[q] = 8 * q + wv < nbp ? ipiv[K0 + 8 * q + wv] : -1;
-#pragma unroll
-        for (int q = 0; q < LU_NBO / 8; ++q) {
-            const int sr = 8 * q + wv < nbp ? src[LU_NBO + 8 * q + wv] : K0;
-            dv[q] = ok ? w[(long)sr * ld + j] : 0.0;
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < LU_NBO / 8; ++b) {
-        const int i = 8 * b + wv;
-        const int sr = LOWER ? (i < nbp ? src[i] : K0) : K0 + i;
-        a[b] = (ok && i < nbp) ? w[(long)sr * ld + j] : 0.0;
-    }
-    // stage the triangle: element (i, k) at tri[i * tri_ld_i + k * tri_ld_k]; the contiguous direction runs along the threads;
-    // eight loads in flight per thread
-    for (int e0 = threadIdx.x; e0 < LU_NBO * LU_NBO; e0 += TRL_T * 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + TRL_T * u;
+        for (int u = 0; u < SB; ++u) {
+            const int e = e0 + nthr * u;
             int i, k;
             if (LOWER) { i = e & (LU_NBO - 1); k = e >> 7; }  // L is column-major in the panel buffer: i contiguous
             else { k = e & (LU_NBO - 1); i = e >> 7; }        // U is row-major in W: k contiguous
             const bool in = i < nbp && k < nbp && (LOWER ? k < i : k >= i);
             v[u] = in ? tri[(long)i * tri_ld_i + (long)k * tri_ld_k] : 0.0;
         }
+    };
+    auto stage_store = [&](int e0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + TRL_T * u;
+        for (int u = 0; u < SB; ++u) {
+            const int e = e0 + nthr * u;
             const int i = LOWER ? (e & (LU_NBO - 1)) : (e >> 7), k = LOWER ? (e >> 7) : (e & (LU_NBO - 1));
-            T[i * TRL_LD + k] = v[u];
+            T[i * TRM_LD + k] = i == k ? 0.0 : -v[u];
+            if (!LOWER && i == k) {
+                const double d = i < nbp ? v[u] : 1.0;
+                dg[i] = d; rdg[i] = 1.0 / d;
+            }
         }
-    }
-    if (LOWER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    };
+    const bool second = nthr * SB < LU_NBO * LU_NBO;          // (uniform)
+    stage_load(threadIdx.x);
+    double a[NQ];
     if (LOWER) {
+        ipiv += ls.ipiv * by; src += 2 * LU_NBO * by;
+        // every read of this wavefront's columns comes before the first store into them (a displaced row may be another position's source)
+        double dv[NQ];
+        int pv[NQ];
 #pragma unroll
-        for (int q = 0; q < LU_NBO / 8; ++q)
+        for (int q = 0; q < NQ; ++q) {
+            const int t = 4 * q + ri;
+            const bool in = t < nbp;
+            pv[q] = in ? ipiv[K0 + t] : -1;
+            const int sa = in ? src[t] : K0, sd = in ? src[LU_NBO + t] : K0;
+            a[q] = (ok && in) ? w[(long)sa * ld + j] : 0.0;
+            dv[q] = (ok && in) ? w[(long)sd * ld + j] : 0.0;
+        }
+        stage_store(threadIdx.x);
+        if (second) stage_load(threadIdx.x + nthr * SB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
             if (pv[q] >= K0 + nbp && ok) w[(long)pv[q] * ld + j] = dv[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int t = 4 * q + ri;
+            a[q] = (ok && t < nbp) ? w[(long)(K0 + t) * ld + j] : 0.0;
+        }
+        stage_store(threadIdx.x);
+        if (second) stage_load(threadIdx.x + nthr * SB);
     }
-    const int nblk = (nbp + 7) / 8;
-    // fully unrolled over the 16 blocks: a[] is indexed at compile time and each block updates exactly the rows that remain
+    if (second) stage_store(threadIdx.x + nthr * SB);
+    __syncthreads();
+    // the inverses of the 32 diagonal 4 x 4 triangles, one thread per column of one inverse (substitution on a unit vector)
+    double *dinv = rdg + LU_NBO;                              // dinv[16 q + 4 i + k]
+    if (threadIdx.x < LU_NBO) {
+        const int q = threadIdx.x >> 2, c = threadIdx.x & 3;
+        const double *tq = T + (4 * q) * TRM_LD + 4 * q;      // (negated off-diagonal entries)
+        double y[4] = {0.0, 0.0, 0.0, 0.0};
+        if (LOWER) {
 #pragma unroll
-    for (int t = 0; t < LU_NBO / 8; ++t) {
-        const int b = LOWER ? t : LU_NBO / 8 - 1 - t, ib = 8 * b;
-        if (b < nblk) {                                       // (uniform; a short last block of the matrix has fewer)
-            sx[t & 1][wv][lane] = a[b];
-            __syncthreads();
-            double x[8];
-            const double *tb = T + ib * TRL_LD + ib;          // the block's 8 x 8 triangle
-            if (LOWER) {
+            for (int i = 0; i < 4; ++i) {
+                double v = i == c ? 1.0 : 0.0;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    double v = sx[t & 1][r][lane];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (k < r) v = __builtin_fma(-tb[r * TRL_LD + k], x[k], v);
-                    x[r] = v;
-                }
-            } else {
-#pragma unroll
-                for (int r = 7; r >= 0; --r) {
-                    double v = sx[t & 1][r][lane];
-#pragma unroll
-                    for (int k = 7; k >= 0; --k)
-                        if (k > r) v = __builtin_fma(-tb[r * TRL_LD + k], x[k], v);
-                    const double dg = tb[r * TRL_LD + r];
-                    v = ib + r < nbp ? v / dg : 0.0;          // (rows past a short last block are padding)
-                    x[r] = v;
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (k < i) v = __builtin_fma(tq[i * TRM_LD + k], y[k], v);
+                y[i] = i >= c ? v : 0.0;
             }
-            {   // this wavefront's row of the block is final
-                double xm = 0.0;
+        } else {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) xm = r == wv ? x[r] : xm;
-                if (ok && ib + wv < nbp) w[(long)(K0 + ib + wv) * ld + j] = xm;
+            for (int i = 3; i >= 0; --i) {
+                double v = i == c ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 3; k >= 0; --k)
+                    if (k > i) v = __builtin_fma(tq[i * TRM_LD + k], y[k], v);
+                y[i] = i <= c ? v / dg[4 * q + i] : 0.0;
             }
-            // the block's 8 solutions applied to the rows this wavefront still holds
+        }
 #pragma unroll
-            for (int q = 0; q < LU_NBO / 8; ++q) {
-                if (LOWER ? q > b : q < b) {
-                    const double *row = T + (8 * q + wv) * TRL_LD + ib;
-                    double cf[8];
+        for (int i = 0; i < 4; ++i) dinv[16 * q + 4 * i + c] = y[i];
+    }
+    __syncthreads();
+    const double *ta = T + (lane & 3) * TRM_LD + (lane >> 4);                // A operand of quad pair (q2, q): ta[4 q2 * TRM_LD + 4 q]
+    const double *ti = dinv + 4 * (lane & 3) + (lane >> 4);                  // A operand of quad q's inverse: ti[16 q]
+    // Straight-line code, all 32 quads whatever nbp: rows and coefficients past a short last block are zeros (diagonal 1), and a
+    // uniform branch around each MFMA put every one of them behind its own LDS round trip (53 us per launch).
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) cf[k] = row[k];
-                    double v = a[q];
-                    if (LOWER) {
+    for (int s = 0; s < NQ; ++s) {
+        const int q = LOWER ? s : NQ - 1 - s;
+        const double xa = __builtin_amdgcn_mfma_f64_4x4x4f64(ti[16 * q], a[q], 0.0, 0, 0, 0);
+        if (ok && 4 * q + ri < nbp) w[(long)(K0 + 4 * q + ri) * ld + j] = xa;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v = __builtin_fma(-cf[k], x[k], v);
-                    } else {
-#pragma unroll
-                        for (int k = 7; k >= 0; --k) v = __builtin_fma(-cf[k], x[k], v);
-                    }
-                    a[q] = v;
-                }
-            }
+        for (int d = 1; d < NQ; ++d) {                        // nearest quad first: the next solve waits for it
+            const int q2 = LOWER ? q + d : q - d;
+            if (q2 >= 0 && q2 < NQ) a[q2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[4 * q2 * TRM_LD + 4 * q], xa, a[q2], 0, 0, 0);
         }
     }
 }
 
 template <bool LOWER>
-__global__ __launch_bounds__(TRL_T) void k_lu_trsm_rl(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
+__global__ __launch_bounds__(256) void k_lu_trsm_mfma(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
                                                        int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
                                                        long tri_stride)
 {
-    lu_trsm_rl_body<LOWER>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, src, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
+    lu_trsm_mfma_body<LOWER>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, src, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // back substitution update: Y(i, :) -= sum_k U(i, K0 + k) X(K0 + k, :) for the rows i < K0 above a solved block (K = nb <= 128,
@@ -1218,15 +1226,16 @@ __global__ __launch_bounds__(256) void k_lu_backsub_near(double *__restrict__ y,
     if (rok && col + 1 < nrhs) yp[1] = acc1;
 }
 
-// One step of the back substitution as ONE launch: the first ntr workgroups solve the block at Kt (k_lu_trsm_rl<false>), the others
+// One step of the back substitution as ONE launch: the first ntr workgroups solve the block at Kt (as k_lu_trsm_mfma<false>), the others
 // apply the block solved in the step before (at Ku = Kt + 128) to the rows above Kt -- the two are independent once the rows of the
 // block at Kt have had that update (k_lu_backsub_update on those 128 rows, the launch before this one), and one after the other
 // on one stream they took 34 + 38 us per step.
 __global__ __launch_bounds__(TRL_T) void k_lu_backsub_step(double *__restrict__ w, long ld, int n_aug, int nrhs, int Kt, int nbt, int Ku, int nbu, int ntr,
                                                             LuStride ls)
 {
-    if ((int)blockIdx.x < ntr)
-        lu_trsm_rl_body<false>(w + (long)Kt * ld + Kt, 1L, ld, w, ld, Kt, nbt, n_aug, n_aug + nrhs, nullptr, nullptr, ls, ls.w, (int)blockIdx.x, (int)blockIdx.y);
+    if ((int)blockIdx.x < ntr)          // (512 threads: eight wavefronts x 16 right-hand sides per solving workgroup)
+        lu_trsm_mfma_body<false>(w + (long)Kt * ld + Kt, 1L, ld, w, ld, Kt, nbt, n_aug, n_aug + nrhs, nullptr, nullptr, ls, ls.w, (int)blockIdx.x,
+                                 (int)blockIdx.y);
     else
         lu_backsub_update_body(w + n_aug, w, ld, Ku, nbu, nrhs, ls, ((int)blockIdx.x - ntr) * BS_ROWS, Kt, (int)blockIdx.y);
 }
@@ -1668,8 +1677,8 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     int rc;
     static bool trl_attr = false;
     if (!trl_attr) {
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_rl<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRL_LDS));
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_rl<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRL_LDS));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
         trl_attr = true;
     }
     for (int i = 0; i < nb; ++i)
@@ -1716,7 +1725,7 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         const int ce = (S.confined && c0 < n_aug) ? c0 + std::min(LU_NBO, n_aug - c0) : ncols;    // (exactly the columns lu_trailing updates on S.sp)
         auto gather_and_u12 = [&](int j0, int j1, hipStream_t st) {
             if (j1 <= j0) return;
-            hipLaunchKernelGGL(k_lu_trsm_rl<true>, dim3((j1 - j0 + 63) / 64, nb), dim3(TRL_T), TRL_LDS, st, Pk + K0, np, 1L, S.w, ld, K0, nbp, j0, j1, S.ipiv,
+            hipLaunchKernelGGL(k_lu_trsm_mfma<true>, dim3((j1 - j0 + 63) / 64, nb), dim3(256), TRM_LDS, st, Pk + K0, np, 1L, S.w, ld, K0, nbp, j0, j1, S.ipiv,
                                S.src, ls, ls.p);
         };
         if (S.confined) {                                                    // S.sg needs the permutation; it is long done with panel k-1
@@ -1756,13 +1765,13 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     }
     static const bool bs_split = getenv("SML_LU_BACKSUB_SPLIT") ? atoi(getenv("SML_LU_BACKSUB_SPLIT")) != 0 : true;
     if (!bs_attr2) {
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRL_LDS)));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRM_LDS)));
         bs_attr2 = true;
     }
     // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns n_aug .. n_aug + n_out of W
     const int ntr = (n_out + 63) / 64;
     auto solve_block = [&](int K0) {
-        hipLaunchKernelGGL(k_lu_trsm_rl<false>, dim3(ntr, nb), dim3(TRL_T), TRL_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
+        hipLaunchKernelGGL(k_lu_trsm_mfma<false>, dim3(ntr, nb), dim3(256), TRM_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
                            std::min(LU_NBO, n_aug - K0), n_aug, n_aug + n_out, (const int *)nullptr, (const int *)nullptr, ls, ls.w);
     };
     auto update_rows = [&](int K0, int lo, int hi) {          // rows lo .. hi -= U(., block at K0) X(block at K0)
@@ -1784,9 +1793,11 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
             const int Kn = K0 - LU_NBO;
             hipLaunchKernelGGL(k_lu_backsub_near, dim3(LU_NBO / BN_ROWS, (n_out + BN_COLS - 1) / BN_COLS, nb), dim3(256), 0, S.sg, S.w + n_aug, S.w, ld, K0,
                                std::min(LU_NBO, n_aug - K0), n_out, Kn, ls);
-            if (Kn > 0)
-                hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntr + (Kn + BS_ROWS - 1) / BS_ROWS, nb), dim3(TRL_T), std::max(bs_lds, TRL_LDS), S.sg, S.w, ld, n_aug,
-                                   n_out, Kn, LU_NBO, K0, std::min(LU_NBO, n_aug - K0), ntr, ls);
+            if (Kn > 0) {
+                const int ntm = (n_out + 127) / 128;
+                hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntm + (Kn + BS_ROWS - 1) / BS_ROWS, nb), dim3(TRL_T), std::max(bs_lds, TRM_LDS), S.sg, S.w, ld, n_aug,
+                                   n_out, Kn, LU_NBO, K0, std::min(LU_NBO, n_aug - K0), ntm, ls);
+            }
             else
                 solve_block(0);
             SML_HIP(hipGetLastError());

@@ -317,5 +317,6 @@ def test_full_size_ridge_fit_of_a_driven_reservoir():
     assert eta <= 1e-15 + 4.0 * eta_ref, (eta, eta_ref)
     dw = wg - want
     pred = np.sqrt(max(np.trace(dw @ c @ dw.T), 0.0) / np.trace(want @ c @ want.T))
+    print(f"backward error {eta:.3e} (LAPACK on the host: {eta_ref:.3e}), prediction difference {pred:.3e}")
     assert pred <= 1e-9, pred
     assert np.max(np.abs(dw)) <= 1e-5 * np.max(np.abs(want)), np.max(np.abs(dw)) / np.max(np.abs(want))
