@@ -15,6 +15,6 @@ print({k: round(v, 2) for k, v in sorted(tot.items(), key=lambda x: -x[1])})
 leaf = [e for e in ev if e[2] == 'k_lu_leaf']
 gaps = [(b[0] - a[1]) / 1e3 for a, b in zip(leaf[:-1], leaf[1:]) if (b[0] - a[1]) / 1e3 > 25]
 print('inter-panel gaps', len(gaps), 'median us', statistics.median(gaps), 'sum ms', sum(gaps) / 1e3)
-upd = [i for i, e in enumerate(ev) if e[2] == 'k_lu_backsub_update']
-first_bs = max(i for i in range(upd[0]) if ev[i][2] == 'k_lu_trsm_rl')          # the triangular solve in front of the first update
+upd = [i for i, e in enumerate(ev) if e[2].startswith('k_lu_backsub')]
+first_bs = max(i for i in range(upd[0]) if ev[i][2].startswith('k_lu_trsm'))       # the triangular solve in front of the first update
 print('back substitution span ms', (ev[-1][1] - ev[first_bs][0]) / 1e6, ' first leaf at ms', leaf[0][0] / 1e6, ' last leaf end ms', leaf[-1][1] / 1e6)
