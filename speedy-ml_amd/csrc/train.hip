@@ -1103,7 +1103,7 @@ constexpr int BS_ROWS = 24, BS_CG = 17;                       // 12 row pairs x 
 // The rows [row0, min(row0 + BS_ROWS, row_end)) are this workgroup's; the first 256 threads of the workgroup do the work (the body
 // also runs inside the 512-thread k_lu_backsub_step).
 __device__ __forceinline__ void lu_backsub_update_body(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls,
-                                                       int row0, int row_end, int by)
+                                                       int row0, int row_stride, int row_end, int by)
 {
     y += ls.w * by; U += ls.w * by;
     double *xs = lu_dyn_lds;                                  // [nb][BS_CG * 8]
@@ -1125,59 +1125,58 @@ __device__ __forceinline__ void lu_backsub_update_body(double *__restrict__ y, c
             if (e < nb * XW) xs[e] = v[m];
         }
     }
-    if (tid < 256) {
-        double v[12];
-#pragma unroll
-        for (int m = 0; m < 12; ++m) {
-            const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
-            v[m] = (k < nb && row0 + r < row_end) ? U[(long)(row0 + r) * ld + K0 + k] : 0.0;
-        }
-#pragma unroll
-        for (int m = 0; m < 12; ++m) {
-            const int e = tid + 256 * m, r = e >> 7, k = e & (LU_NBO - 1);
-            us[r * LU_NBO + k] = v[m];
-        }
-    }
-    __syncthreads();
     const int rp = tid / BS_CG, g = tid % BS_CG;              // row pair, column group
     const int r = 2 * rp;
-    if (tid >= 256 || rp >= BS_ROWS / 2 || row0 + r >= row_end) return;
-    const bool two = row0 + r + 1 < row_end;
-    double acc0[8], acc1[8];
-    double *yp0 = y + (long)(row0 + r) * ld + g * 8, *yp1 = yp0 + ld;
+    // (a workgroup takes the row groups row0, row0 + row_stride, ...: the solved block is staged once, and a launch whose groups
+    // outnumber the CUs runs in 1.4 rounds' time instead of two)
+    for (; row0 < row_end; row0 += row_stride) {
+        if (tid < 256) {
+            double v[12];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        acc0[o] = g * 8 + o < nrhs ? yp0[o] : 0.0;
-        acc1[o] = (two && g * 8 + o < nrhs) ? yp1[o] : 0.0;
-    }
-    const double *ur0 = us + r * LU_NBO, *ur1 = ur0 + LU_NBO;
-    for (int k = nb - 1; k >= 0; --k) {                       // descending k, as the column-oriented dtrsm subtracts
-        const double u0 = ur0[k], u1 = ur1[k];
-        const double *xk = xs + k * XW + g * 8;
+            for (int m = 0; m < 12; ++m) {
+                const int e = tid + 256 * m, rr = e >> 7, k = e & (LU_NBO - 1);
+                v[m] = (k < nb && row0 + rr < row_end) ? U[(long)(row0 + rr) * ld + K0 + k] : 0.0;
+            }
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const double xv = xk[o];
-            acc0[o] = __builtin_fma(-u0, xv, acc0[o]);
-            acc1[o] = __builtin_fma(-u1, xv, acc1[o]);
+            for (int m = 0; m < 12; ++m) {
+                const int e = tid + 256 * m, rr = e >> 7, k = e & (LU_NBO - 1);
+                us[rr * LU_NBO + k] = v[m];
+            }
         }
-    }
+        __syncthreads();
+        if (tid < 256 && rp < BS_ROWS / 2 && row0 + r < row_end) {
+            const bool two = row0 + r + 1 < row_end;
+            double acc0[8], acc1[8];
+            double *yp0 = y + (long)(row0 + r) * ld + g * 8, *yp1 = yp0 + ld;
 #pragma unroll
-    for (int o = 0; o < 8; ++o)
-        if (g * 8 + o < nrhs) {
-            yp0[o] = acc0[o];
-            if (two) yp1[o] = acc1[o];
+            for (int o = 0; o < 8; ++o) {
+                acc0[o] = g * 8 + o < nrhs ? yp0[o] : 0.0;
+                acc1[o] = (two && g * 8 + o < nrhs) ? yp1[o] : 0.0;
+            }
+            const double *ur0 = us + r * LU_NBO, *ur1 = ur0 + LU_NBO;
+            for (int k = nb - 1; k >= 0; --k) {               // descending k, as the column-oriented dtrsm subtracts
+                const double u0 = ur0[k], u1 = ur1[k];
+                const double *xk = xs + k * XW + g * 8;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const double xv = xk[o];
+                    acc0[o] = __builtin_fma(-u0, xv, acc0[o]);
+                    acc1[o] = __builtin_fma(-u1, xv, acc1[o]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (g * 8 + o < nrhs) {
+                    yp0[o] = acc0[o];
+                    if (two) yp1[o] = acc1[o];
+                }
         }
-}
-
-// rows [row_lo, row_hi) of the right-hand sides, BS_ROWS per workgroup
-__global__ __launch_bounds__(256) void k_lu_backsub_update(double *__restrict__ y, const double *__restrict__ U, long ld, int K0, int nb, int nrhs, LuStride ls,
-                                                            int row_lo, int row_hi)
-{
-    lu_backsub_update_body(y, U, ld, K0, nb, nrhs, ls, row_lo + (int)blockIdx.x * BS_ROWS, row_hi, (int)blockIdx.y);
+        __syncthreads();                                      // (us is restaged for the next group)
+    }
 }
 
 // The same update for the 128 rows right above a solved block only -- the rows the next triangular solve waits for.  There the cost
-// of k_lu_backsub_update is a workgroup's latency (all of X staged by each of 6 workgroups: 31 us), so this launch is cut the other
+// of the tall-workgroup update above is a workgroup's latency (all of X staged by each of 6 workgroups: 31 us), so this launch is cut the other
 // way: 32 rows x 16 right-hand sides per workgroup (48 KB staged in one round trip), two outputs per thread, same descending-k
 // fused multiply-subtracts.
 constexpr int BN_ROWS = 32, BN_COLS = 16;
@@ -1228,16 +1227,16 @@ __global__ __launch_bounds__(256) void k_lu_backsub_near(double *__restrict__ y,
 
 // One step of the back substitution as ONE launch: the first ntr workgroups solve the block at Kt (as k_lu_trsm_mfma<false>), the others
 // apply the block solved in the step before (at Ku = Kt + 128) to the rows above Kt -- the two are independent once the rows of the
-// block at Kt have had that update (k_lu_backsub_update on those 128 rows, the launch before this one), and one after the other
+// block at Kt have had that update (k_lu_backsub_near, the launch before this one), and one after the other
 // on one stream they took 34 + 38 us per step.
 __global__ __launch_bounds__(TRL_T) void k_lu_backsub_step(double *__restrict__ w, long ld, int n_aug, int nrhs, int Kt, int nbt, int Ku, int nbu, int ntr,
-                                                            LuStride ls)
+                                                            int nwu, LuStride ls)
 {
     if ((int)blockIdx.x < ntr)          // (512 threads: eight wavefronts x 16 right-hand sides per solving workgroup)
         lu_trsm_mfma_body<false>(w + (long)Kt * ld + Kt, 1L, ld, w, ld, Kt, nbt, n_aug, n_aug + nrhs, nullptr, nullptr, ls, ls.w, (int)blockIdx.x,
                                  (int)blockIdx.y);
     else
-        lu_backsub_update_body(w + n_aug, w, ld, Ku, nbu, nrhs, ls, ((int)blockIdx.x - ntr) * BS_ROWS, Kt, (int)blockIdx.y);
+        lu_backsub_update_body(w + n_aug, w, ld, Ku, nbu, nrhs, ls, ((int)blockIdx.x - ntr) * BS_ROWS, nwu * BS_ROWS, Kt, (int)blockIdx.y);
 }
 
 template <bool A_KC, bool B_KC>
@@ -1544,6 +1543,7 @@ struct LuSys {                 // scratch and streams of one batch of factorisat
     double **wout_list = nullptr;
     hipStream_t sp = nullptr, sg = nullptr;
     hipEvent_t ev_panel = nullptr, ev_strip = nullptr;
+    int sg_cus = 0;                // CUs S.sg may use
     bool confined = false;         // the panel stream has the reserved CUs to itself (single solves: see lu_sys_alloc)
     LuStride ls{};
 };
@@ -1596,6 +1596,7 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
         int dev = 0, ncu = 0;
         SML_HIP(hipGetDevice(&dev));
         SML_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        s.sg_cus = (reserve > 0 && reserve < ncu) ? ncu - reserve : ncu;
         if (reserve > 0 && reserve < ncu) {
             auto reserved = [&](int cu) { return layout_env == 0 ? cu < reserve : (cu % 8 == 0 && cu / 8 < reserve); };
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u), pm((ncu + 31) / 32, 0u);
@@ -1758,50 +1759,32 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     // back substitution on the right-hand sides (columns n_aug .. ncols of W)
     SML_REQUIRE(n_out <= BS_CG * 8, "sml_train_fit: n_out = %d exceeds the %d right-hand sides of the back substitution kernel", n_out, BS_CG * 8);
     const size_t bs_lds = (size_t)(LU_NBO * BS_CG * 8 + BS_ROWS * LU_NBO) * sizeof(double);
-    static bool bs_attr = false, bs_attr2 = false;
+    static bool bs_attr = false;
     if (!bs_attr) {
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRM_LDS)));
         bs_attr = true;
     }
-    static const bool bs_split = getenv("SML_LU_BACKSUB_SPLIT") ? atoi(getenv("SML_LU_BACKSUB_SPLIT")) != 0 : true;
-    if (!bs_attr2) {
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRM_LDS)));
-        bs_attr2 = true;
-    }
     // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns n_aug .. n_aug + n_out of W
-    const int ntr = (n_out + 63) / 64;
     auto solve_block = [&](int K0) {
-        hipLaunchKernelGGL(k_lu_trsm_mfma<false>, dim3(ntr, nb), dim3(256), TRM_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
+        hipLaunchKernelGGL(k_lu_trsm_mfma<false>, dim3((n_out + 63) / 64, nb), dim3(256), TRM_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
                            std::min(LU_NBO, n_aug - K0), n_aug, n_aug + n_out, (const int *)nullptr, (const int *)nullptr, ls, ls.w);
     };
-    auto update_rows = [&](int K0, int lo, int hi) {          // rows lo .. hi -= U(., block at K0) X(block at K0)
-        hipLaunchKernelGGL(k_lu_backsub_update, dim3((hi - lo + BS_ROWS - 1) / BS_ROWS, nb), dim3(256), bs_lds, S.sg, S.w + n_aug, S.w, ld, K0,
-                           std::min(LU_NBO, n_aug - K0), n_out, ls, lo, hi);
-    };
-    const int K_last = ((n_aug - 1) / LU_NBO) * LU_NBO;
-    if (!bs_split) {
-        for (int K0 = K_last; K0 >= 0; K0 -= LU_NBO) {
-            solve_block(K0);
-            if (K0 > 0) update_rows(K0, 0, K0);
-            SML_HIP(hipGetLastError());
-        }
-    } else {
-        // per step: the 128 rows of the next block get the update first (they are what the chain waits for), then ONE launch solves
-        // that block and updates the rows above it
-        solve_block(K_last);
-        for (int K0 = K_last; K0 > 0; K0 -= LU_NBO) {
-            const int Kn = K0 - LU_NBO;
-            hipLaunchKernelGGL(k_lu_backsub_near, dim3(LU_NBO / BN_ROWS, (n_out + BN_COLS - 1) / BN_COLS, nb), dim3(256), 0, S.sg, S.w + n_aug, S.w, ld, K0,
-                               std::min(LU_NBO, n_aug - K0), n_out, Kn, ls);
-            if (Kn > 0) {
-                const int ntm = (n_out + 127) / 128;
-                hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntm + (Kn + BS_ROWS - 1) / BS_ROWS, nb), dim3(TRL_T), std::max(bs_lds, TRM_LDS), S.sg, S.w, ld, n_aug,
-                                   n_out, Kn, LU_NBO, K0, std::min(LU_NBO, n_aug - K0), ntm, ls);
-            }
-            else
-                solve_block(0);
-            SML_HIP(hipGetLastError());
-        }
+    // per step: the 128 rows of the next block get the update first (they are what the chain waits for), then ONE launch solves that
+    // block and updates the rows above it (one workgroup per CU: at most as many far-update workgroups as S.sg has CUs left)
+    const int K_last = ((n_aug - 1) / LU_NBO) * LU_NBO, ntm = (n_out + 127) / 128;
+    solve_block(K_last);
+    for (int K0 = K_last; K0 > 0; K0 -= LU_NBO) {
+        const int Kn = K0 - LU_NBO;
+        hipLaunchKernelGGL(k_lu_backsub_near, dim3(LU_NBO / BN_ROWS, (n_out + BN_COLS - 1) / BN_COLS, nb), dim3(256), 0, S.sg, S.w + n_aug, S.w, ld, K0,
+                           std::min(LU_NBO, n_aug - K0), n_out, Kn, ls);
+        if (Kn > 0) {
+            const int groups = (Kn + BS_ROWS - 1) / BS_ROWS;
+            const int nwu = nb == 1 ? std::min(groups, std::max(1, S.sg_cus - ntm)) : groups;
+            hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntm + nwu, nb), dim3(TRL_T), std::max(bs_lds, TRM_LDS), S.sg, S.w, ld, n_aug, n_out, Kn, LU_NBO, K0,
+                               std::min(LU_NBO, n_aug - K0), ntm, nwu, ls);
+        } else
+            solve_block(0);
+        SML_HIP(hipGetLastError());
     }
     const long tw = (long)n_aug * n_out;
     hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256), nb), dim3(256), 0, S.sg, S.w, ld, S.wout_list, n_aug, n_out, ls);

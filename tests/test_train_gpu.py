@@ -100,6 +100,24 @@ def test_fit_general_matrix_needs_pivoting():
     assert np.max(np.abs(wg - want)) <= 1e-9 * np.max(np.abs(want))
 
 
+@pytest.mark.parametrize("n,n_out", [(700, 130), (385, 17), (128, 64)])
+def test_fit_indefinite_systems_against_lapack(n, n_out):
+    """Symmetric indefinite systems (every panel interchanges rows, displaced rows travel through the composite permutation) with
+    full, ragged and multi-workgroup right-hand-side blocks: the blocked back substitution's near / step launches at sizes the host
+    LAPACK solves in milliseconds."""
+    rng = np.random.default_rng(1000 + n)
+    a = rng.standard_normal((n, n))
+    a = a + a.T
+    a[np.arange(0, n, 7), np.arange(0, n, 7)] = 0.0
+    bmat = rng.standard_normal((n_out, n))
+    wg = to_host(train.fit_chunk_hybrid(to_dev(a), to_dev(bmat), n, 0, n_out, 0.0, 0.0, 0.0, False))
+    want = np.linalg.solve(a.T, bmat.T).T
+    resid = a.T @ wg.T - bmat.T
+    eta = np.linalg.norm(resid) / (np.linalg.norm(a) * np.linalg.norm(wg) + np.linalg.norm(bmat))
+    assert eta <= 1e-15, eta
+    assert np.max(np.abs(wg - want)) <= 1e-8 * np.max(np.abs(want))
+
+
 def test_singular_matrix_fails_loudly():
     from speedy_ml_amd._lib import SmlError
     n, n_out = 64, 2
