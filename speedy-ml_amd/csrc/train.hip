@@ -528,7 +528,7 @@ __global__ void k_symmetrize_diag(double *__restrict__ c, int n)
 //
 // Schedule per outer panel (two streams; `P` = panel chain, `G` = everything else):
 //   P: 16 x [ k_lu_leaf   : ONE workgroup factorises 8 columns held entirely in registers (<= 7 rows x 8 columns per thread):
-//                           one global read and one global write of the leaf, two barriers per pivot.  The same workgroup
+//                           one global read and one global write of the leaf, one barrier per pivot.  The same workgroup
 //                           applies each interchange to the panel's other columns and finishes U (8 x 120) of the leaf's rows.
 //             k_lu_panel_update : rank-8 update of the panel's remaining columns, all CUs ]
 //   G: k_lu_perm_src (the composite permutation of the panel's 128 interchanges on the <= 256 rows they touch: no dependent chain of
@@ -536,6 +536,8 @@ __global__ void k_symmetrize_diag(double *__restrict__ c, int n)
 //      k_lu_trsm_mfma<true> (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
 //      K = 128: FIRST the next panel's 128 columns (+ k_lu_strip_to_panel, which hands them to P), THEN the rest, which runs
 //      beside the next panel's leaf chain (look-ahead).
+// Back substitution, per 128-row block from the bottom: k_lu_backsub_near (the block above gets the solved block's update), then
+// k_lu_backsub_step (that block solved beside the update of all rows above it).
 // The previous form (32-wide panel in one workgroup that walked the panel through memory for every sub-panel, one dependent
 // chain of 32 row swaps per column, trailing updates at K = 32) spent 64 % of an 84 ms factorisation in the panel kernel.
 constexpr int LU_NBO = 128;    // outer panel width = K of the trailing update
