@@ -1600,7 +1600,11 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
         SML_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         s.sg_cus = (reserve > 0 && reserve < ncu) ? ncu - reserve : ncu;
         if (reserve > 0 && reserve < ncu) {
-            auto reserved = [&](int cu) { return layout_env == 0 ? cu < reserve : (cu % 8 == 0 && cu / 8 < reserve); };
+            // (mask bit i is CU i / 8 of XCD i % 8.  layout 0: the first `reserve` bits = reserve / 8 CUs of every XCD; 1: CUs of XCD 0 only;
+            //  2: whole XCDs -- all CUs of the first reserve / 32 XCDs)
+            auto reserved = [&](int cu) {
+                return layout_env == 0 ? cu < reserve : layout_env == 1 ? (cu % 8 == 0 && cu / 8 < reserve) : (cu % 8) < reserve / 32;
+            };
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u), pm((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (reserved(i) ? pm : mask)[i / 32] |= 1u << (i % 32);
             SML_HIP(hipExtStreamCreateWithCUMask(&s.sg, (uint32_t)mask.size(), mask.data()));
