@@ -38,7 +38,25 @@ def parse():
     ap.add_argument("--slab", action="store_true", help="BASELINE config 5: add the 1152-region slab-ocean reservoirs and their coupling")
     ap.add_argument("--no-physics", action="store_true", help="adiabatic SPEEDY window (development aid: isolates the cost of the column physics)")
     ap.add_argument("--regions", type=int, default=1152, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)     # launch + rendezvous only (CPU test of the N > 1 launch)
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the ranks ourselves, as a CHILD
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU over RCCL), relay its output and
+    exit code.  Nothing here touches the GPU, and the launcher is a child process, never an exec of this one."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(model, budget_s=12.0):
@@ -276,6 +294,8 @@ def training_block(with_cpu):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
@@ -287,6 +307,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        # launch + rendezvous only, no GPU: every rank joins a gloo group and rank 0 prints who arrived
+        if world > 1:
+            dist.init_process_group("gloo")
+            seen = [None] * world
+            dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank})
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            seen = [{"rank": rank, "local_rank": local_rank}]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm).  SML_DIST_BACKEND=gloo lets several ranks share one GPU so that

@@ -89,3 +89,34 @@ def test_training_shards_are_disjoint_and_complete(world, tmp_path):
         assert complete == 1 and groups_ok == 1
         total += int(n)
     assert total == NREG
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """The driver runs `python bench.py --gpus N ...` with no launcher around it: bench.py must start the N ranks itself (a child
+    torch.distributed.run, never an exec).  --dry-run stops after the rendezvous, so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SML_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and sorted(r["rank"] for r in line["ranks"]) == [0, 1]
+    assert sorted(r["local_rank"] for r in line["ranks"]) == [0, 1]
+
+
+def test_bench_gpus_n_relays_a_failing_rank():
+    """... and the child's exit code comes back: without a GPU the ranks refuse to run (there is no CPU fallback)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "no HIP device visible" in p.stderr
