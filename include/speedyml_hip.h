@@ -246,6 +246,13 @@ int sml_handoff_check(const double *fields_dev, int32_t *safe_dev, void *stream)
 typedef struct sml_comm sml_comm;
 int sml_comm_unique_id(char *id128);
 int sml_comm_create(int nranks, int rank, const char *id128, sml_comm **out);
+/* For a host without MPI (this image has no Fortran MPI module; the drop-in's startmpi takes rank and rank count from the launcher's
+ * environment): every rank of ONE node calls this with the same `name`.  SML_COMM_TRANSPORT=rccl (default): rank 0 draws the RCCL id
+ * and leaves it in /dev/shm/<name>.id for the others -- what MPI_Bcast does in an MPI build -- then sml_comm_create.
+ * SML_COMM_TRANSPORT=shm: a host-staged all-gather through a POSIX shared-memory segment, for REHEARSING the multi-rank path with
+ * several ranks on one GPU (RCCL refuses two ranks on one device); never used for numbers.  max_doubles_per_rank bounds one rank's
+ * contribution to a collective (shm only; 0 = 512 Ki doubles). */
+int sml_comm_bootstrap(int nranks, int rank, const char *name, uint64_t max_doubles_per_rank, sml_comm **out);
 int sml_comm_destroy(sml_comm *comm);
 int sml_comm_allgather_outvec(sml_comm *comm, sml_bank *bank, int number_of_regions, double *all_outvec_dev, void *stream);
 int sml_comm_unpack_regions(const double *stage_dev, int nranks, int slots_per_rank, int number_of_regions, int max_n_out,
@@ -279,6 +286,22 @@ int sml_hybrid_attach_physics(sml_hybrid *h, const double *hsg9, const double *r
 int sml_hybrid_initial_inputs(sml_hybrid *h, void *stream);
 int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream);
 int sml_hybrid_safe(sml_hybrid *h, int *safe_out);
+/* ---- the `ocean_model` branches and the rank exchange inside the engine (src/mpires.f90:286-330,347-454,470-484,756-790) ----
+ *   attach_slab : the rank's slab-ocean bank beside its atmosphere bank (slot i of both = region_of_slot[i]; slab slots are loaded
+ *                 for SST-predicting regions only).  sea_of_slot[nslots] / sea_of_region[number_of_regions] = sst_bool_prediction;
+ *                 timestep_slab_hours = 168 as shipped.  Every later exchange assembles wholegrid_sst from the slab reservoirs' last
+ *                 outputs (272 K where a region has none), applies the mask / floor, and keeps the slab inputs' averaging ring.
+ *   set_comm    : with a communicator (sml_comm_create / sml_comm_bootstrap) an exchange whose all_outvec_dev is NULL all-gathers the
+ *                 banks' outvec buffers (sml_comm_allgather_outvec) instead of placing this rank's rows only.  Not owned.
+ *   restart     : a new forecast (program main's prediction_num loop): step counter, forcing calendar and range guard start over
+ *   slab_due    : 1 when mod(t * timestep, timestep_slab) == 0 for the step about to be taken (src/parallelmain.f90:238)
+ *   step        : one whole iteration of program main's t loop for this rank: predict of every resident reservoir, predict_slab_ml
+ *                 of the slab bank when due, then exchange_and_speedy(NULL, leapfrog_steps) */
+int sml_hybrid_attach_slab(sml_hybrid *h, sml_bank *slab_bank, const int32_t *sea_of_slot, const int32_t *sea_of_region, int timestep_slab_hours);
+int sml_hybrid_set_comm(sml_hybrid *h, sml_comm *comm);
+int sml_hybrid_restart(sml_hybrid *h, int start_hours);
+int sml_hybrid_slab_due(sml_hybrid *h);
+int sml_hybrid_step(sml_hybrid *h, int leapfrog_steps, void *stream);
 double *sml_hybrid_g_dev(sml_hybrid *h);
 double *sml_hybrid_f_dev(sml_hybrid *h);
 

@@ -55,10 +55,10 @@ EXPORTS = [
     "sml_bank_predict_all", "sml_bank_predict_one", "sml_bank_synchronize_all", "sml_bank_synchronize_one", "sml_bank_advance_all", "sml_bank_readout_part",
     "sml_bank_algorithmic_bytes", "sml_bank_readout_part_bytes", "sml_bank_timing", "sml_bank_timing_collect",
     "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
-    "sml_comm_unique_id", "sml_comm_create", "sml_comm_destroy", "sml_comm_allgather_outvec", "sml_comm_unpack_regions",
+    "sml_comm_unique_id", "sml_comm_create", "sml_comm_bootstrap", "sml_comm_destroy", "sml_comm_allgather_outvec", "sml_comm_unpack_regions",
     "sml_hybrid_create", "sml_hybrid_destroy", "sml_hybrid_set_state", "sml_hybrid_get_state", "sml_hybrid_set_base_sst", "sml_hybrid_set_orography",
     "sml_hybrid_set_tisr_table", "sml_hybrid_attach_physics", "sml_hybrid_initial_inputs", "sml_hybrid_exchange_and_speedy", "sml_hybrid_safe",
-    "sml_hybrid_g_dev", "sml_hybrid_f_dev",
+    "sml_hybrid_g_dev", "sml_hybrid_f_dev", "sml_hybrid_attach_slab", "sml_hybrid_set_comm", "sml_hybrid_restart", "sml_hybrid_slab_due", "sml_hybrid_step",
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_predict_hybrid", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",
@@ -89,10 +89,8 @@ def lib():
         getattr(L, name).restype = C.c_void_p
         getattr(L, name).argtypes = [C.c_void_p]
     _lib = L
-    # The ridge solver keeps streams (one of them CU-masked) and scratch between calls; give them back while the HIP runtime is
-    # still up (rocprofv3 crashes at process exit when a CU-masked stream is still alive: seen with --kernel-trace on ROCm 7.2).
-    import atexit
-    atexit.register(L.sml_train_release_workspace)
+    # (CU-masked streams -- the ridge solver's, sml_stream_create_cu_mask's -- are released by an exit handler the LIBRARY registers
+    # at the first such stream, csrc/bank.hip, so that non-Python hosts are covered too; nothing to do here.)
     return L
 
 

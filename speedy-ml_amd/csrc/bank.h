@@ -48,4 +48,7 @@ struct sml_bank {
 
 namespace sml {
 int bank_sync_descs(sml_bank *b);
+// CU-masked streams go through a registry whose exit handler destroys the ones still alive (see bank.hip)
+int masked_stream_create(hipStream_t *out, const uint32_t *mask, int nwords);
+int masked_stream_destroy(hipStream_t st);
 }

@@ -662,6 +662,56 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
 
 }  // namespace
 
+// ---- CU-masked streams and process exit ----
+// A process that ends while a CU-masked stream (hipExtStreamCreateWithCUMask) is still alive crashes inside the runtime's own
+// finalisation when rocprofv3 is attached (SIGSEGV in __cxa_finalize after the tool's finalisation, ROCm 7.2; seen with the ridge
+// solver's trailing stream).  Every masked stream of the library is therefore created through this registry, and the first one
+// registers ONE exit handler -- inside the library, so that every host is covered, a Fortran program as much as Python -- that
+// releases the ridge solver's workspace and destroys whatever masked stream its owner left behind.  The handler is registered
+// after the HIP runtime came up (a stream was just created), so at exit it runs before the runtime's own handlers.
+namespace sml {
+namespace {
+std::vector<hipStream_t> &masked_streams()
+{
+    static std::vector<hipStream_t> *v = new std::vector<hipStream_t>;      // (never destroyed: the exit handler may run late)
+    return *v;
+}
+
+void exit_cleanup()
+{
+    (void)sml_train_release_workspace();
+    std::vector<hipStream_t> left;
+    left.swap(masked_streams());
+    for (hipStream_t st : left) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
+}
+}  // namespace
+
+int masked_stream_create(hipStream_t *out, const uint32_t *mask, int nwords)
+{
+    static bool registered = false;
+    SML_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)nwords, mask));
+    masked_streams().push_back(*out);
+    if (!registered) {
+        registered = true;
+        atexit(exit_cleanup);
+    }
+    return SML_OK;
+}
+
+int masked_stream_destroy(hipStream_t st)
+{
+    if (!st) return SML_OK;
+    auto &v = masked_streams();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == st) { v.erase(v.begin() + i); break; }
+    SML_HIP(hipStreamDestroy(st));
+    return SML_OK;
+}
+}  // namespace sml
+
 extern "C" {
 
 const char *sml_last_error(void) { return sml::last_error_ref().c_str(); }
@@ -680,21 +730,22 @@ int sml_set_device(int ordinal)
     return SML_OK;
 }
 
-// device memory for hosts that have no HIP binding of their own (the Fortran drop-ins): plain hipMalloc / hipMemcpy
 int sml_stream_create_cu_mask(const uint32_t *mask, int nwords, void **stream_out)
 {
     SML_REQUIRE(mask && nwords > 0 && stream_out, "sml_stream_create_cu_mask: bad arguments");
     hipStream_t st = nullptr;
-    SML_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask));
+    int rc = sml::masked_stream_create(&st, mask, nwords);
+    if (rc) return rc;
     *stream_out = (void *)st;
     return SML_OK;
 }
 
 int sml_stream_destroy(void *stream)
 {
-    if (stream) SML_HIP(hipStreamDestroy((hipStream_t)stream));
-    return SML_OK;
+    return sml::masked_stream_destroy((hipStream_t)stream);
 }
+
+// device memory for hosts that have no HIP binding of their own (the Fortran drop-ins): plain hipMalloc / hipMemcpy
 
 int sml_dev_alloc(uint64_t bytes, void **out_dev)
 {

@@ -5,6 +5,14 @@
 // librccl is resolved with dlopen at the first call, not at link time: inside a Python process torch has already loaded its
 // own copy and a second, link-time copy of the library would give the process two RCCL runtimes.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 
 #include "bank.h"
 
@@ -59,14 +67,69 @@ int check(Rccl *r, int rc, const char *what)
 
 }  // namespace
 
+// Host-staged transport (rehearsal only): the ranks of one node meet in a POSIX shared-memory segment.  RCCL refuses two ranks on
+// one device, so a box with ONE GPU can run the multi-rank path only this way (as bench.py's SML_DIST_BACKEND=gloo does for the
+// Python host); numbers are never taken with it.
+struct ShmHeader {
+    std::atomic<int> magic, arrive, generation, id_ready;
+    char id[128];
+    unsigned long long doubles_per_rank;
+};
+constexpr int SHM_MAGIC = 0x534d4c43;
+
 struct sml_comm {
     void *comm = nullptr;
     int nranks = 0, rank = 0;
     double *send = nullptr, *stage = nullptr;          // padded contribution / gathered slabs of the ragged split
     size_t send_count = 0, stage_count = 0;
+    // shm transport
+    ShmHeader *hdr = nullptr;
+    double *shm_data = nullptr;
+    size_t shm_bytes = 0;
+    std::string shm_name, id_file;
 };
 
 namespace {
+
+int shm_barrier(sml_comm *c)
+{
+    ShmHeader *h = c->hdr;
+    const int g = h->generation.load();
+    if (h->arrive.fetch_add(1) + 1 == c->nranks) {
+        h->arrive.store(0);
+        h->generation.fetch_add(1);
+        return SML_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (h->generation.load() == g) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+            return sml::fail(SML_ERR_STATE, "sml_comm (shm): rank %d waited 120 s for its peers at a barrier", c->rank);
+    }
+    return SML_OK;
+}
+
+// every rank's `count` doubles -> [nranks][count] on every rank, through the host
+int shm_all_gather(sml_comm *c, const double *send_dev, double *recv_dev, size_t count, hipStream_t st)
+{
+    if (count > c->hdr->doubles_per_rank) return sml::fail(SML_ERR_ARG, "sml_comm (shm): %zu doubles per rank exceed the segment's %llu", count, c->hdr->doubles_per_rank);
+    SML_HIP(hipMemcpyAsync(c->shm_data + (size_t)c->rank * count, send_dev, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    SML_HIP(hipStreamSynchronize(st));
+    int rc = shm_barrier(c);
+    if (rc) return rc;
+    SML_HIP(hipMemcpyAsync(recv_dev, c->shm_data, count * c->nranks * sizeof(double), hipMemcpyHostToDevice, st));
+    SML_HIP(hipStreamSynchronize(st));
+    return shm_barrier(c);                      // nobody overwrites its block before everyone has read it
+}
+
+int comm_all_gather(sml_comm *c, const double *send_dev, double *recv_dev, size_t count, hipStream_t st)
+{
+    if (c->hdr) return shm_all_gather(c, send_dev, recv_dev, count, st);
+    Rccl *r;
+    int rc = load(&r);
+    if (rc) return rc;
+    return check(r, r->all_gather(send_dev, recv_dev, count, NCCL_FLOAT64, c->comm, st), "ncclAllGather");
+}
 
 // all_out[r][:] = stage[owner(r)][slot(r)][:]  (sml_domain_region_owner's rule)
 __global__ void k_unpack_regions(const double *__restrict__ stage, int nranks, int slots, int nreg, int width, double *__restrict__ all_out)
@@ -112,11 +175,96 @@ int sml_comm_create(int nranks, int rank, const char *id128, sml_comm **out)
     return SML_OK;
 }
 
+/* For hosts without MPI (the image has no Fortran MPI module): all ranks of ONE node call this with the same `name`.
+ * Transport from the environment: SML_COMM_TRANSPORT=rccl (default) -- rank 0 draws the RCCL id and leaves it in /dev/shm/<name>.id
+ * for the others (what MPI_Bcast does in an MPI build), then sml_comm_create; =shm -- the host-staged rehearsal transport above
+ * (several ranks on one GPU).  max_doubles_per_rank bounds one rank's contribution to a collective (shm only). */
+int sml_comm_bootstrap(int nranks, int rank, const char *name, uint64_t max_doubles_per_rank, sml_comm **out)
+{
+    SML_REQUIRE(out && name && *name && nranks >= 1 && rank >= 0 && rank < nranks, "sml_comm_bootstrap: bad arguments");
+    const char *tr = getenv("SML_COMM_TRANSPORT");
+    const bool shm = tr && !strcmp(tr, "shm");
+    const auto t0 = std::chrono::steady_clock::now();
+    auto timed_out = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120); };
+    if (!shm) {
+        const std::string path = std::string("/dev/shm/") + name + ".id";
+        char id[ID_BYTES];
+        if (rank == 0) {
+            int rc = sml_comm_unique_id(id);
+            if (rc) return rc;
+            const std::string tmp = path + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, ID_BYTES, f) != ID_BYTES) { if (f) fclose(f); return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot write %s", tmp.c_str()); }
+            fclose(f);
+            if (rename(tmp.c_str(), path.c_str())) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot publish %s", path.c_str());
+        } else {
+            for (;;) {
+                FILE *f = fopen(path.c_str(), "rb");
+                if (f) {
+                    const size_t got = fread(id, 1, ID_BYTES, f);
+                    fclose(f);
+                    if (got == ID_BYTES) break;
+                }
+                if (timed_out()) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d waited 120 s for %s", rank, path.c_str());
+                usleep(2000);
+            }
+        }
+        int rc = sml_comm_create(nranks, rank, id, out);
+        if (!rc && rank == 0) (*out)->id_file = path;
+        return rc;
+    }
+    const std::string shm_name = std::string("/") + name;
+    const size_t per = max_doubles_per_rank ? (size_t)max_doubles_per_rank : (size_t)1 << 19;
+    const size_t bytes = sizeof(ShmHeader) + 64 + per * nranks * sizeof(double);
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(shm_name.c_str());
+        fd = shm_open(shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes)) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot create shared memory %s", shm_name.c_str());
+    } else {
+        for (;;) {
+            fd = shm_open(shm_name.c_str(), O_RDWR, 0600);
+            struct stat sb;
+            if (fd >= 0 && !fstat(fd, &sb) && (size_t)sb.st_size >= bytes) break;
+            if (fd >= 0) close(fd);
+            if (timed_out()) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d waited 120 s for shared memory %s", rank, shm_name.c_str());
+            usleep(2000);
+        }
+    }
+    void *mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: mmap of %s failed", shm_name.c_str());
+    sml_comm *c = new sml_comm;
+    c->nranks = nranks; c->rank = rank; c->hdr = (ShmHeader *)mem; c->shm_bytes = bytes; c->shm_name = shm_name;
+    c->shm_data = (double *)((char *)mem + ((sizeof(ShmHeader) + 63) & ~(size_t)63));
+    if (rank == 0) {
+        c->hdr->arrive.store(0); c->hdr->generation.store(0); c->hdr->id_ready.store(0);
+        c->hdr->doubles_per_rank = per;
+        c->hdr->magic.store(SHM_MAGIC);
+    } else {
+        while (c->hdr->magic.load() != SHM_MAGIC) {
+            if (timed_out()) { munmap(mem, bytes); delete c; return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d: segment %s never initialised", rank, shm_name.c_str()); }
+            usleep(1000);
+        }
+    }
+    int rc = shm_barrier(c);
+    if (rc) { munmap(mem, bytes); delete c; return rc; }
+    *out = c;
+    return SML_OK;
+}
+
 int sml_comm_destroy(sml_comm *c)
 {
     if (!c) return SML_OK;
+    if (c->hdr) {
+        (void)shm_barrier(c);                   // (a rank that is still reading keeps the segment mapped; the name can go)
+        if (c->rank == 0) (void)shm_unlink(c->shm_name.c_str());
+        munmap((void *)c->hdr, c->shm_bytes);
+        c->hdr = nullptr;
+    }
+    if (!c->id_file.empty()) (void)unlink(c->id_file.c_str());
     Rccl *r;
-    if (load(&r) == SML_OK && c->comm) (void)r->destroy(c->comm);
+    if (c->comm && load(&r) == SML_OK) (void)r->destroy(c->comm);
     if (c->send) (void)hipFree(c->send);
     if (c->stage) (void)hipFree(c->stage);
     delete c;
@@ -140,9 +288,7 @@ int sml_comm_unpack_regions(const double *stage_dev, int nranks, int slots_per_r
 int sml_comm_allgather_outvec(sml_comm *c, sml_bank *bank, int number_of_regions, double *all_outvec_dev, void *stream)
 {
     SML_REQUIRE(c && bank && all_outvec_dev && number_of_regions > 0, "sml_comm_allgather_outvec: bad arguments");
-    Rccl *r;
-    int rc = load(&r);
-    if (rc) return rc;
+    int rc;
     hipStream_t st = sml::as_stream(stream);
     const int per = number_of_regions / c->nranks, left = number_of_regions % c->nranks;
     const int mine = per + ((c->rank >= 1 && c->rank <= left) ? 1 : 0);
@@ -150,7 +296,7 @@ int sml_comm_allgather_outvec(sml_comm *c, sml_bank *bank, int number_of_regions
                 c->nranks, mine, number_of_regions);
     const size_t width = (size_t)bank->max_n_out;
     if (left == 0 && bank->capacity == per)       // equal blocks: the gathered slab IS the region-ordered slab
-        return check(r, r->all_gather(bank->d_outvec, all_outvec_dev, (size_t)per * width, NCCL_FLOAT64, c->comm, st), "ncclAllGather");
+        return comm_all_gather(c, bank->d_outvec, all_outvec_dev, (size_t)per * width, st);
     // ragged (or an over-sized bank): every rank contributes per + 1 slots; its own first `mine` are real
     const int slots = per + 1;
     const size_t send_count = (size_t)slots * width, stage_count = send_count * c->nranks;
@@ -166,7 +312,7 @@ int sml_comm_allgather_outvec(sml_comm *c, sml_bank *bank, int number_of_regions
         c->stage_count = stage_count;
     }
     SML_HIP(hipMemcpyAsync(c->send, bank->d_outvec, (size_t)mine * width * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if ((rc = check(r, r->all_gather(c->send, c->stage, send_count, NCCL_FLOAT64, c->comm, st), "ncclAllGather"))) return rc;
+    if ((rc = comm_all_gather(c, c->send, c->stage, send_count, st))) return rc;
     return sml_comm_unpack_regions(c->stage, c->nranks, slots, number_of_regions, bank->max_n_out, all_outvec_dev, stream);
 }
 

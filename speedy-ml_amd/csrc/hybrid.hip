@@ -31,6 +31,14 @@ struct sml_hybrid {
     int32_t *sea_mask = nullptr, *in_scale = nullptr, *in_desc = nullptr, *out_desc = nullptr, *safe = nullptr;
     int32_t *region_index = nullptr;
     int start_hours = 12000 + 24 * 14, timestep_hours = 6, t = 0, phys_day = -1;
+    // optional: the rank exchange (RCCL all-gather of the outvec slabs) and the slab-ocean coupling (config 5)
+    sml_comm *comm = nullptr;
+    sml_bank *slab_bank = nullptr;
+    sml_slab *slab = nullptr;
+    double *all_slab_out = nullptr;          // [nreg][slab_bank->max_n_out], region order
+    int32_t *sea_of_region = nullptr;        // [nreg] on the device
+    int slab_every = 0;                      // timestep_slab / timestep
+    std::vector<int32_t> regions, sst_input;
     std::vector<void *> owned;
 };
 
@@ -68,6 +76,7 @@ extern "C" {
 int sml_hybrid_destroy(sml_hybrid *h)
 {
     if (!h) return SML_OK;
+    if (h->slab) (void)sml_slab_destroy(h->slab);
     if (h->ex) (void)sml_exchange_destroy(h->ex);
     if (h->dyn) (void)sml_dyn_destroy(h->dyn);
     if (h->phys) (void)sml_phys_destroy(h->phys);
@@ -83,6 +92,8 @@ int sml_hybrid_create(sml_bank *bank, int number_of_regions, const int32_t *regi
     SML_REQUIRE(bank && region_of_slot && sst_input_of_slot && out && nslots > 0 && number_of_regions >= nslots, "sml_hybrid_create: bad arguments");
     sml_hybrid *h = new sml_hybrid;
     h->bank = bank; h->nreg = number_of_regions; h->nslots = nslots;
+    h->regions.assign(region_of_slot, region_of_slot + nslots);
+    h->sst_input.assign(sst_input_of_slot, sst_input_of_slot + nslots);
     int rc;
 #define HY(call) do { rc = (call); if (rc) { sml_hybrid_destroy(h); return rc; } } while (0)
     HY(sml_exchange_create(bank, number_of_regions, region_of_slot, nslots, overlap, precip_bool, sst_input_of_slot, &h->ex));
@@ -232,12 +243,22 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
     hipStream_t st = sml::as_stream(stream);
     int rc;
     const double *slab = all_outvec_dev;
+    auto place = [&](const sml_bank *bank, double *all) {       // this rank's rows into the region-ordered slab (the others keep theirs)
+        const long total = (long)h->nslots * bank->max_n_out;
+        hipLaunchKernelGGL(k_place_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double *)bank->d_outvec, h->region_index, h->nslots,
+                           bank->max_n_out, all);
+    };
     if (!slab) {
-        const long total = (long)h->nslots * h->max_n_out;
-        hipLaunchKernelGGL(k_place_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double *)h->bank->d_outvec, h->region_index, h->nslots,
-                           h->max_n_out, h->all_out);
-        SML_HIP(hipGetLastError());
+        // the gather-to-root of src/mpires.f90:347-454: with a communicator, ONE all-gather of the outvec slab; a single rank places its rows
+        if (h->comm) { if ((rc = sml_comm_allgather_outvec(h->comm, h->bank, h->nreg, h->all_out, stream))) return rc; }
+        else { place(h->bank, h->all_out); SML_HIP(hipGetLastError()); }
         slab = h->all_out;
+    }
+    if (h->slab) {
+        // the slab reservoirs' last outputs keep being gathered between their steps (src/mpires.f90:367-395); SST assembly (:309-330)
+        if (h->comm) { if ((rc = sml_comm_allgather_outvec(h->comm, h->slab_bank, h->nreg, h->all_slab_out, stream))) return rc; }
+        else { place(h->slab_bank, h->all_slab_out); SML_HIP(hipGetLastError()); }
+        if ((rc = sml_slab_scatter_sst(h->slab, h->all_slab_out, h->slab_bank->max_n_out, h->sea_of_region, h->G, stream))) return rc;
     }
     if ((rc = sml_exchange_scatter(h->ex, slab, h->G, h->base_sst, h->sea_mask, stream))) return rc;
     // iogrid(30)
@@ -266,7 +287,73 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
     // next inputs: get_tisr_by_date(timestep - 1) (src/mpires.f90:750), then tile + standardise
     h->t += 1;
     if ((rc = tisr_to_G(h, h->t - 1, st))) return rc;
-    return sml_exchange_gather(h->ex, h->G, h->F, stream);
+    if ((rc = sml_exchange_gather(h->ex, h->G, h->F, stream))) return rc;
+    // the slab reservoirs' inputs: ring column mod(timestep - 1, R) + 1 and the running mean (src/mpires.f90:776-781)
+    if (h->slab) return sml_slab_update_inputs(h->slab, h->t, stream);
+    return SML_OK;
+}
+
+/* The `ocean_model` branches of sendrecievegrid (src/mpires.f90:286-330,470-484,756-790) for an engine whose atmosphere bank has a
+ * slab bank beside it (slot i of both = region_of_slot[i]; slab slots loaded for the regions that predict SST only).
+ *   sea_of_slot / sea_of_region: sst_bool_prediction of this rank's slots and of EVERY region (regions without a slab model get
+ *   272 K, :315-328); timestep_slab_hours: 168 as shipped (src/mod_reservoir.f90:37).
+ * From then on every exchange assembles the SST grid from the slab reservoirs' last outputs and keeps their inputs (ring of
+ * timestep_slab / timestep - 1 columns) up to date; sml_hybrid_step also fires predict_slab_ml every timestep_slab / timestep-th step. */
+int sml_hybrid_attach_slab(sml_hybrid *h, sml_bank *slab_bank, const int32_t *sea_of_slot, const int32_t *sea_of_region, int timestep_slab_hours)
+{
+    SML_REQUIRE(h && slab_bank && sea_of_slot && sea_of_region && timestep_slab_hours > 0, "sml_hybrid_attach_slab: bad arguments");
+    SML_REQUIRE(timestep_slab_hours % h->timestep_hours == 0 && timestep_slab_hours / h->timestep_hours >= 2,
+                "sml_hybrid_attach_slab: timestep_slab = %d h is not a multiple (>= 2) of the %d-hour step", timestep_slab_hours, h->timestep_hours);
+    SML_REQUIRE(!h->slab, "sml_hybrid_attach_slab: a slab bank is already attached");
+    h->slab_every = timestep_slab_hours / h->timestep_hours;
+    int rc = sml_slab_create(h->bank, slab_bank, h->nreg, h->regions.data(), h->nslots, sea_of_slot, h->sst_input.data(), h->slab_every - 1, &h->slab);
+    if (rc) return rc;
+    h->slab_bank = slab_bank;
+    if ((rc = dalloc(h, &h->all_slab_out, (size_t)h->nreg * slab_bank->max_n_out))) return rc;
+    if ((rc = dalloc(h, &h->sea_of_region, (size_t)h->nreg))) return rc;
+    SML_HIP(hipMemcpy(h->sea_of_region, sea_of_region, sizeof(int32_t) * h->nreg, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+/* the rank exchange: from now on an exchange without a caller-supplied slab all-gathers the banks' outvec buffers over `comm`
+ * (sml_comm_create / sml_comm_bootstrap; NULL detaches).  The engine does not own the communicator. */
+int sml_hybrid_set_comm(sml_hybrid *h, sml_comm *comm)
+{
+    SML_REQUIRE(h, "sml_hybrid_set_comm: null handle");
+    h->comm = comm;
+    return SML_OK;
+}
+
+/* a new forecast from the same engine (program main's prediction_num loop, src/parallelmain.f90:206): the step counter, the calendar
+ * of the physics' daily forcing and the range guard start over; start_hours = traininglength + prediction marker + synclength of the
+ * new forecast.  The caller reloads G (sml_hybrid_set_state) and the reservoirs' states / first inputs. */
+int sml_hybrid_restart(sml_hybrid *h, int start_hours)
+{
+    SML_REQUIRE(h, "sml_hybrid_restart: null handle");
+    h->start_hours = start_hours;
+    h->t = 0;
+    h->phys_day = -1;
+    const int32_t one = 1;
+    SML_HIP(hipDeviceSynchronize());
+    SML_HIP(hipMemcpy(h->safe, &one, sizeof one, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+/* mod(t * timestep, timestep_slab) == 0 for the step about to be taken (src/parallelmain.f90:238): 1 when the slab reservoirs predict */
+int sml_hybrid_slab_due(sml_hybrid *h)
+{
+    return (h && h->slab && (h->t + 1) % h->slab_every == 0) ? 1 : 0;
+}
+
+/* One whole iteration of program main's `t` loop (src/parallelmain.f90:207-272) for this rank: predict (or predict_ml when
+ * leapfrog_steps < 0) of every resident reservoir, predict_slab_ml of the slab reservoirs when due, then the exchange above. */
+int sml_hybrid_step(sml_hybrid *h, int leapfrog_steps, void *stream)
+{
+    SML_REQUIRE(h, "sml_hybrid_step: null handle");
+    int rc = sml_bank_predict_all(h->bank, 0, stream);
+    if (rc) return rc;
+    if (sml_hybrid_slab_due(h) && (rc = sml_bank_predict_all(h->slab_bank, 0, stream))) return rc;
+    return sml_hybrid_exchange_and_speedy(h, nullptr, leapfrog_steps, stream);
 }
 
 /* run_speedy of the reference (src/mpires.f90:744): 1 while every state handed to SPEEDY passed iogrid(30)'s range guard.

@@ -26,7 +26,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "common.h"
+#include "bank.h"
 
 namespace {
 
@@ -1547,6 +1547,7 @@ struct LuSys {                 // scratch and streams of one batch of factorisat
     hipEvent_t ev_panel = nullptr, ev_strip = nullptr;
     int sg_cus = 0;                // CUs S.sg may use
     bool confined = false;         // the panel stream has the reserved CUs to itself (single solves: see lu_sys_alloc)
+    bool sp_masked = false, sg_masked = false;     // created through sml::masked_stream_create
     LuStride ls{};
 };
 
@@ -1560,8 +1561,8 @@ static void lu_sys_free(LuSys &s)
     if (s.c_list) (void)hipFree((void *)s.c_list);
     if (s.b_list) (void)hipFree((void *)s.b_list);
     if (s.wout_list) (void)hipFree((void *)s.wout_list);
-    if (s.sp) (void)hipStreamDestroy(s.sp);
-    if (s.sg) (void)hipStreamDestroy(s.sg);
+    if (s.sp) (void)(s.sp_masked ? sml::masked_stream_destroy(s.sp) : (int)hipStreamDestroy(s.sp));
+    if (s.sg) (void)(s.sg_masked ? sml::masked_stream_destroy(s.sg) : (int)hipStreamDestroy(s.sg));
     if (s.ev_panel) (void)hipEventDestroy(s.ev_panel);
     if (s.ev_strip) (void)hipEventDestroy(s.ev_strip);
     s = LuSys{};
@@ -1607,10 +1608,14 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
             };
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u), pm((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (reserved(i) ? pm : mask)[i / 32] |= 1u << (i % 32);
-            SML_HIP(hipExtStreamCreateWithCUMask(&s.sg, (uint32_t)mask.size(), mask.data()));
+            int rcm = sml::masked_stream_create(&s.sg, mask.data(), (int)mask.size());
+            if (rcm) return rcm;
+            s.sg_masked = true;
             if (s.confined) {
                 (void)hipStreamDestroy(s.sp);
-                SML_HIP(hipExtStreamCreateWithCUMask(&s.sp, (uint32_t)pm.size(), pm.data()));
+                s.sp = nullptr;
+                if ((rcm = sml::masked_stream_create(&s.sp, pm.data(), (int)pm.size()))) return rcm;
+                s.sp_masked = true;
             }
         } else
             SML_HIP(hipStreamCreateWithFlags(&s.sg, hipStreamNonBlocking));

@@ -27,7 +27,7 @@ module mod_reservoir
   use speedyml_state
   use mod_utilities, only : dp, main_type, reservoir_type, grid_type, model_parameters_type, era_data_type, speedy_data_type, &
                             standardize_data_given_pars5d, standardize_data_given_pars_5d_logp, standardize_data_given_pars_5d_logp_tisr, &
-                            standardize_data_given_pars3d, total_precip_over_a_period, gaussian_noise_columns
+                            standardize_data_given_pars3d, total_precip_over_a_period
   implicit none
   integer :: global_time_step
 
@@ -338,16 +338,51 @@ contains
   end subroutine
 
   ! ---- training ----
+  ! noisy copy of one input column: gaussian_noise_1d_function / gaussian_noise_1d_function_precip (src/mod_utilities.f90:1387-1464) --
+  ! g ~ N(0,1) per entry in entry order (Box-Muller on RANDOM_NUMBER), x + g noisemag x; with precip_bool the precipitation segment is
+  ! un-standardised, taken out of log space, perturbed, made non-negative, and taken back
+  subroutine noisy_column(x, noisemag, grid, model_parameters, with_precip, out)
+    use mod_utilities, only : box_muller
+    real(kind=dp), intent(in) :: x(:), noisemag
+    type(grid_type), intent(in) :: grid
+    type(model_parameters_type), intent(in) :: model_parameters
+    logical, intent(in) :: with_precip
+    real(kind=dp), intent(out) :: out(:)
+    real(kind=dp), allocatable :: g(:), t(:)
+    real(kind=dp), parameter :: e_constant = 2.7182818284590452353602874_dp
+    integer :: i, a, b
+    allocate(g(size(x)))
+    do i = 1, size(x)
+      g(i) = box_muller()
+    end do
+    out = x + g * noisemag * x
+    if (with_precip) then
+      a = grid%precip_start; b = grid%precip_end
+      t = x(a:b)
+      t = t * grid%std(grid%precip_mean_std_idx) + grid%mean(grid%precip_mean_std_idx)
+      t = model_parameters%precip_epsilon * (e_constant**t - 1)
+      t = t + g(a:b) * noisemag * t
+      t = abs(t)
+      t = log(1 + t / model_parameters%precip_epsilon)
+      t = t - grid%mean(grid%precip_mean_std_idx)
+      out(a:b) = t / grid%std(grid%precip_mean_std_idx)
+    end if
+  end subroutine
+
+  ! train_reservoir (:214-320).  The reservoir is built here (data, A, W_in) and ENQUEUED for training with everything the device
+  ! needs (speedyml_train): the recurrences of up to SML_TRAIN_GROUP reservoirs share their per-column launches and the ridge
+  ! systems of a size class are solved in lockstep.  The queue runs when it is full, when the rank's last reservoir has arrived, or
+  ! when a result is needed (finish_training, called by every procedure that comes after training in program main).
   subroutine train_reservoir(reservoir, grid, model_parameters)
+    use speedyml_train
     type(reservoir_type), intent(inout) :: reservoir
     type(grid_type), intent(inout) :: grid
     type(model_parameters_type), intent(inout) :: model_parameters
-    type(c_ptr) :: tbank, dnoisy, dmodel(1), dtarg(1), dc(1), db(1), dw
-    real(kind=dp), allocatable :: rand(:), pass_in(:,:), noisy(:,:), targ(:,:), mdl(:,:)
+    type(train_job) :: job
+    real(kind=dp), allocatable :: rand(:), pass_in(:,:)
     integer(c_int), allocatable :: tpos(:)
-    integer(c_int) :: ntarg, nb
-    integer :: q, i, ncol, discard, batch, n_aug, d, nm, no
-    integer(c_int64_t) :: bytes
+    integer(c_int) :: ntarg
+    integer :: q, i, c, ncol, d, nm, no, step
     call set_level_flags(reservoir, grid, model_parameters)
     call get_training_data(reservoir, model_parameters, grid, 1)
     call gen_res(reservoir)
@@ -360,61 +395,56 @@ contains
     end do
     d = reservoir%reservoir_numinputs; nm = reservoir%chunk_size_speedy; no = reservoir%chunk_size_prediction
     if (model_parameters%ml_only) nm = 0
-    n_aug = reservoir%n + nm
+    step = model_parameters%timestep
     ! initialize_chunk_training (:1561-1592): 20 batches per pass, batch size the closest divisor
-    ncol = model_parameters%traininglength / model_parameters%timestep
-    discard = model_parameters%discardlength / model_parameters%timestep
-    batch = sml_find_closest_divisor(int((model_parameters%traininglength - model_parameters%discardlength) / (20 * model_parameters%timestep), c_int), &
-                                     int((model_parameters%traininglength - model_parameters%discardlength) / model_parameters%timestep, c_int))
-    reservoir%batch_size = batch
-    ! a private one-slot bank for the recurrence of this reservoir; W_out is not used during training
+    ncol = model_parameters%traininglength / step
+    reservoir%batch_size = sml_find_closest_divisor(int((model_parameters%traininglength - model_parameters%discardlength) / (20 * step), c_int), &
+                                                    int((model_parameters%traininglength - model_parameters%discardlength) / step, c_int))
     reservoir%wout = 0.0_dp
-    call sml_check(sml_bank_create(1_c_int, int(d, c_int), int(max(nm, 1), c_int), int(no, c_int), tbank), 'sml_bank_create')
-    call sml_check(sml_bank_load(tbank, 0_c_int, int(reservoir%n, c_int), int(d, c_int), int(reservoir%k, c_int), int(nm, c_int), int(no, c_int), &
-                                 reservoir%rows, reservoir%cols, reservoir%vals, reservoir%win, reservoir%wout, reservoir%leakage, &
-                                 grid%mean, grid%std, int(size(grid%mean), c_int), [(-1_c_int, i = 1, no)]), 'sml_bank_load')
+    call load_into_bank(reservoir, grid, model_parameters)               ! resident for the prediction that follows; W_out arrives with the flush
     allocate(tpos(no))
     ntarg = sml_domain_target_map(int(grid%number_of_regions, c_int), int(reservoir%assigned_region, c_int), int(grid%overlap, c_int), &
                                   int(grid%num_vert_levels, c_int), int(grid%level_index, c_int), int(grid%vert_overlap, c_int), &
                                   merge(1_c_int, 0_c_int, reservoir%precip_bool), tpos, int(no, c_int))
     call sml_check(ntarg, 'sml_domain_target_map')
-    bytes = 8_c_int64_t * n_aug
-    call sml_check(sml_dev_alloc(bytes * n_aug, dc(1)), 'sml_dev_alloc'); call sml_check(sml_dev_zero(dc(1), bytes * n_aug), 'sml_dev_zero')
-    call sml_check(sml_dev_alloc(bytes * no, db(1)), 'sml_dev_alloc'); call sml_check(sml_dev_zero(db(1), bytes * no), 'sml_dev_zero')
-    call sml_check(sml_dev_alloc(8_c_int64_t * d * ncol, dnoisy), 'sml_dev_alloc')
-    call sml_check(sml_dev_alloc(8_c_int64_t * no * ncol, dtarg(1)), 'sml_dev_alloc')
-    call sml_check(sml_dev_alloc(8_c_int64_t * max(nm, 1) * ncol, dmodel(1)), 'sml_dev_alloc')
-    allocate(noisy(d, ncol), targ(no, ncol))
-    do i = 1, model_parameters%timestep                                  ! the interleaved passes (:298-305)
-      pass_in = reservoir%trainingdata(:, i:model_parameters%traininglength:model_parameters%timestep)
-      if (model_parameters%noisy) then
-        call gaussian_noise_columns(pass_in, reservoir%noisemag, noisy)  ! gaussian_noise_1d_function per column (:1116-1124)
-      else
-        noisy = pass_in
+    job%n = reservoir%n; job%d = d; job%k = reservoir%k; job%n_model = nm; job%n_out = no
+    job%discard = model_parameters%discardlength / step; job%batch = reservoir%batch_size
+    job%ml_variant = merge(1, 0, model_parameters%ml_only); job%using_prior = merge(1, 0, model_parameters%using_prior)
+    job%leakage = reservoir%leakage; job%beta_res = reservoir%beta_res; job%beta_model = reservoir%beta_model; job%prior_val = reservoir%prior_val
+    job%rows = reservoir%rows; job%cols = reservoir%cols; job%vals = reservoir%vals; job%win = reservoir%win
+    job%mean = grid%mean; job%std = grid%std
+    job%bank = hip_bank; job%slot = reservoir%hip_slot
+    allocate(job%pass(step))
+    do i = 1, step                                                       ! the interleaved passes (:298-305)
+      pass_in = reservoir%trainingdata(:, i:model_parameters%traininglength:step)
+      allocate(job%pass(i)%noisy(d, ncol))
+      job%pass(i)%noisy = pass_in
+      if (model_parameters%noisy) then                                   ! one noisy copy per column the recurrence reads (:1091-1166)
+        do c = 1, ncol - 1
+          call noisy_column(pass_in(:, c), reservoir%noisemag, grid, model_parameters, model_parameters%precip_bool .and. reservoir%precip_bool, &
+                            job%pass(i)%noisy(:, c))
+        end do
       end if
-      targ = pass_in(tpos(1:no) + 1, :)                                  ! chunking_matmul's targets (tile_full_input_to_target_data)
-      call sml_check(sml_dev_upload(dnoisy, noisy, 8_c_int64_t * d * ncol), 'sml_dev_upload')
-      call sml_check(sml_dev_upload(dtarg(1), targ, 8_c_int64_t * no * ncol), 'sml_dev_upload')
-      if (nm > 0) then
-        mdl = reservoir%imperfect_model_states(:, i:model_parameters%traininglength:model_parameters%timestep)
-        call sml_check(sml_dev_upload(dmodel(1), mdl, 8_c_int64_t * nm * ncol), 'sml_dev_upload')
-      end if
-      nb = sml_bank_train_pass(tbank, dnoisy, int(ncol, c_int), int(discard, c_int), int(batch, c_int), dmodel, dtarg, dc, db, &
-                               merge(1_c_int, 0_c_int, model_parameters%ml_only), c_null_ptr)
-      call sml_check(nb, 'sml_bank_train_pass')
+      job%pass(i)%targ = pass_in(tpos(1:no) + 1, :)                      ! chunking_matmul's targets (tile_full_input_to_target_data)
+      if (nm > 0) job%pass(i)%mdl = reservoir%imperfect_model_states(:, i:model_parameters%traininglength:step)
     end do
-    ! fit_chunk_hybrid (:1235-1334): ridge regularisation + dgesv on the device
-    call sml_check(sml_dev_alloc(bytes * no, dw), 'sml_dev_alloc')
-    call sml_check(sml_train_fit(dc(1), db(1), int(reservoir%n, c_int), int(nm, c_int), int(no, c_int), reservoir%beta_res, reservoir%beta_model, &
-                                 reservoir%prior_val, merge(1_c_int, 0_c_int, model_parameters%using_prior), dw, c_null_ptr), 'sml_train_fit')
-    call sml_check(sml_dev_download(reservoir%wout, dw, bytes * no), 'sml_dev_download')
-    call sml_check(sml_dev_free(dw), 'sml_dev_free'); call sml_check(sml_dev_free(dc(1)), 'sml_dev_free'); call sml_check(sml_dev_free(db(1)), 'sml_dev_free')
-    call sml_check(sml_dev_free(dnoisy), 'sml_dev_free'); call sml_check(sml_dev_free(dtarg(1)), 'sml_dev_free'); call sml_check(sml_dev_free(dmodel(1)), 'sml_dev_free')
-    call sml_check(sml_bank_destroy(tbank), 'sml_bank_destroy')
+    reservoir%hip_train_job = train_enqueue(job)
     if (.not. (model_parameters%slab_ocean_model_bool .and. grid%bottom)) deallocate(reservoir%trainingdata)
     if (allocated(reservoir%imperfect_model_states)) deallocate(reservoir%imperfect_model_states)
+    ! the rank's last reservoir: nothing else will join the queue
+    if (hip_loaded == hip_capacity) call train_flush()
+  end subroutine
+
+  ! W_out of a reservoir that went through the training queue: into reservoir%wout and the weights file (write_trained_res, :1330)
+  subroutine finish_training(reservoir, model_parameters, grid)
+    use speedyml_train
+    type(reservoir_type), intent(inout) :: reservoir
+    type(model_parameters_type), intent(in) :: model_parameters
+    type(grid_type), intent(in) :: grid
+    if (reservoir%hip_train_job <= 0) return
+    call train_take(reservoir%hip_train_job, reservoir%wout)
+    reservoir%hip_train_job = 0
     call write_trained_res(reservoir, model_parameters, grid)
-    call load_into_bank(reservoir, grid, model_parameters)               ! resident for the prediction that follows
   end subroutine
 
   ! write_trained_res (:1703-1737) through the reference's NetCDF helpers
@@ -475,6 +505,7 @@ contains
     type(model_parameters_type), intent(inout) :: model_parameters
     type(grid_type), intent(inout) :: grid
     integer, parameter :: un_noisy_sync = 2160
+    call finish_training(reservoir, model_parameters, grid)
     if (.not. allocated(reservoir%saved_state)) allocate(reservoir%saved_state(reservoir%n))
     reservoir%saved_state = 0
     call get_prediction_data(reservoir, model_parameters, grid, model_parameters%traininglength - un_noisy_sync, un_noisy_sync)

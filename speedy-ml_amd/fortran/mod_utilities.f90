@@ -34,6 +34,7 @@ module mod_utilities
     real(kind=dp), allocatable :: trainingdata(:,:)
     ! device residency (in place of cooA / descrA): the slot of this reservoir in the rank's bank, the Gram matrices of training
     integer(c_int) :: hip_slot = -1
+    integer :: hip_train_job = 0                                  ! its entry in the training queue while W_out is still on its way
     type(c_ptr) :: hip_c = c_null_ptr, hip_b = c_null_ptr
     real(kind=dp) :: deg, radius, beta_res, beta_model, density, sigma, leakage
     integer, allocatable :: rows(:), cols(:)
@@ -136,17 +137,202 @@ module mod_utilities
     integer :: mpi_world = 0
   end type mpi_type
 
+  ! the generic names program main imports (src/mod_utilities.f90:641-663)
+  interface standardize_data
+    module procedure standardize_data_1d, standardize_data_2d, standardize_data_3d, standardize_data_4d, standardize_data_5d, &
+                     standardize_data_5d_logp, standardize_data_5d_logp_tisr
+  end interface
+  interface gaussian_noise
+    module procedure gaussian_noise_2d, gaussian_noise_1d
+  end interface
+
 contains
 
   ! a different random seed on every worker (src/mod_utilities.f90 init_random_marker)
-  subroutine init_random_marker(indx)
-    integer, intent(in) :: indx
-    integer :: nseed
+  ! seed word i = (3 + 2 input)(i - 1): the same on every run (src/mod_utilities.f90:1553-1567)
+  subroutine init_random_marker(input)
+    integer, intent(in) :: input
+    integer :: nseed, i
     integer, allocatable :: seed(:)
     call random_seed(size=nseed)
     allocate(seed(nseed))
-    seed = indx
+    seed = (3 + input * 2) * [(i - 1, i = 1, nseed)]
     call random_seed(put=seed)
+  end subroutine
+
+  ! seed word i = clock + (18 + 12 worker)(i - 1): different on every run and worker (src/mod_utilities.f90:1535-1551)
+  subroutine init_random_seed(worker)
+    integer, intent(in) :: worker
+    integer :: nseed, clock, i
+    integer, allocatable :: seed(:)
+    call random_seed(size=nseed)
+    allocate(seed(nseed))
+    call system_clock(count=clock)
+    seed = clock + (18 + worker * 12) * [(i - 1, i = 1, nseed)]
+    call random_seed(put=seed)
+  end subroutine
+
+  ! ---- standardize_data: statistics of the data itself, returned, then (x - mean) / std as two statements ----
+  ! 1-d .. 4-d (src/mod_utilities.f90:833-983): ONE statistic over the whole array, the variance in its one-pass form
+  ! (sum x^2 - (sum x)^2 / N) / N;  5-d forms (:934-1193): one statistic per (variable, level) in two-pass form, then the 2-d fields
+  subroutine one_pass_stats(total, total_sq, count, mean, std)
+    real(kind=dp), intent(in) :: total, total_sq
+    integer, intent(in) :: count
+    real(kind=dp), intent(out) :: mean, std
+    mean = total / count
+    std = sqrt((total_sq - total**2 / count) / count)
+  end subroutine
+
+  subroutine standardize_data_1d(inputdata, mean, std)
+    real(kind=dp), intent(inout) :: inputdata(:)
+    real(kind=dp), intent(out) :: mean, std
+    call one_pass_stats(sum(inputdata), sum(inputdata**2), size(inputdata), mean, std)
+    call standardize_data_given_pars1d(inputdata, mean, std)
+  end subroutine
+
+  subroutine standardize_data_2d(inputdata, mean, std)
+    real(kind=dp), intent(inout) :: inputdata(:,:)
+    real(kind=dp), intent(out) :: mean, std
+    call one_pass_stats(sum(inputdata), sum(inputdata**2), size(inputdata), mean, std)
+    call standardize_data_given_pars2d(inputdata, mean, std)
+  end subroutine
+
+  subroutine standardize_data_3d(inputdata, mean, std)
+    real(kind=dp), intent(inout) :: inputdata(:,:,:)
+    real(kind=dp), intent(out) :: mean, std
+    call one_pass_stats(sum(inputdata), sum(inputdata**2), size(inputdata), mean, std)
+    call standardize_data_given_pars3d(inputdata, mean, std)
+  end subroutine
+
+  subroutine standardize_data_4d(inputdata, mean, std)
+    real(kind=dp), intent(inout) :: inputdata(:,:,:,:)
+    real(kind=dp), intent(out) :: mean, std
+    call one_pass_stats(sum(inputdata), sum(inputdata**2), size(inputdata), mean, std)
+    call standardize_data_given_pars4d(inputdata, mean, std)
+  end subroutine
+
+  subroutine two_pass_field(field, mean, std)
+    real(kind=dp), intent(inout) :: field(:,:,:)
+    real(kind=dp), intent(out) :: mean, std
+    mean = sum(field) / size(field)
+    std = sqrt(sum((field - mean)**2) / size(field))
+    call standardize_data_given_pars3d(field, mean, std)
+  end subroutine
+
+  subroutine standardize_data_5d(reservoir, inputdata, mean, std)
+    type(reservoir_type), intent(in) :: reservoir
+    real(kind=dp), intent(inout) :: inputdata(:,:,:,:,:)
+    real(kind=dp), intent(out) :: mean(:), std(:)
+    real(kind=dp), allocatable :: field(:,:,:)
+    integer :: v, z, l
+    l = 0
+    do v = 1, size(inputdata, 1)
+      do z = 1, size(inputdata, 4)
+        l = l + 1
+        field = inputdata(v,:,:,z,:)
+        call two_pass_field(field, mean(l), std(l))
+        inputdata(v,:,:,z,:) = field
+      end do
+    end do
+  end subroutine
+
+  subroutine standardize_data_5d_logp(reservoir, inputdata, logp, mean, std)
+    type(reservoir_type), intent(in) :: reservoir
+    real(kind=dp), intent(inout) :: inputdata(:,:,:,:,:), logp(:,:,:)
+    real(kind=dp), intent(out) :: mean(:), std(:)
+    integer :: l
+    call standardize_data_5d(reservoir, inputdata, mean, std)
+    l = size(inputdata, 1) * size(inputdata, 4) + 1
+    call two_pass_field(logp, mean(l), std(l))
+  end subroutine
+
+  subroutine standardize_data_5d_logp_tisr(reservoir, inputdata, logp, tisr, mean, std)
+    type(reservoir_type), intent(in) :: reservoir
+    real(kind=dp), intent(inout) :: inputdata(:,:,:,:,:), logp(:,:,:), tisr(:,:,:)
+    real(kind=dp), intent(out) :: mean(:), std(:)
+    integer :: l
+    call standardize_data_5d_logp(reservoir, inputdata, logp, mean, std)
+    l = size(inputdata, 1) * size(inputdata, 4) + 2
+    call two_pass_field(tisr, mean(l), std(l))
+  end subroutine
+
+  ! standardize_data_given_pars{1,2,4}d (src/mod_utilities.f90:1283-1329): subtract, then divide (two roundings)
+  subroutine standardize_data_given_pars1d(inputdata, mean, std)
+    real(kind=dp), intent(inout) :: inputdata(:)
+    real(kind=dp), intent(in) :: mean, std
+    inputdata = inputdata - mean
+    inputdata = inputdata / std
+  end subroutine
+
+  subroutine standardize_data_given_pars2d(inputdata, mean, std)
+    real(kind=dp), intent(inout) :: inputdata(:,:)
+    real(kind=dp), intent(in) :: mean, std
+    inputdata = inputdata - mean
+    inputdata = inputdata / std
+  end subroutine
+
+  subroutine standardize_data_given_pars4d(inputdata, mean, std)
+    real(kind=dp), intent(inout) :: inputdata(:,:,:,:)
+    real(kind=dp), intent(in) :: mean, std
+    inputdata = inputdata - mean
+    inputdata = inputdata / std
+  end subroutine
+
+  ! gaussian_noise_{1d,2d} (src/mod_utilities.f90:1345-1385): x <- x + g noisemag x, g ~ N(0,1) drawn element by element with the
+  ! Box-Muller pair of gaussian_noise_maker (:1519-1533; the 2-d form walks the FIRST index outermost, :1481-1495)
+  function box_muller() result(g)
+    real(kind=dp) :: g, u1, u2
+    call random_number(u1)
+    call random_number(u2)
+    g = sqrt(-2.0_dp * log(u1)) * cos(8.0_dp * atan(1.0_dp) * u2)
+  end function
+
+  subroutine gaussian_noise_1d(inputdata, noisemag)
+    real(kind=dp), intent(inout) :: inputdata(:)
+    real(kind=dp), intent(in) :: noisemag
+    real(kind=dp), allocatable :: g(:)
+    integer :: i
+    allocate(g(size(inputdata)))
+    do i = 1, size(g)
+      g(i) = box_muller()
+    end do
+    inputdata = inputdata + g * noisemag * inputdata
+  end subroutine
+
+  subroutine gaussian_noise_2d(inputdata, noisemag)
+    real(kind=dp), intent(inout) :: inputdata(:,:)
+    real(kind=dp), intent(in) :: noisemag
+    real(kind=dp), allocatable :: g(:,:)
+    integer :: i, j
+    allocate(g(size(inputdata, 1), size(inputdata, 2)))
+    do i = 1, size(g, 1)
+      do j = 1, size(g, 2)
+        g(i, j) = box_muller()
+      end do
+    end do
+    inputdata = inputdata + g * noisemag * inputdata
+  end subroutine
+
+  ! rolling_average_over_a_period_2d (src/mod_utilities.f90:1773-1813): running mean along the second index over the last
+  ! `period` + 1 entries divided by `period` (the first `period` entries: mean of what there is); a window whose sum is within 1e-7
+  ! of zero leaves the entry as it was
+  subroutine rolling_average_over_a_period_2d(grid, period)
+    real(kind=dp), intent(inout) :: grid(:,:)
+    integer, intent(in) :: period
+    real(kind=dp), allocatable :: copy(:,:)
+    real(kind=dp) :: window
+    integer :: i, t
+    copy = grid
+    do i = 1, size(grid, 1)
+      do t = 1, size(grid, 2)
+        if (t - period < 1) then
+          grid(i, t) = sum(copy(i, 1:t)) / t
+        else
+          window = sum(copy(i, t-period:t))
+          if (abs(window) > 0.0000001_dp) grid(i, t) = window / period
+        end if
+      end do
+    end do
   end subroutine
 
   ! standardize_data_given_pars5d / _5d_logp / _5d_logp_tisr / 3d (src/mod_utilities.f90:1195-1329): (v - mean_l) / std_l with
@@ -199,19 +385,6 @@ contains
       t0 = merge(1, t - period, t - period < 1)             ! (the reference's window holds period + 1 hours, :1720-1724)
       precip(:,:,t) = sum(copy(:,:,t0:t), dim=3)
     end do
-  end subroutine
-
-  ! gaussian_noise_1d_function (src/mod_utilities.f90:1387-1409): x + g * noisemag * x with g ~ N(0,1) from RANDOM_NUMBER
-  ! (Box-Muller), column by column
-  subroutine gaussian_noise_columns(x, noisemag, out)
-    real(kind=dp), intent(in) :: x(:,:), noisemag
-    real(kind=dp), intent(out) :: out(:,:)
-    real(kind=dp), allocatable :: u1(:,:), u2(:,:)
-    allocate(u1(size(x,1), size(x,2)), u2(size(x,1), size(x,2)))
-    call random_number(u1)
-    call random_number(u2)
-    u1 = max(u1, tiny(1.0_dp))
-    out = x + sqrt(-2.0_dp * log(u1)) * cos(8.0_dp * atan(1.0_dp) * u2) * noisemag * x
   end subroutine
 
 end module mod_utilities

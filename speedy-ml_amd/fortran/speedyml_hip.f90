@@ -415,6 +415,90 @@ module speedyml_hip
       type(c_ptr), value :: bank
       type(c_ptr) :: p
     end function
+    function sml_hybrid_attach_slab(h, slab_bank, sea_of_slot, sea_of_region, timestep_slab_hours) bind(C, name="sml_hybrid_attach_slab") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, slab_bank
+      integer(c_int), intent(in) :: sea_of_slot(*), sea_of_region(*)
+      integer(c_int), value :: timestep_slab_hours
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_set_base_sst(h, base_sst, sea_mask) bind(C, name="sml_hybrid_set_base_sst") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: base_sst(*)
+      integer(c_int), intent(in) :: sea_mask(*)
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_set_comm(h, comm) bind(C, name="sml_hybrid_set_comm") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, comm
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_restart(h, start_hours) bind(C, name="sml_hybrid_restart") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: start_hours
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_slab_due(h) bind(C, name="sml_hybrid_slab_due") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_destroy(h) bind(C, name="sml_hybrid_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int) :: rc
+    end function
+    function sml_comm_bootstrap(nranks, rank, name, max_doubles_per_rank, comm) bind(C, name="sml_comm_bootstrap") result(rc)
+      import :: c_int, c_ptr, c_char, c_int64_t
+      integer(c_int), value :: nranks, rank
+      character(kind=c_char), intent(in) :: name(*)
+      integer(c_int64_t), value :: max_doubles_per_rank
+      type(c_ptr), intent(out) :: comm
+      integer(c_int) :: rc
+    end function
+    function sml_comm_destroy(comm) bind(C, name="sml_comm_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: comm
+      integer(c_int) :: rc
+    end function
+    function sml_slab_sizes(g, m, deg, local_predictvars, out) bind(C, name="sml_slab_sizes") result(rc)
+      import :: c_int, sml_region, sml_res_sizes
+      type(sml_region), intent(in) :: g
+      integer(c_int), value :: m, deg, local_predictvars
+      type(sml_res_sizes), intent(out) :: out
+      integer(c_int) :: rc
+    end function
+    function sml_slab_predict_hybrid(slab_bank, stream) bind(C, name="sml_slab_predict_hybrid") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: slab_bank, stream
+      integer(c_int) :: rc
+    end function
+    function sml_bank_outvec_dev(bank) bind(C, name="sml_bank_outvec_dev") result(p)
+      import :: c_ptr
+      type(c_ptr), value :: bank
+      type(c_ptr) :: p
+    end function
+    function sml_train_fit_batched(count, c_dev, b_dev, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout_dev, stream) &
+        bind(C, name="sml_train_fit_batched") result(rc)
+      import :: c_int, c_ptr, c_double
+      integer(c_int), value :: count, n, n_model, n_out, using_prior
+      type(c_ptr), intent(in) :: c_dev(*), b_dev(*), wout_dev(*)
+      real(c_double), value :: beta_res, beta_model, prior_val
+      type(c_ptr), value :: stream
+      integer(c_int) :: rc
+    end function
+    function sml_train_release_workspace() bind(C, name="sml_train_release_workspace") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+    function sml_dev_upload_raw(dst_dev, src_host, bytes) bind(C, name="sml_dev_upload") result(rc)
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: dst_dev, src_host
+      integer(c_int64_t), value :: bytes
+      integer(c_int) :: rc
+    end function
     function sml_dev_download_raw(dst_host, src_dev, bytes) bind(C, name="sml_dev_download") result(rc)
       import :: c_int, c_ptr, c_int64_t
       type(c_ptr), value :: dst_host, src_dev
@@ -432,6 +516,15 @@ contains
     integer(c_int64_t), intent(in) :: off, bytes
     integer(c_int) :: rc
     rc = sml_dev_download_raw(c_loc(dst), transfer(transfer(src_dev, 0_c_intptr_t) + off, src_dev), bytes)
+  end function
+
+  ! upload `bytes` bytes to `off` bytes into a device buffer
+  function sml_dev_upload_off(dst_dev, off, src, bytes) result(rc)
+    type(c_ptr), intent(in) :: dst_dev
+    real(c_double), intent(in), target :: src(*)
+    integer(c_int64_t), intent(in) :: off, bytes
+    integer(c_int) :: rc
+    rc = sml_dev_upload_raw(transfer(transfer(dst_dev, 0_c_intptr_t) + off, dst_dev), c_loc(src), bytes)
   end function
 
   ! The reference prints library status and stops (src/mod_linalg.f90:18-22,147-150); same here.

@@ -1,6 +1,7 @@
 ! Test support for the module-API drop-ins: synthetic stand-ins of exactly the reference procedures the drop-ins call for DATA --
 !   speedy_res_interface :: read_era, read_model_states   (src/speedy_res_interface.f90: ERA5 / SPEEDY NetCDF readers)
-!   mod_io               :: read_trained_res, write_netcdf_2d_non_met_data, write_netcdf_1d_non_met_data_int / _real (src/mod_io.f90)
+!   mod_io               :: read_trained_res, read_trained_ocean_res, read_3d_file_parallel, write_netcdf_2d_non_met_data,
+!                           write_netcdf_1d_non_met_data_int / _real (src/mod_io.f90)
 ! -- with the reference's argument lists, plus hybrid_boundary_fields, the one procedure a host adds to hand SPEEDY's boundary
 ! arrays to the engine (INTEGRATION.md).  A maintainer links the reference's modules instead of this file.  The fields are
 ! deterministic, smooth and ERA5-shaped (SURVEY 8d); nothing here is part of the product.
@@ -223,6 +224,14 @@ contains
       reservoir%wout(i, s%chunk_size_speedy + 1 + mod(7 * i, s%n)) = 1.0e-3_dp
       if (i > s%chunk_size_speedy) reservoir%wout(i, s%chunk_size_speedy + 1 + mod(11 * i, s%n)) = 0.05_dp
     end do
+    call synthetic_statistics(grid)
+  end subroutine
+
+  ! the statistics a weights file carries (mean / std per variable and level, then logp, tisr, precip, sst): the same synthetic climate
+  ! for every region
+  subroutine synthetic_statistics(grid)
+    type(grid_type), intent(inout) :: grid
+    integer :: i, nl
     nl = 4 * 8
     if (allocated(grid%mean)) deallocate(grid%mean, grid%std)
     allocate(grid%mean(nl + 4), grid%std(nl + 4))
@@ -236,6 +245,76 @@ contains
     grid%mean(34) = 1.2e6_dp; grid%std(34) = 1.5e6_dp                 ! tisr
     grid%mean(35) = 0.5_dp; grid%std(35) = 0.6_dp                     ! precip (log-transformed)
     grid%mean(36) = 290.0_dp; grid%std(36) = 8.0_dp                   ! sst
+  end subroutine
+
+  ! read_trained_ocean_res (src/mod_io.f90:2985-3036): worker_RRRR_ocean_<trial>.nc -- here a synthetic trained slab reservoir for the
+  ! regions whose atmosphere reservoir takes SST input ("the file exists"), with a small W_out (SST anomalies around the region's mean)
+  subroutine read_trained_ocean_res(reservoir, model_parameters, grid)
+    type(reservoir_type), intent(inout) :: reservoir
+    type(model_parameters_type), intent(in) :: model_parameters
+    type(grid_type), intent(inout) :: grid
+    type(sml_region) :: g
+    type(sml_res_sizes) :: s
+    real(c_double) :: eigs
+    character(len=32) :: env
+    integer :: i, j, q, m, mlen, stat
+    reservoir%sst_bool_input = abs(grid%res_ystart - 24.5) < 14 .and. mod(grid%res_xstart / 8, 3) /= 0            ! the "sea" regions of read_trained_res
+    reservoir%sst_bool_prediction = reservoir%sst_bool_input
+    if (.not. reservoir%sst_bool_input) return
+    m = 4000
+    call get_environment_variable('SML_SLAB_M', env, mlen, stat)
+    if (stat == 0 .and. mlen > 0) read(env(1:mlen), *) m
+    g%resxchunk = grid%resxchunk; g%resychunk = grid%resychunk; g%inputxchunk = grid%inputxchunk; g%inputychunk = grid%inputychunk
+    call sml_check(sml_slab_sizes(g, int(m, c_int), 6_c_int, 4_c_int, s), 'sml_slab_sizes')
+    if (allocated(reservoir%win)) deallocate(reservoir%win, reservoir%wout, reservoir%rows, reservoir%cols, reservoir%vals)
+    allocate(reservoir%win(s%n, s%reservoir_numinputs), reservoir%wout(s%chunk_size_prediction, s%n), reservoir%rows(s%k), reservoir%cols(s%k), &
+             reservoir%vals(s%k))
+    call sml_check(sml_gen_res(s%n, s%k, 0.6_c_double, int(555 + mod(reservoir%assigned_region, 5), c_int64_t), reservoir%rows, reservoir%cols, reservoir%vals, eigs), &
+                   'sml_gen_res')
+    q = s%n / s%reservoir_numinputs
+    reservoir%win = 0.0_dp
+    do i = 1, s%reservoir_numinputs
+      do j = 1, q
+        reservoir%win((i-1)*q + j, i) = 0.6_dp * sin(0.29_dp * (i * q + j) + 0.7_dp)
+      end do
+    end do
+    reservoir%wout = 0.0_dp
+    do i = 1, s%chunk_size_prediction
+      reservoir%wout(i, 1 + mod(13 * i, s%n)) = 0.02_dp
+      reservoir%wout(i, 1 + mod(29 * i + 5, s%n)) = -0.015_dp
+    end do
+    call synthetic_statistics(grid)                    ! (a slab weights file carries the atmosphere reservoir's statistics, :366-367)
+  end subroutine
+
+  ! read_3d_file_parallel (src/mod_io.f90:2731-2812): (x, y, t) of the region's input patch from a NetCDF file, hourly from
+  ! start_time_arg -- here the synthetic ocean heat content [J m-2] (and, for other variable names, zeros)
+  subroutine read_3d_file_parallel(filename, varname, mpi_res, grid, var3d, start_time_arg, stride_arg, time_length)
+    use mod_utilities, only : mpi_type
+    character(len=*), intent(in) :: filename, varname
+    type(mpi_type), intent(in) :: mpi_res
+    type(grid_type), intent(in) :: grid
+    real(kind=dp), allocatable, intent(inout) :: var3d(:,:,:)
+    integer, intent(in), optional :: start_time_arg, stride_arg, time_length
+    integer :: nt, t0, ix, iy, t, x, y
+    real(kind=dp) :: lat, lon
+    real(kind=dp), parameter :: pi = 3.14159265358979323846_dp
+    nt = 8760; t0 = 1
+    if (present(time_length)) nt = time_length
+    if (present(start_time_arg)) t0 = start_time_arg
+    if (allocated(var3d)) deallocate(var3d)
+    allocate(var3d(grid%inputxchunk, grid%inputychunk, nt))
+    var3d = 0.0_dp
+    if (varname /= 'sohtc300') return
+    do t = 1, nt
+      do iy = 1, grid%inputychunk
+        y = grid%input_ystart + iy - 1
+        do ix = 1, grid%inputxchunk
+          x = modulo(grid%input_xstart + ix - 2, 96) + 1
+          lat = (y - 24.5_dp) * 3.71_dp * pi / 180.0_dp; lon = (x - 1) * 2.0_dp * pi / 96
+          var3d(ix, iy, t) = 1.1e10_dp * cos(lat)**2 + 4.0e8_dp * sin(2.0_dp * lon) + 6.0e8_dp * sin(2.0_dp * pi * (t0 + t) / 8760.0_dp)
+        end do
+      end do
+    end do
   end subroutine
 
   subroutine write_netcdf_2d_non_met_data(array, varname, filename, units, x_dim, y_dim)

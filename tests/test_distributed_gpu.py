@@ -172,3 +172,55 @@ def test_sharded_training_equals_single_rank(tmp_path):
     for region in range(TRAIN_NREG):
         assert np.array_equal(got[region], single[region]), region
         assert os.path.exists(tmp_path / weights.trained_res_filename(region, "shard"))
+
+
+def _engine_worker(rank, world, name, out_dir, slab):
+    """one rank of the NATIVE engine (sml_hybrid_* + sml_comm over the host-staged rehearsal transport: two ranks share the GPU)"""
+    import ctypes as C
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["SML_COMM_TRANSPORT"] = "shm"
+    from __graft_entry__ import load_package
+    load_package()
+    from speedy_ml_amd import _lib, domain, hybrid, synth
+    from test_hybrid_engine_gpu import make_engine
+    torch.cuda.set_device(0)
+    L, check = _lib.lib(), _lib.check
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = [int(r) for r in domain.processor_decomposition_manual(rank, world, NREG)]
+    m = hybrid.HybridRank(regions, classes, world=1, rank=0, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2, slab=slab)
+    comm = C.c_void_p()
+    if world > 1:
+        check(L.sml_comm_bootstrap(world, rank, name.encode(), C.c_uint64(0), C.byref(comm)))
+    h = make_engine(m, regions, classes, comm=comm if world > 1 else None)
+    stream = torch.cuda.current_stream()
+    for _ in range(30 if slab else 3):
+        check(L.sml_hybrid_step(h, 2, _lib.vp(stream)))
+    torch.cuda.synchronize()
+    g, fc = np.zeros(domain.G_SIZE), np.zeros(domain.G_SIZE)
+    check(L.sml_hybrid_get_state(h, _lib.dp(g), _lib.dp(fc)))
+    np.savez(os.path.join(out_dir, f"eng{world}_{rank}.npz"), G=g, F=fc, fb=m.feedback.cpu().numpy(), lm=m.local_model.cpu().numpy(), regions=np.array(regions))
+    check(L.sml_hybrid_destroy(h))
+    if world > 1:
+        check(L.sml_comm_destroy(comm))
+
+
+@pytest.mark.parametrize("slab", [False, True])
+def test_native_engine_two_ranks_equal_one_rank(tmp_path, slab):
+    """The C-ABI's own rank exchange inside the engine (sml_hybrid_set_comm -> sml_comm_allgather_outvec, for the atmosphere and
+    the slab bank): two processes, each with its share of processor_decomposition and its own engine, reproduce the single-rank run
+    bit for bit.  Two ranks on ONE GPU: the communicator is the host-staged rehearsal transport (SML_COMM_TRANSPORT=shm); with one GPU
+    per rank the same calls run over RCCL."""
+    import torch.multiprocessing as mp
+    name = f"sml_test_{os.getpid()}_{int(slab)}"
+    mp.spawn(_engine_worker, args=(2, name, str(tmp_path), slab), nprocs=2, join=True)
+    _engine_worker(0, 1, name, str(tmp_path), slab)
+    one = np.load(tmp_path / "eng1_0.npz")
+    for r in range(2):
+        d = np.load(tmp_path / f"eng2_{r}.npz")
+        assert np.array_equal(d["G"], one["G"]) and np.array_equal(d["F"], one["F"]), r
+        regs = d["regions"]
+        assert np.array_equal(d["fb"], one["fb"][regs]) and np.array_equal(d["lm"], one["lm"][regs]), r

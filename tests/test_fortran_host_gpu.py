@@ -22,17 +22,88 @@ def test_fortran_driver_parity():
     assert "FORTRAN HOST PARITY OK" in p.stdout
 
 
-def test_fortran_module_api_runs_program_mains_loop():
-    """The module-API drop-ins (modules mpires, mod_reservoir, resdomain, mod_utilities, mod_calendar with the reference's procedure
-    names and argument lists, speedy-ml_amd/fortran/*.f90) driven by the prediction part of the reference's program main
-    (src/parallelmain.f90:140-272) for two time steps with all 1152 regions on one rank: fortran/test_main_loop.f90 checks the batched
-    predict behind the per-region predict calls against a per-region predict, the next feedback against the host-side tiling of the
-    global state, run_speedy, and mod_slab_ocean_reservoir's predict_slab_ml against the same step written out in Fortran on the host.  (About two minutes: the synthetic stand-ins of the ERA5 readers generate 2304 region-windows.)"""
-    exe = os.path.join(FDIR, "test_main_loop")
+def _run(exe_name, env, timeout=900):
+    exe = os.path.join(FDIR, exe_name)
     if not os.path.exists(exe):
         assert shutil.which("amdflang") or os.path.exists("/opt/rocm/bin/amdflang"), "no prebuilt driver and no amdflang"
-        subprocess.check_call(["make", "-C", FDIR, "test_main_loop"])
-    p = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, SML_RES_M="600"))
+        subprocess.check_call(["make", "-C", FDIR, exe_name])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env))
     print(p.stdout[-3000:], p.stderr[-2000:])
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "main loop parity OK" in p.stdout
+    return p.stdout
+
+
+def _read_dump(path):
+    import numpy as np
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw, dtype=np.int32, count=1)[0])
+    off = 4
+    G = np.frombuffer(raw, dtype=np.float64, count=165888, offset=off); off += 165888 * 8
+    F = np.frombuffer(raw, dtype=np.float64, count=152064, offset=off); off += 152064 * 8
+    regions = {}
+    for _ in range(n):
+        r = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off)[0]); off += 4
+        fb = np.frombuffer(raw, dtype=np.float64, count=576, offset=off); off += 576 * 8
+        lm = np.frombuffer(raw, dtype=np.float64, count=132, offset=off); off += 132 * 8
+        regions[r] = (fb, lm)
+    assert off == len(raw)
+    return G, F, regions
+
+
+def test_fortran_module_api_runs_program_mains_loop(tmp_path):
+    """The module-API drop-ins (modules mpires, mod_reservoir, mod_slab_ocean_reservoir, resdomain, mod_utilities, mod_calendar with the
+    reference's procedure names and argument lists, speedy-ml_amd/fortran/*.f90) driven by the trained-model part of the reference's
+    program main (src/parallelmain.f90:140-272) with slab_ocean_model_bool = .true. as shipped, all 1152 regions on one rank, 30 steps
+    (the slab reservoirs step at the 28th), then a second forecast of 2 steps: fortran/test_main_loop.f90 checks the batched predict
+    behind the per-region predict calls against a per-region predict, the next feedback against the host-side tiling of the global
+    state, run_speedy, the batched predict_slab_ml against the slab step written out on the host and its SST in the hybrid state, and
+    the TISR slice after the engine's restart for the second forecast."""
+    out = _run("test_main_loop", dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="30", SML_TEST_PREDICTIONS="2",
+                                      SML_TEST_DUMP=str(tmp_path / "one.bin")))
+    assert "main loop parity OK" in out and "slab predict_slab_ml of region" in out
+
+
+def test_fortran_main_loop_two_ranks_equal_one_rank(tmp_path):
+    """mpires::startmpi / sendrecievegrid on more than one rank: two processes (SML_RANK / SML_NRANKS), each with the regions of
+    processor_decomposition in its own banks and its own SPEEDY replica, the outvec slabs (atmosphere and slab ocean) all-gathered inside
+    the engine -- here over the host-staged rehearsal transport, because both ranks share the box's one GPU (with one GPU per rank the
+    same calls go over RCCL).  G, F and every region's next feedback / local_model after 3 steps equal the 1-rank run bit for bit."""
+    import numpy as np
+    base = dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="3", SML_TEST_PREDICTIONS="1")
+    _run("test_main_loop", dict(base, SML_TEST_DUMP=str(tmp_path / "one.bin")))
+    exe = os.path.join(FDIR, "test_main_loop")
+    name = f"sml_f90_{os.getpid()}"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, **base, SML_RANK=str(r), SML_NRANKS="2", SML_LOCAL_RANK="0", SML_COMM_TRANSPORT="shm", SML_COMM_NAME=name,
+                   SML_TEST_DUMP=str(tmp_path / f"two_{r}.bin"))
+        procs.append(subprocess.Popen([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        print(o[-1500:])
+        assert p.returncode == 0 and "main loop parity OK" in o, f"rank {r}: " + o[-3000:]
+    G1, F1, reg1 = _read_dump(tmp_path / "one.bin")
+    seen = set()
+    for r in range(2):
+        G, F, reg = _read_dump(tmp_path / f"two_{r}.bin")
+        assert np.array_equal(G, G1) and np.array_equal(F, F1), r
+        assert len(reg) == 576
+        for k, (fb, lm) in reg.items():
+            assert np.array_equal(fb, reg1[k][0]) and np.array_equal(lm, reg1[k][1]), (r, k)
+            seen.add(k)
+    assert seen == set(range(1152))
+
+
+def test_fortran_training_in_groups_equals_one_at_a_time(tmp_path):
+    """train_reservoir / train_slab_ocean_model of the drop-in through the training branch of program main (src/parallelmain.f90:72-137,
+    fortran/test_train_batch.f90): 8 regions, trained one at a time (SML_TRAIN_GROUP=1, the reference's granularity) and as one group
+    (shared recurrence launches, ridge solves in lockstep) give identical W_out files; the time per reservoir of both is printed."""
+    base = dict(SML_RES_M="1200", SML_SLAB_M="400", SML_TEST_REGIONS="8")
+    o1 = _run("test_train_batch", dict(base, SML_TRAIN_GROUP="1", SML_TEST_DUMP=str(tmp_path / "single.bin")))
+    o8 = _run("test_train_batch", dict(base, SML_TRAIN_GROUP="64", SML_TEST_DUMP=str(tmp_path / "group.bin")))
+    assert "training through the module API OK" in o1 and "training through the module API OK" in o8
+    a, b = open(tmp_path / "single.bin", "rb").read(), open(tmp_path / "group.bin", "rb").read()
+    assert len(a) > 8 * 136 * 600 * 8 and a == b
+    per = lambda o: [l for l in o.splitlines() if "speedyml_train: trained" in l]
+    print("one at a time:", per(o1)[:3], "... grouped:", per(o8))
+    assert any(" 8 reservoir(s)" in l for l in per(o8))

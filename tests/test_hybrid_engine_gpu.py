@@ -54,3 +54,100 @@ def test_native_engine_equals_python_step():
     check(L.sml_hybrid_safe(h, C.byref(safe)))
     assert safe.value == 1 and not np.array_equal(g, g0)
     check(L.sml_hybrid_destroy(h))
+
+
+def make_engine(model, regions, classes, comm=None):
+    """sml_hybrid_* over the banks and the start state of a HybridRank built for the same regions (the Python object only supplies
+    identical reservoirs, surface fields and tables; from here on the native engine steps them)."""
+    L, check = _lib.lib(), _lib.check
+    h = C.c_void_p()
+    ros = np.ascontiguousarray(regions, dtype=np.int32)
+    sst = np.array([int(classes[r][1]) for r in regions], dtype=np.int32)
+    check(L.sml_hybrid_create(model.bank._h, hybrid.NREG, _lib.ip(ros), len(ros), 1, 1, _lib.ip(sst), C.byref(h)))
+    check(L.sml_hybrid_set_state(h, _lib.dp(model.G.cpu().numpy().copy())))
+    check(L.sml_hybrid_set_orography(h, _lib.dp(np.ascontiguousarray(synth.synthetic_orography()))))
+    check(L.sml_hybrid_set_tisr_table(h, _lib.dp(np.ascontiguousarray(model.tisr.cpu().numpy())), model.start_hours, model.timestep_hours))
+    sia = np.asarray(model.sp.table(1)).ravel()
+    radang = np.concatenate([-np.arcsin(sia), np.arcsin(sia)[::-1]])
+    s = model.surface
+    f = lambda k: _lib.dp(np.ascontiguousarray(s[k], dtype=np.float64))
+    check(L.sml_hybrid_attach_physics(h, _lib.dp(HSG), _lib.dp(radang), f("fmask"), f("phis0"), f("tland"), f("swav"), f("alb_l"), f("alb_s"),
+                                      f("albsfc"), f("snowc"), NSTRAD))
+    if model.slab is not None:
+        base = np.ascontiguousarray(model.base_sst.cpu().numpy())
+        mask = np.ascontiguousarray(model.sst_mask.cpu().numpy(), dtype=np.int32)
+        check(L.sml_hybrid_set_base_sst(h, _lib.dp(base), _lib.ip(mask)))
+        sea_slot = np.array([int(classes[r][1]) for r in regions], dtype=np.int32)
+        sea_reg = np.array([int(c[1]) for c in classes], dtype=np.int32)
+        check(L.sml_hybrid_attach_slab(h, model.slab_bank._h, _lib.ip(sea_slot), _lib.ip(sea_reg), 168))
+    if comm is not None:
+        check(L.sml_hybrid_set_comm(h, comm))
+    check(L.sml_hybrid_initial_inputs(h, None))
+    return h
+
+
+def test_native_engine_with_slab_equals_python_over_30_steps():
+    """config 5 in the native engine: sml_hybrid_attach_slab + sml_hybrid_step (predict, predict_slab_ml on the 28th step, SST
+    assembly, mask / floor, the averaging ring of the slab inputs) against HybridRank(slab=True), bit for bit, over 30 steps -- the slab
+    reservoirs fire once (step 28) and their SST reaches the atmosphere reservoirs' inputs and SPEEDY's sea temperature after it."""
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = list(range(hybrid.NREG))
+    ref = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, slab=True)
+    eng = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, slab=True)
+    L, check = _lib.lib(), _lib.check
+    h = make_engine(eng, regions, classes)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.feedback, ref.feedback) and torch.equal(eng.local_model, ref.local_model)
+    stream = torch.cuda.current_stream()
+    fired = 0
+    sst_before = ref.G[domain.GS_OFF:domain.GT_OFF].clone()
+    for t in range(30):
+        fired += L.sml_hybrid_slab_due(h)
+        assert ref.step(stream) is True
+        check(L.sml_hybrid_step(h, hybrid.LEAPFROG_PER_WINDOW, _lib.vp(stream)))
+        if t in (0, 26, 27, 28, 29):
+            torch.cuda.synchronize()
+            g, fc = np.zeros(domain.G_SIZE), np.zeros(domain.G_SIZE)
+            check(L.sml_hybrid_get_state(h, _lib.dp(g), _lib.dp(fc)))
+            assert np.array_equal(g, ref.G.cpu().numpy()), t
+            assert np.array_equal(fc[:domain.GP_OFF], ref.F.cpu().numpy()[:domain.GP_OFF]), t
+            assert torch.equal(eng.feedback, ref.feedback) and torch.equal(eng.local_model, ref.local_model) and torch.equal(eng.outvec, ref.outvec), t
+            assert torch.equal(eng.slab_feedback, ref.slab_feedback) and torch.equal(eng.slab_outvec, ref.slab_outvec), t
+    assert fired == 1
+    assert not torch.equal(ref.G[domain.GS_OFF:domain.GT_OFF], sst_before), "the slab reservoirs' SST never reached the hybrid state"
+    safe = C.c_int()
+    check(L.sml_hybrid_safe(h, C.byref(safe)))
+    assert safe.value == 1
+    check(L.sml_hybrid_destroy(h))
+
+
+def test_engine_restart_reproduces_the_first_forecast():
+    """sml_hybrid_restart (program main's prediction_num loop): after a restart with the same start hour, the same G and the same
+    reservoir states, the engine repeats its first forecast bit for bit (step counter, TISR slice, forcing day and range guard reset)."""
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = list(range(0, hybrid.NREG, 1))
+    eng = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1)
+    L, check = _lib.lib(), _lib.check
+    h = make_engine(eng, regions, classes)
+    g0 = eng.G.cpu().numpy().copy()
+    x0 = [eng.bank.get_state(i) for i in (0, 500, 1151)]
+    stream = torch.cuda.current_stream()
+    runs = []
+    for attempt in range(2):
+        for _ in range(3):
+            check(L.sml_hybrid_step(h, 2, _lib.vp(stream)))
+        torch.cuda.synchronize()
+        g = np.zeros(domain.G_SIZE)
+        check(L.sml_hybrid_get_state(h, _lib.dp(g), None))
+        runs.append((g, eng.feedback.cpu().numpy().copy()))
+        if attempt == 0:
+            check(L.sml_hybrid_restart(h, eng.start_hours))
+            check(L.sml_hybrid_set_state(h, _lib.dp(g0)))
+            for i in range(hybrid.NREG):
+                eng.bank.set_state(i, np.zeros_like(eng.bank.get_state(i)))
+            check(L.sml_hybrid_initial_inputs(h, None))
+    assert np.abs(x0[0]).max() == 0.0          # (the synthetic banks start from x = 0)
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    check(L.sml_hybrid_destroy(h))
