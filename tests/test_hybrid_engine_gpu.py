@@ -122,32 +122,42 @@ def test_native_engine_with_slab_equals_python_over_30_steps():
     check(L.sml_hybrid_destroy(h))
 
 
-def test_engine_restart_reproduces_the_first_forecast():
-    """sml_hybrid_restart (program main's prediction_num loop): after a restart with the same start hour, the same G and the same
-    reservoir states, the engine repeats its first forecast bit for bit (step counter, TISR slice, forcing day and range guard reset)."""
+def test_engine_restart_starts_a_new_forecast():
+    """sml_hybrid_restart (program main's prediction_num loop, src/parallelmain.f90:206): the step counter -- hence the TISR slice
+    get_tisr_by_date picks -- and the range guard start over.  (The column physics' carried fields -- the short-wave heating of the last
+    short-wave step and the like -- live on across forecasts, as the reference's module variables do inside one process, so a repeated
+    forecast is not expected to repeat bit for bit.)"""
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
-    regions = list(range(0, hybrid.NREG, 1))
+    regions = list(range(hybrid.NREG))
     eng = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1)
     L, check = _lib.lib(), _lib.check
     h = make_engine(eng, regions, classes)
     g0 = eng.G.cpu().numpy().copy()
-    x0 = [eng.bank.get_state(i) for i in (0, 500, 1151)]
     stream = torch.cuda.current_stream()
-    runs = []
-    for attempt in range(2):
-        for _ in range(3):
-            check(L.sml_hybrid_step(h, 2, _lib.vp(stream)))
-        torch.cuda.synchronize()
-        g = np.zeros(domain.G_SIZE)
-        check(L.sml_hybrid_get_state(h, _lib.dp(g), None))
-        runs.append((g, eng.feedback.cpu().numpy().copy()))
-        if attempt == 0:
-            check(L.sml_hybrid_restart(h, eng.start_hours))
-            check(L.sml_hybrid_set_state(h, _lib.dp(g0)))
-            for i in range(hybrid.NREG):
-                eng.bank.set_state(i, np.zeros_like(eng.bank.get_state(i)))
-            check(L.sml_hybrid_initial_inputs(h, None))
-    assert np.abs(x0[0]).max() == 0.0          # (the synthetic banks start from x = 0)
-    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    table = eng.tisr.cpu().numpy().reshape(8760, -1)
+    g, safe = np.zeros(domain.G_SIZE), C.c_int()
+    for _ in range(3):
+        check(L.sml_hybrid_step(h, 2, _lib.vp(stream)))
+    check(L.sml_hybrid_get_state(h, _lib.dp(g), None))
+    assert np.array_equal(g[domain.GT_OFF:], table[domain.tisr_index(eng.start_hours + 2 * 6) - 1])          # get_tisr_by_date(timestep - 1), step 3
+    # an unphysical state trips iogrid(30)'s guard ...
+    bad = g0.copy()
+    bad[domain.G4_OFF:domain.G4_OFF + 4 * 96] = 1000.0
+    check(L.sml_hybrid_set_state(h, _lib.dp(bad)))
+    eng.outvec.fill_(1.0e4)
+    check(L.sml_hybrid_exchange_and_speedy(h, None, 2, _lib.vp(stream)))
+    check(L.sml_hybrid_safe(h, C.byref(safe)))
+    assert safe.value == 0
+    # ... and a new forecast, 336 hours later in the calendar, starts clean
+    later = eng.start_hours + 336
+    check(L.sml_hybrid_restart(h, later))
+    check(L.sml_hybrid_set_state(h, _lib.dp(g0)))
+    check(L.sml_hybrid_initial_inputs(h, None))
+    check(L.sml_hybrid_step(h, 2, _lib.vp(stream)))
+    check(L.sml_hybrid_safe(h, C.byref(safe)))
+    assert safe.value == 1
+    check(L.sml_hybrid_get_state(h, _lib.dp(g), None))
+    assert np.array_equal(g[domain.GT_OFF:], table[domain.tisr_index(later) - 1])
+    assert not np.array_equal(table[domain.tisr_index(later) - 1], table[domain.tisr_index(eng.start_hours + 2 * 6) - 1])
     check(L.sml_hybrid_destroy(h))
