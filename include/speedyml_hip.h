@@ -544,17 +544,28 @@ int sml_bank_train_pass(sml_bank *bank, const double *noisy_inputs_dev, int T, i
 /* sml_train_accumulate updates only the tiles of C on or below the diagonal (half the flops and half the C traffic of
  * the reference's full DGEMM); this mirrors them into the upper triangle (sml_train_fit calls it itself). */
 int sml_train_symmetrize(double *c_dev, int n_aug, void *stream);
-/* fit_chunk_hybrid: regularise the diagonal, solve C^T Z = (B+prior)^T by LU with partial pivoting (dgesv), wout = Z^T.
- * c_dev is symmetrised in place (not destroyed).  wout_dev: (n_out, n_aug) column-major.  Synchronises the stream.
- * Returns SML_ERR_NUMERIC when a pivot is exactly zero (dgesv info > 0). */
+/* fit_chunk_hybrid (src/mod_reservoir.f90:1235-1334): regularise the diagonal, solve C^T Z = (B + prior)^T, wout = Z^T.
+ * wout_dev: (n_out, n_aug) column-major.  Synchronises the stream.
+ * Solver.  The regularised Gram matrix is symmetric positive definite by construction (C = sum aug aug^T plus a positive diagonal), so
+ * the default is a blocked Cholesky of C's lower triangle -- half the flops and half the traffic of an LU, no pivot search, no row
+ * interchanges (SURVEY 2.2 lists it as an allowed form; W_out parity is defined by backward error, H4).  A pivot that is not positive
+ * (an indefinite matrix, or one singular to working precision) sends that system through the pivoted LU instead, which is dgesv's
+ * algorithm (first maximum per column, row interchange), as mldivide is (src/mod_linalg.f90:109-151); sml_train_select_solver(1) makes
+ * the LU the only solver.  Only the LU symmetrises c_dev in place (the Cholesky reads the lower triangle sml_train_accumulate fills).
+ * Limits: the LU keeps its panel in registers and takes n_aug <= 7168; the Cholesky has no size limit.  Any n_out (the back substitution
+ * runs in groups of 136 right-hand sides).  Both are checked before anything is enqueued.
+ * Returns SML_ERR_NUMERIC when a pivot of the LU is exactly zero (dgesv info > 0). */
 int sml_train_fit(double *c_dev, const double *b_dev, int n, int n_model, int n_out, double beta_res, double beta_model,
                   double prior_val, int using_prior, double *wout_dev, void *stream);
 
-/* Several ridge solves of equal size at once (host arrays of device pointers): up to 8 systems are kept in flight on
- * separate streams, because a single LU is latency-bound on its one-workgroup pivot search. */
+/* Several ridge solves of equal size at once (host arrays of device pointers): up to 16 systems advance in lockstep through ONE chain
+ * of launches (the panel chain of a single factorisation is latency-bound; its trailing updates fill the chip only together). */
 int sml_train_fit_batched(int count, double *const *c_dev, const double *const *b_dev, int n, int n_model, int n_out,
                           double beta_res, double beta_model, double prior_val, int using_prior, double *const *wout_dev,
                           void *stream);
+/* 0 = Cholesky, LU where it breaks down (default; environment SML_FIT_SOLVER=auto|lu|chol presets it); 1 = pivoted LU only;
+ * 2 = Cholesky only (SML_ERR_NUMERIC for a system that is not positive definite); < 0 = query.  Returns the previous setting. */
+int sml_train_select_solver(int solver);
 /* sml_train_fit[_batched] keep their device scratch (the row-major system, panel buffers, streams: ~310 MB per factorisation in
  * flight at n_aug = 5892) between calls; this frees it. */
 int sml_train_release_workspace(void);

@@ -71,7 +71,7 @@ EXPORTS = [
     "sml_phys_create", "sml_phys_destroy", "sml_phys_set_surface", "sml_phys_set_sst_dev", "sml_phys_bind_sst_dev", "sml_phys_sol_oz", "sml_phys_get_tables",
     "sml_phys_tendencies", "sml_phys_tendencies_sfcwind", "sml_phys_diag",
     "sml_makesparse", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",
-    "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit", "sml_train_fit_batched", "sml_train_release_workspace",
+    "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit", "sml_train_fit_batched", "sml_train_select_solver", "sml_train_release_workspace",
 ]
 
 

@@ -1039,7 +1039,7 @@ int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int 
         const ResDesc &D = b->res[s].desc;
         if (D.loaded && c_dev[s] && b_dev[s] && targets_dev[s]) per_batch_bytes += (size_t)D.n * batch * sizeof(double);
     }
-    static const int forced_group = getenv("SML_TRAIN_GROUP") ? atoi(getenv("SML_TRAIN_GROUP")) : 0;
+    static const int forced_group = getenv("SML_TRAIN_FLUSH_GROUP") ? atoi(getenv("SML_TRAIN_FLUSH_GROUP")) : 0;
     int group = forced_group > 0 ? forced_group : std::max(1, std::min(16, 2048 / batch));
     while (group > 1 && per_batch_bytes * group > ((size_t)16 << 30)) --group;
     std::vector<TrainSlot> ts(b->capacity, TrainSlot{nullptr, 0});

@@ -17,10 +17,10 @@
 //   LU         : right-looking blocked LU with partial pivoting (dgesv semantics) on the row-major system [A^T+reg | B^T+prior], so
 //                that the forward substitution of the right-hand sides rides along.  128-column panels, factored recursively:
 //                8-column register-resident leaves (k_lu_leaf: one barrier per pivot) and k_lu_panel_update for the rest of
-//                the panel; one composite row permutation per panel (k_lu_perm_src), applied as U12 is formed by k_lu_trsm_mfma<true>;
+//                the panel; one composite row permutation per panel (k_lu_perm_src), applied as U12 is formed by k_lu_trsm_mfma<1>;
 //                trailing update with k_gemm_nt_dma (alpha = -1), the next panel's strip first (look-ahead on two streams, the
 //                trailing stream CU-masked so that the leaf always finds a free CU); blocked back substitution
-//                (k_lu_trsm_mfma<false>, k_lu_backsub_near, k_lu_backsub_step).  Up to FIT_BATCH systems advance in lockstep through one chain of
+//                (k_lu_trsm_mfma<0>, k_lu_backsub_near, k_lu_backsub_step).  Up to FIT_BATCH systems advance in lockstep through one chain of
 //                launches (grid dimension z).
 // All matrices are column-major fp64, as in the reference.
 #include <cstdlib>
@@ -216,7 +216,13 @@ __global__ __launch_bounds__(GT, 2) void k_gemm_nt_dma(const double *__restrict_
     __shared__ __attribute__((aligned(16))) double S[NBUF][2][DKT][LDS_LD];       // [ring slot][operand][k][row]  73.7 KB
     int ti, tj;
     if (mode == 0) { ti = blockIdx.x; tj = blockIdx.y; }
-    else tri_tile((int)blockIdx.x, ti, tj);
+    else {
+        // mode 1: tiles on or below the diagonal of a square product; mode 2: the same for M > N (the Cholesky's trailing update with
+        // the right-hand sides riding along): the triangle of the nbj x nbj square, then the full tile rows below it
+        const int nbj = (N + BN - 1) / BN, ntri = nbj * (nbj + 1) / 2, L = (int)blockIdx.x;
+        if (mode == 1 || L < ntri) tri_tile(L, ti, tj);
+        else { ti = nbj + (L - ntri) / nbj; tj = (L - ntri) % nbj; }
+    }
     // (UN = 8: 64 rows of B per workgroup; the DMA still moves 128 -- the second half is the next tile's, clamped like any row past N)
     const int i0 = ti * BM, j0 = tj * (8 * UN);
     const WavePos w = wave_pos<UN>();
@@ -533,7 +539,7 @@ __global__ void k_symmetrize_diag(double *__restrict__ c, int n)
 //             k_lu_panel_update : rank-8 update of the panel's remaining columns, all CUs ]
 //   G: k_lu_perm_src (the composite permutation of the panel's 128 interchanges on the <= 256 rows they touch: no dependent chain of
 //      128 swaps, and no separate pass over W -- the triangular solve reads its rows through it),
-//      k_lu_trsm_mfma<true> (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
+//      k_lu_trsm_mfma<1> (U12 = L11^-1 A12 + the displaced rows written back), then the trailing update with the MFMA GEMM at
 //      K = 128: FIRST the next panel's 128 columns (+ k_lu_strip_to_panel, which hands them to P), THEN the rest, which runs
 //      beside the next panel's leaf chain (look-ahead).
 // Back substitution, per 128-row block from the bottom: k_lu_backsub_near (the block above gets the solved block's update), then
@@ -550,14 +556,16 @@ constexpr int LU_LEAF = 8;     // columns factorised in registers by one workgro
 // stream pairs were multiplexed onto the runtime's four hardware queues and ran no faster than one after another (measured).
 struct LuStride { long w, p; int ipiv; };
 
+// upper_only: W's strict lower triangle is left alone (the Cholesky reads j >= i only: C(j,i) with j >= i is the LOWER triangle of the
+// column-major C, the part sml_train_accumulate always fills -- no symmetrisation pass)
 __global__ void k_build_system(const double *const *__restrict__ c_list, const double *const *__restrict__ b_list, double *__restrict__ w, long ld, int n_aug,
-                               int n_model, int n_out, double reg_model, double reg_res, double prior_diag, LuStride ls)
+                               int n_model, int n_out, double reg_model, double reg_res, double prior_diag, LuStride ls, int upper_only)
 {
     const double *__restrict__ c = c_list[blockIdx.z], *__restrict__ b = b_list[blockIdx.z];
     w += ls.w * blockIdx.z;
     const int i = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ld) return;
+    if (j >= ld || (upper_only && j < i)) return;
     double v = 0.0;
     if (j < n_aug) {
         v = c[(long)j + (long)i * n_aug];
@@ -967,7 +975,9 @@ extern __shared__ __attribute__((aligned(16))) double lu_dyn_lds[];      // (the
 // throughout, 1.79e-17 for LAPACK on the host (tests/test_train_gpu.py prints it).
 constexpr int TRM_LD = 133;
 constexpr size_t TRM_LDS = sizeof(double) * ((size_t)LU_NBO * TRM_LD + 2 * LU_NBO + 16 * (LU_NBO / 4));
-template <bool LOWER>
+// MODE 0: UPPER (U X = Y, U row-major in W); 1: LOWER, unit diagonal, the LU's panel + its interchanges; 2: LOWER with its own diagonal and no
+// interchanges -- the Cholesky's U12 = U11^-T A12, the triangle read as the transpose of U11 in W (L(i,k) = U11(k,i): i contiguous)
+template <int MODE>
 __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
                                                   int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
                                                   long tri_stride, int bx, int by)
@@ -979,6 +989,7 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
     const int ri = lane >> 4, cc = lane & 15;
     const int j = c0 + (bx * nwv + wave) * 16 + cc;
     const bool ok = j < ncols;
+    constexpr bool LOWER = MODE != 0, UNIT = MODE == 1;
     constexpr int NQ = LU_NBO / 4;
     // The triangle goes through registers in batches of 32 loads per thread (one batch with 512 threads, two with 256); the first
     // batch is in flight while the rows are fetched (with 8 loads per batch a 256-thread workgroup paid eight round trips).
@@ -991,7 +1002,7 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
             int i, k;
             if (LOWER) { i = e & (LU_NBO - 1); k = e >> 7; }  // L is column-major in the panel buffer: i contiguous
             else { k = e & (LU_NBO - 1); i = e >> 7; }        // U is row-major in W: k contiguous
-            const bool in = i < nbp && k < nbp && (LOWER ? k < i : k >= i);
+            const bool in = i < nbp && k < nbp && (MODE == 1 ? k < i : MODE == 2 ? k <= i : k >= i);
             v[u] = in ? tri[(long)i * tri_ld_i + (long)k * tri_ld_k] : 0.0;
         }
     };
@@ -1001,7 +1012,7 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
             const int e = e0 + nthr * u;
             const int i = LOWER ? (e & (LU_NBO - 1)) : (e >> 7), k = LOWER ? (e >> 7) : (e & (LU_NBO - 1));
             T[i * TRM_LD + k] = i == k ? 0.0 : -v[u];
-            if (!LOWER && i == k) {
+            if (!UNIT && i == k) {
                 const double d = i < nbp ? v[u] : 1.0;
                 dg[i] = d; rdg[i] = 1.0 / d;
             }
@@ -1010,7 +1021,7 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
     const bool second = nthr * SB < LU_NBO * LU_NBO;          // (uniform)
     stage_load(threadIdx.x);
     double a[NQ];
-    if (LOWER) {
+    if (MODE == 1) {
         ipiv += ls.ipiv * by; src += 2 * LU_NBO * by;
         // every read of this wavefront's columns comes before the first store into them (a displaced row may be another position's source)
         double dv[NQ];
@@ -1054,6 +1065,7 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < i) v = __builtin_fma(tq[i * TRM_LD + k], y[k], v);
+                if (!UNIT) v = v / dg[4 * q + i];
                 y[i] = i >= c ? v : 0.0;
             }
         } else {
@@ -1087,12 +1099,12 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
     }
 }
 
-template <bool LOWER>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_lu_trsm_mfma(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
                                                        int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
                                                        long tri_stride)
 {
-    lu_trsm_mfma_body<LOWER>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, src, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
+    lu_trsm_mfma_body<MODE>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, src, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // back substitution update: Y(i, :) -= sum_k U(i, K0 + k) X(K0 + k, :) for the rows i < K0 above a solved block (K = nb <= 128,
@@ -1227,18 +1239,115 @@ __global__ __launch_bounds__(256) void k_lu_backsub_near(double *__restrict__ y,
     if (rok && col + 1 < nrhs) yp[1] = acc1;
 }
 
-// One step of the back substitution as ONE launch: the first ntr workgroups solve the block at Kt (as k_lu_trsm_mfma<false>), the others
+// One step of the back substitution as ONE launch: the first ntr workgroups solve the block at Kt (as k_lu_trsm_mfma<0>), the others
 // apply the block solved in the step before (at Ku = Kt + 128) to the rows above Kt -- the two are independent once the rows of the
 // block at Kt have had that update (k_lu_backsub_near, the launch before this one), and one after the other
 // on one stream they took 34 + 38 us per step.
-__global__ __launch_bounds__(TRL_T) void k_lu_backsub_step(double *__restrict__ w, long ld, int n_aug, int nrhs, int Kt, int nbt, int Ku, int nbu, int ntr,
+// (rhs0 = first column of W of this group of right-hand sides: n_aug + a multiple of BS_CG * 8)
+__global__ __launch_bounds__(TRL_T) void k_lu_backsub_step(double *__restrict__ w, long ld, int rhs0, int nrhs, int Kt, int nbt, int Ku, int nbu, int ntr,
                                                             int nwu, LuStride ls)
 {
     if ((int)blockIdx.x < ntr)          // (512 threads: eight wavefronts x 16 right-hand sides per solving workgroup)
-        lu_trsm_mfma_body<false>(w + (long)Kt * ld + Kt, 1L, ld, w, ld, Kt, nbt, n_aug, n_aug + nrhs, nullptr, nullptr, ls, ls.w, (int)blockIdx.x,
+        lu_trsm_mfma_body<0>(w + (long)Kt * ld + Kt, 1L, ld, w, ld, Kt, nbt, rhs0, rhs0 + nrhs, nullptr, nullptr, ls, ls.w, (int)blockIdx.x,
                                  (int)blockIdx.y);
     else
-        lu_backsub_update_body(w + n_aug, w, ld, Ku, nbu, nrhs, ls, ((int)blockIdx.x - ntr) * BS_ROWS, nwu * BS_ROWS, Kt, (int)blockIdx.y);
+        lu_backsub_update_body(w + rhs0, w, ld, Ku, nbu, nrhs, ls, ((int)blockIdx.x - ntr) * BS_ROWS, nwu * BS_ROWS, Kt, (int)blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Cholesky for the ridge systems: C + diag(beta) is symmetric positive definite by construction (C = sum aug aug^T, a positive diagonal
+// added: src/mod_reservoir.f90:1275-1282), so the general pivoted LU above does work the problem does not need: no pivot search, no
+// interchanges, no column-by-column leaf chain, and only the triangle of the trailing matrix.  Same storage as the LU: the row-major
+// system W = [A | B^T] (right-hand sides as extra columns); A = U^T U with U upper triangular IN the upper triangle of W (row-major:
+// the trailing update's operands U12(k, :) are rows of W, read contiguously by the LDS-DMA GEMM -- no panel buffer at all); the
+// forward substitution rides along (the U12 solve covers the right-hand-side columns), and the back substitution U X = Y is the LU's own.
+//   per 128-row block k:  k_chol_potrf (ONE workgroup: the diagonal block)  ->  k_lu_trsm_mfma<2> (U12 = U11^-T A12, all columns to the
+//   right, MFMA)  ->  trailing update A22 -= U12^T U12 with k_gemm_nt_dma at K = 128, lower-trapezoid tile list (i >= j only):
+//   block row k+1 first, on the panel stream (the next potrf waits for nothing else), block row k+2 next and the rest after it on the
+//   trailing stream.
+// A non-positive (or NaN) pivot sets info; the host then solves the system with the LU (indefinite or numerically singular systems).
+//
+// k_chol_potrf: the 128 x 128 diagonal block in the registers of eight wavefronts, in the accumulator layout of v_mfma_f64_4x4x4 exactly
+// as lu_trsm_mfma_body holds its rows: wavefront w owns columns 16 w .. 16 w + 15 and all 128 rows (lane = 16 i + c: row 4 q + i of
+// quad q in register q).  Right-looking over the 32 row quads; per quad: (1) the diagonal 4 x 4 goes to LDS and EVERY lane factorises it
+// (R^T R, then M = R^-T by substitution: 4 square roots and 4 divisions in a dependent chain -- the chain of the whole kernel), (2) each
+// wavefront solves its 16 columns of the row quad with ONE MFMA (M as the A operand) and stores them, (3) the solved row quad goes to
+// LDS and every later quad gets its rank-4 update as ONE MFMA (A operand = -U(quad rows, the later quad's columns)^T, a 16-address LDS
+// read).  Two barriers per quad (the LDS buffers alternate); wavefront w stops at quad 4 w + 3 (rows below its columns are never read).
+constexpr int CH_T = 512;
+__global__ __launch_bounds__(CH_T) void k_chol_potrf(double *__restrict__ w, long ld, int K0, int nb, int *__restrict__ info, LuStride ls)
+{
+    w += ls.w * blockIdx.x; info += blockIdx.x;
+    __shared__ __attribute__((aligned(16))) double dq[2][4][4];
+    __shared__ __attribute__((aligned(16))) double xrow[2][4][LU_NBO + 4];
+    constexpr int NQ = LU_NBO / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ri = lane >> 4, cc = lane & 15, col = 16 * wave + cc;
+    double *const base = w + (long)K0 * ld + K0 + col;
+    double a[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int row = 4 * q + ri;
+        // (rows and columns past a short last block: the identity; below the diagonal: never used, kept finite)
+        a[q] = (row < nb && col < nb && row <= col) ? base[(long)row * ld] : (row == col ? 1.0 : 0.0);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int par = q & 1, wq = q >> 2, c0q = 4 * (q & 3);
+        if (wave == wq && cc >= c0q && cc < c0q + 4) dq[par][ri][cc - c0q] = a[q];
+        __syncthreads();
+        // R^T R = D (upper R), then M = R^-T (lower): m(i,k), k <= i
+        const double d00 = dq[par][0][0], d01 = dq[par][0][1], d02 = dq[par][0][2], d03 = dq[par][0][3];
+        const double d11 = dq[par][1][1], d12 = dq[par][1][2], d13 = dq[par][1][3];
+        const double d22 = dq[par][2][2], d23 = dq[par][2][3], d33 = dq[par][3][3];
+        if (!(d00 > 0.0)) bad = bad ? bad : 4 * q + 1;
+        const double r00 = sqrt(d00), i0 = 1.0 / r00;
+        const double r01 = d01 * i0, r02 = d02 * i0, r03 = d03 * i0;
+        const double e11 = d11 - r01 * r01;
+        if (!(e11 > 0.0)) bad = bad ? bad : 4 * q + 2;
+        const double r11 = sqrt(e11), i1 = 1.0 / r11;
+        const double r12 = (d12 - r01 * r02) * i1, r13 = (d13 - r01 * r03) * i1;
+        const double e22 = d22 - r02 * r02 - r12 * r12;
+        if (!(e22 > 0.0)) bad = bad ? bad : 4 * q + 3;
+        const double r22 = sqrt(e22), i2 = 1.0 / r22;
+        const double r23 = (d23 - r02 * r03 - r12 * r13) * i2;
+        const double e33 = d33 - r03 * r03 - r13 * r13 - r23 * r23;
+        if (!(e33 > 0.0)) bad = bad ? bad : 4 * q + 4;
+        const double r33 = sqrt(e33), i3 = 1.0 / r33;
+        // M = (R^T)^-1: column by column of the lower triangle
+        const double m10 = -(r01 * i0) * i1;
+        const double m20 = -(r02 * i0 + r12 * m10) * i2, m21 = -(r12 * i1) * i2;
+        const double m30 = -(r03 * i0 + r13 * m10 + r23 * m20) * i3, m31 = -(r13 * i1 + r23 * m21) * i3, m32 = -(r23 * i2) * i3;
+        // this lane's element of the MFMA's A operand: (i, k) = (lane & 3, lane >> 4)
+        const int mi = lane & 3, mk = lane >> 4;
+        double mv = 0.0;
+        mv = (mi == 0 && mk == 0) ? i0 : mv; mv = (mi == 1 && mk == 1) ? i1 : mv; mv = (mi == 2 && mk == 2) ? i2 : mv; mv = (mi == 3 && mk == 3) ? i3 : mv;
+        mv = (mi == 1 && mk == 0) ? m10 : mv; mv = (mi == 2 && mk == 0) ? m20 : mv; mv = (mi == 2 && mk == 1) ? m21 : mv;
+        mv = (mi == 3 && mk == 0) ? m30 : mv; mv = (mi == 3 && mk == 1) ? m31 : mv; mv = (mi == 3 && mk == 2) ? m32 : mv;
+        const double xa = __builtin_amdgcn_mfma_f64_4x4x4f64(mv, a[q], 0.0, 0, 0, 0);        // U(4 q + i, col)
+        const int row = 4 * q + ri;
+        if (row < nb && col < nb && row <= col) base[(long)row * ld] = xa;
+        xrow[par][ri][col] = xa;
+        __syncthreads();
+        // rank-4 update of the later quads this wavefront still needs (rows <= its last column): groups of four quads = 16 rows
+        const double *xr = &xrow[par][lane >> 4][lane & 3];                                  // A operand (i', k) = -U(4 q + k, 4 q2 + i')
+        double av[NQ];                              // every later quad's operand in ONE batch of reads (a read inside each branch below
+#pragma unroll                                      // would put every group of MFMAs behind its own LDS round trip)
+        for (int q2 = 0; q2 < NQ; ++q2)
+            if (q2 > q) av[q2] = -xr[4 * q2];
+#pragma unroll
+        for (int g = 0; g < NQ / 4; ++g) {
+            if (4 * g + 3 > q && g <= wave) {                                                // (uniform)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int q2 = 4 * g + t;
+                    if (q2 > q) a[q2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q2], xa, a[q2], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (bad && threadIdx.x == 0 && *info == 0) *info = K0 + bad;
 }
 
 template <bool A_KC, bool B_KC>
@@ -1269,6 +1378,9 @@ int gemm_nt(const double *A, long lda, const double *B, long ldb, double *C, lon
         const int nbi = (M + BM - 1) / BM, nbj = (N + BN - 1) / BN;
         if (half_j && !lower_only)      // 128 x 64 tiles: twice the workgroups, half the MFMA stream each (a product of few tiles is one tile's latency)
             hipLaunchKernelGGL(k_gemm_nt_dma<8>, dim3(nbi, (N + 63) / 64, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0, Mr, Nr, gb);
+        else if (lower_only && nbi > nbj)      // trapezoid: tiles with ti >= tj
+            hipLaunchKernelGGL(k_gemm_nt_dma<16>, dim3(nbj * (nbj + 1) / 2 + (nbi - nbj) * nbj, 1, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain,
+                               alpha, 2, Mr, Nr, gb);
         else if (!lower_only || nbi != nbj)
             hipLaunchKernelGGL(k_gemm_nt_dma<16>, dim3(nbi, nbj, nbatch), dim3(GT), 0, st, A, lda, B, ldb, C, ldc, M, N, kmain, alpha, 0, Mr, Nr, gb);
         else
@@ -1627,6 +1739,7 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
 
 // leaf shape by height: (threads, rows per thread, columns); R x LW doubles + ~56 registers must stay within 256
 struct LeafShape { int threads, slots, width; };
+constexpr int LU_LEAF_MAX_ROWS = 14 * 512;
 static LeafShape leaf_shape(int rows_left)
 {
     if (rows_left <= 14 * 256) return {256, (rows_left + 255) / 256, 8};
@@ -1679,6 +1792,48 @@ static int lu_trailing(LuSys &S, int nb, long ld, long np, int n_aug, int K0, in
                    nb, GemmBatch{S.ls.w, S.ls.p, S.ls.w}, half_j);
 }
 
+// Back substitution U X = Y on the right-hand-side columns of W (U = the upper triangle of W's rows, from the LU or the Cholesky), on
+// S.sg behind everything S.sp did; right-hand sides in groups of BS_CG * 8 = 136 columns (one group for the shipped 132 / 136 outputs).
+static int backsub_enqueue(LuSys &S, int nb, int n_aug, int n_out, long ld)
+{
+    const LuStride ls = S.ls;
+    SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+    SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+    const size_t bs_lds = (size_t)(LU_NBO * BS_CG * 8 + BS_ROWS * LU_NBO) * sizeof(double);
+    static bool bs_attr = false;
+    if (!bs_attr) {
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRM_LDS)));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
+        bs_attr = true;
+    }
+    for (int r0 = 0; r0 < n_out; r0 += BS_CG * 8) {
+        const int nr = std::min(BS_CG * 8, n_out - r0), rhs0 = n_aug + r0;
+        // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns rhs0 .. rhs0 + nr of W
+        auto solve_block = [&](int K0) {
+            hipLaunchKernelGGL(k_lu_trsm_mfma<0>, dim3((nr + 63) / 64, nb), dim3(256), TRM_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
+                               std::min(LU_NBO, n_aug - K0), rhs0, rhs0 + nr, (const int *)nullptr, (const int *)nullptr, ls, ls.w);
+        };
+        // per step: the 128 rows of the next block get the update first (they are what the chain waits for), then ONE launch solves that
+        // block and updates the rows above it (one workgroup per CU: at most as many far-update workgroups as S.sg has CUs left)
+        const int K_last = ((n_aug - 1) / LU_NBO) * LU_NBO, ntm = (nr + 127) / 128;
+        solve_block(K_last);
+        for (int K0 = K_last; K0 > 0; K0 -= LU_NBO) {
+            const int Kn = K0 - LU_NBO;
+            hipLaunchKernelGGL(k_lu_backsub_near, dim3(LU_NBO / BN_ROWS, (nr + BN_COLS - 1) / BN_COLS, nb), dim3(256), 0, S.sg, S.w + rhs0, S.w, ld, K0,
+                               std::min(LU_NBO, n_aug - K0), nr, Kn, ls);
+            if (Kn > 0) {
+                const int groups = (Kn + BS_ROWS - 1) / BS_ROWS;
+                const int nwu = nb == 1 ? std::min(groups, std::max(1, S.sg_cus - ntm)) : groups;
+                hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntm + nwu, nb), dim3(TRL_T), std::max(bs_lds, TRM_LDS), S.sg, S.w, ld, rhs0, nr, Kn, LU_NBO, K0,
+                                   std::min(LU_NBO, n_aug - K0), ntm, nwu, ls);
+            } else
+                solve_block(0);
+            SML_HIP(hipGetLastError());
+        }
+    }
+    return SML_OK;
+}
+
 // enqueue the ridge solves of systems [first, first + nb) (no host synchronisation): everything is ordered on S.sg / S.sp
 static int fit_enqueue(double *const *c, const double *const *b, int first, int nb, int n, int n_model, int n_out, double beta_res, double beta_model,
                        double prior_val, int using_prior, double *const *wout, LuSys &S)
@@ -1689,8 +1844,8 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     int rc;
     static bool trl_attr = false;
     if (!trl_attr) {
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
         trl_attr = true;
     }
     for (int i = 0; i < nb; ++i)
@@ -1704,7 +1859,7 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
     const double reg_res = using_prior ? beta_res * beta_res : beta_res;
     const double prior_diag = using_prior ? prior_val * (beta_model * beta_model) : 0.0;
     hipLaunchKernelGGL(k_build_system, dim3((unsigned)((ld + 255) / 256), n_aug, nb), dim3(256), 0, S.sg, S.c_list, S.b_list, S.w, ld, n_aug, n_model, n_out,
-                       reg_model, reg_res, prior_diag, ls);
+                       reg_model, reg_res, prior_diag, ls, 0);
     SML_HIP(hipGetLastError());
     auto strip_to_panel = [&](int K0, int nbp, double *P, hipStream_t st) {
         hipLaunchKernelGGL(k_lu_strip_to_panel, dim3((n_aug - K0 + 31) / 32, (nbp + 31) / 32, nb), dim3(256), 0, st, S.w, ld, P, np, n_aug, K0, nbp, ls);
@@ -1737,7 +1892,7 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         const int ce = (S.confined && c0 < n_aug) ? c0 + std::min(LU_NBO, n_aug - c0) : ncols;    // (exactly the columns lu_trailing updates on S.sp)
         auto gather_and_u12 = [&](int j0, int j1, hipStream_t st) {
             if (j1 <= j0) return;
-            hipLaunchKernelGGL(k_lu_trsm_mfma<true>, dim3((j1 - j0 + 63) / 64, nb), dim3(256), TRM_LDS, st, Pk + K0, np, 1L, S.w, ld, K0, nbp, j0, j1, S.ipiv,
+            hipLaunchKernelGGL(k_lu_trsm_mfma<1>, dim3((j1 - j0 + 63) / 64, nb), dim3(256), TRM_LDS, st, Pk + K0, np, 1L, S.w, ld, K0, nbp, j0, j1, S.ipiv,
                                S.src, ls, ls.p);
         };
         if (S.confined) {                                                    // S.sg needs the permutation; it is long done with panel k-1
@@ -1764,39 +1919,72 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         SML_HIP(hipGetLastError());
         SML_HIP(hipEventRecord(S.ev_strip, S.sg));                          // (reused: "S.sg is done with panel k")
     }
-    // the back substitution runs on S.sg: behind everything S.sp did
-    SML_HIP(hipEventRecord(S.ev_panel, S.sp));
-    SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
-    // back substitution on the right-hand sides (columns n_aug .. ncols of W)
-    SML_REQUIRE(n_out <= BS_CG * 8, "sml_train_fit: n_out = %d exceeds the %d right-hand sides of the back substitution kernel", n_out, BS_CG * 8);
-    const size_t bs_lds = (size_t)(LU_NBO * BS_CG * 8 + BS_ROWS * LU_NBO) * sizeof(double);
-    static bool bs_attr = false;
-    if (!bs_attr) {
-        SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRM_LDS)));
-        bs_attr = true;
+    if ((rc = backsub_enqueue(S, nb, n_aug, n_out, ld))) return rc;
+    const long tw = (long)n_aug * n_out;
+    hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256), nb), dim3(256), 0, S.sg, S.w, ld, S.wout_list, n_aug, n_out, ls);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+// ---- the Cholesky chain of systems [first, first + nb) (see k_chol_potrf) ----
+static int chol_update(LuSys &S, int nb, long ld, int ncols, int K0, int nbp, int r0, int nrows, hipStream_t st, bool whole_rows)
+{
+    // W[r0 + j][r0 + i] -= sum_k U(K0 + k, r0 + j) U(K0 + k, r0 + i) for j < nrows, i >= j (and every i when the block is one tile row)
+    double *u = S.w + (long)K0 * ld + r0;
+    const bool half_j = whole_rows && nb == 1;
+    return gemm_nt(u, ld, u, ld, S.w + (long)r0 * ld + r0, ld, ncols - r0, nrows, nbp, -1.0, whole_rows ? 0 : 1, st, lu_dma(), /*padded=*/true, nb,
+                   GemmBatch{S.ls.w, S.ls.w, S.ls.w}, half_j);
+}
+
+static int chol_enqueue(double *const *c, const double *const *b, int first, int nb, int n, int n_model, int n_out, double beta_res, double beta_model,
+                        double prior_val, int using_prior, double *const *wout, LuSys &S)
+{
+    const int n_aug = n + n_model, ncols = n_aug + n_out;
+    const long ld = lu_pad16(ncols);
+    const LuStride ls = S.ls;
+    int rc;
+    static bool attr = false;
+    if (!attr) {
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
+        attr = true;
     }
-    // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns n_aug .. n_aug + n_out of W
-    auto solve_block = [&](int K0) {
-        hipLaunchKernelGGL(k_lu_trsm_mfma<false>, dim3((n_out + 63) / 64, nb), dim3(256), TRM_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
-                           std::min(LU_NBO, n_aug - K0), n_aug, n_aug + n_out, (const int *)nullptr, (const int *)nullptr, ls, ls.w);
-    };
-    // per step: the 128 rows of the next block get the update first (they are what the chain waits for), then ONE launch solves that
-    // block and updates the rows above it (one workgroup per CU: at most as many far-update workgroups as S.sg has CUs left)
-    const int K_last = ((n_aug - 1) / LU_NBO) * LU_NBO, ntm = (n_out + 127) / 128;
-    solve_block(K_last);
-    for (int K0 = K_last; K0 > 0; K0 -= LU_NBO) {
-        const int Kn = K0 - LU_NBO;
-        hipLaunchKernelGGL(k_lu_backsub_near, dim3(LU_NBO / BN_ROWS, (n_out + BN_COLS - 1) / BN_COLS, nb), dim3(256), 0, S.sg, S.w + n_aug, S.w, ld, K0,
-                           std::min(LU_NBO, n_aug - K0), n_out, Kn, ls);
-        if (Kn > 0) {
-            const int groups = (Kn + BS_ROWS - 1) / BS_ROWS;
-            const int nwu = nb == 1 ? std::min(groups, std::max(1, S.sg_cus - ntm)) : groups;
-            hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntm + nwu, nb), dim3(TRL_T), std::max(bs_lds, TRM_LDS), S.sg, S.w, ld, n_aug, n_out, Kn, LU_NBO, K0,
-                               std::min(LU_NBO, n_aug - K0), ntm, nwu, ls);
-        } else
-            solve_block(0);
+    SML_HIP(hipMemsetAsync(S.info, 0, sizeof(int) * nb, S.sg));
+    SML_HIP(hipMemcpyAsync((void *)S.c_list, c + first, sizeof(double *) * nb, hipMemcpyHostToDevice, S.sg));
+    SML_HIP(hipMemcpyAsync((void *)S.b_list, b + first, sizeof(double *) * nb, hipMemcpyHostToDevice, S.sg));
+    SML_HIP(hipMemcpyAsync((void *)S.wout_list, wout + first, sizeof(double *) * nb, hipMemcpyHostToDevice, S.sg));
+    const double reg_model = using_prior ? beta_model * beta_model : beta_model;
+    const double reg_res = using_prior ? beta_res * beta_res : beta_res;
+    const double prior_diag = using_prior ? prior_val * (beta_model * beta_model) : 0.0;
+    hipLaunchKernelGGL(k_build_system, dim3((unsigned)((ld + 255) / 256), n_aug, nb), dim3(256), 0, S.sg, S.c_list, S.b_list, S.w, ld, n_aug, n_model, n_out,
+                       reg_model, reg_res, prior_diag, ls, 1);
+    SML_HIP(hipGetLastError());
+    SML_HIP(hipEventRecord(S.ev_strip, S.sg));
+    SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));
+    // Streams.  S.sp carries what the next diagonal block waits for: potrf(k), the U12 solve, block row k+1's update.  S.sg (CU-masked)
+    // carries the rest of panel k's trailing update, block row k+2 first: S.sp waits for THAT part only (ev_strip) before it touches
+    // block row k+2 itself one panel later; the rows below were last written by S.sg, in order.
+    for (int K0 = 0, k = 0; K0 < n_aug; K0 += LU_NBO, ++k) {
+        const int nbp = std::min(LU_NBO, n_aug - K0), c0 = K0 + nbp;
+        hipLaunchKernelGGL(k_chol_potrf, dim3(nb), dim3(CH_T), 0, S.sp, S.w, ld, K0, nbp, S.info, ls);
+        hipLaunchKernelGGL(k_lu_trsm_mfma<2>, dim3((ncols - c0 + 63) / 64, nb), dim3(256), TRM_LDS, S.sp, S.w + (long)K0 * ld + K0, ld, 1L, S.w, ld, K0, nbp, c0, ncols,
+                           (const int *)nullptr, (const int *)nullptr, ls, ls.w);
         SML_HIP(hipGetLastError());
+        if (c0 >= n_aug) break;
+        SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+        SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+        if (k > 0) SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));          // S.sg is done with block row k+1 (panel k-1's first part)
+        const int nb1 = std::min(LU_NBO, n_aug - c0);
+        if ((rc = chol_update(S, nb, ld, ncols, K0, nbp, c0, nb1, S.sp, true))) return rc;
+        const int r1 = c0 + nb1;
+        if (r1 < n_aug) {
+            const int nb2 = std::min(LU_NBO, n_aug - r1);
+            if ((rc = chol_update(S, nb, ld, ncols, K0, nbp, r1, nb2, S.sg, true))) return rc;
+            SML_HIP(hipEventRecord(S.ev_strip, S.sg));
+            const int r2 = r1 + nb2;
+            if (r2 < n_aug && (rc = chol_update(S, nb, ld, ncols, K0, nbp, r2, n_aug - r2, S.sg, false))) return rc;
+        }
     }
+    if ((rc = backsub_enqueue(S, nb, n_aug, n_out, ld))) return rc;
     const long tw = (long)n_aug * n_out;
     hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256), nb), dim3(256), 0, S.sg, S.w, ld, S.wout_list, n_aug, n_out, ls);
     SML_HIP(hipGetLastError());
@@ -1804,37 +1992,56 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
 }
 
 // Several independent ridge solves at once: up to FIT_BATCH equally sized systems are factorised in lockstep by ONE chain of
-// launches (the grid's batch dimension), so the latency-bound leaf chain is paid once per batch and the trailing updates of all of
+// launches (the grid's batch dimension), so the latency-bound panel chain is paid once per batch and the trailing updates of all of
 // them fill the chip together.  c/b/wout are host arrays of device pointers.  Synchronises; returns SML_ERR_NUMERIC if any system is
 // singular (sml_last_error names the first).
-// The scratch of a batch (per system: the row-major system, two panel buffers: ~300 MB at n_aug = 5892) and its
-// streams are kept between calls: allocating them took 12 ms of a 43 ms call.  sml_train_release_workspace frees them.
+// The scratch of a batch (per system: the row-major system, two panel buffers: ~300 MB at n_aug = 5892) and its streams are kept
+// between calls (allocating them took 12 ms of a 43 ms call), one workspace for single solves and one for batches -- their stream
+// layouts differ (lu_sys_alloc) -- each tied to the device it was made on.  sml_train_release_workspace frees them.
 constexpr int FIT_BATCH = 16;            // (8 / 16 / 32 systems in lockstep: 7.3 / 6.3 / 6.5 ms per 5892-row system, profiles/micro/fit_batch_sizes.py)
-static LuSys g_lu;
-static int g_lu_n = 0, g_lu_cols = 0;
+struct FitWorkspace { LuSys sys; int n_aug = 0, ncols = 0, dev = -1; };
+static FitWorkspace g_ws[2];             // [0] single solves, [1] batches
+static int g_solver = -1;                // 0 auto (Cholesky, LU where it breaks down), 1 LU, 2 Cholesky only; -1: not read from the environment yet
 
 int sml_train_release_workspace(void)
 {
-    lu_sys_free(g_lu);
-    g_lu_n = g_lu_cols = 0;
+    for (FitWorkspace &ws : g_ws) {
+        lu_sys_free(ws.sys);
+        ws.n_aug = ws.ncols = 0; ws.dev = -1;
+    }
     return SML_OK;
 }
 
-int sml_train_fit_batched(int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res,
-                          double beta_model, double prior_val, int using_prior, double *const *wout, void *stream)
+/* 0 = Cholesky with the LU where a pivot is not positive (default; SML_FIT_SOLVER=lu|chol|auto presets it), 1 = always the pivoted LU
+ * (dgesv's algorithm: what mldivide does for a general matrix), 2 = Cholesky only (SML_ERR_NUMERIC when the system is not positive
+ * definite).  Returns the previous setting. */
+int sml_train_select_solver(int solver)
 {
-    SML_REQUIRE(count > 0 && c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit_batched: bad arguments");
-    for (int i = 0; i < count; ++i) SML_REQUIRE(c[i] && b[i] && wout[i], "sml_train_fit_batched: null system %d", i);
-    hipStream_t st = sml::as_stream(stream);
+    if (g_solver < 0) {
+        const char *e = getenv("SML_FIT_SOLVER");
+        g_solver = (e && !strcmp(e, "lu")) ? 1 : (e && !strcmp(e, "chol")) ? 2 : 0;
+    }
+    const int prev = g_solver;
+    if (solver >= 0 && solver <= 2) g_solver = solver;
+    return prev;
+}
+
+static int fit_run(bool chol, int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res, double beta_model,
+                   double prior_val, int using_prior, double *const *wout, hipStream_t st, std::vector<int> &hinfo)
+{
     const int n_aug = n + n_model, ncols = n_aug + n_out;
     static const int fit_batch = getenv("SML_FIT_BATCH") ? std::max(1, atoi(getenv("SML_FIT_BATCH"))) : FIT_BATCH;
     const int nbmax = std::min(count, fit_batch);
-    int rc = SML_OK;
-    if (g_lu_n != n_aug || g_lu_cols != ncols || g_lu.nbatch < nbmax) {
-        sml_train_release_workspace();
-        if ((rc = lu_sys_alloc(g_lu, n_aug, ncols, nbmax))) { sml_train_release_workspace(); return rc; }
-        g_lu_n = n_aug; g_lu_cols = ncols;
+    int rc = SML_OK, dev = 0;
+    SML_HIP(hipGetDevice(&dev));
+    FitWorkspace &ws = g_ws[nbmax == 1 ? 0 : 1];
+    if (ws.n_aug != n_aug || ws.ncols != ncols || ws.sys.nbatch < nbmax || ws.dev != dev) {
+        lu_sys_free(ws.sys);
+        ws.n_aug = ws.ncols = 0; ws.dev = -1;
+        if ((rc = lu_sys_alloc(ws.sys, n_aug, ncols, nbmax))) { lu_sys_free(ws.sys); return rc; }
+        ws.n_aug = n_aug; ws.ncols = ncols; ws.dev = dev;
     }
+    LuSys &S = ws.sys;
     static const bool want_stamps = getenv("SML_LU_STAMP") && atoi(getenv("SML_LU_STAMP"));
     if (want_stamps && !g_lu_stamps) {
         SML_HIP(hipMalloc((void **)&g_lu_stamps, sizeof(long long) * 32 * LU_STAMP_LEAVES));
@@ -1844,22 +2051,23 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
     hipEvent_t fork = nullptr;
     SML_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     hipError_t fe = hipEventRecord(fork, st);
-    if (fe == hipSuccess) fe = hipStreamWaitEvent(g_lu.sg, fork, 0);
+    if (fe == hipSuccess) fe = hipStreamWaitEvent(S.sg, fork, 0);
     (void)hipEventDestroy(fork);
     if (fe != hipSuccess) return sml::fail(SML_ERR_HIP, "sml_train_fit_batched: %s", hipGetErrorString(fe));
-    std::vector<int> hinfo(count, 0);
-    for (int first = 0; first < count && rc == SML_OK; first += g_lu.nbatch) {
-        const int nb = std::min(g_lu.nbatch, count - first);
-        rc = fit_enqueue(c, b, first, nb, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, g_lu);
+    hinfo.assign(count, 0);
+    for (int first = 0; first < count && rc == SML_OK; first += S.nbatch) {
+        const int nb = std::min(S.nbatch, count - first);
+        rc = chol ? chol_enqueue(c, b, first, nb, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, S)
+                  : fit_enqueue(c, b, first, nb, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, S);
         // (the pointer lists and info are reused by the next batch: wait for this one)
-        hipError_t e = hipStreamSynchronize(g_lu.sg);
-        if (e == hipSuccess) e = hipStreamSynchronize(g_lu.sp);
+        hipError_t e = hipStreamSynchronize(S.sg);
+        if (e == hipSuccess) e = hipStreamSynchronize(S.sp);
         if (e != hipSuccess && rc == SML_OK) rc = sml::fail(SML_ERR_HIP, "sml_train_fit_batched: %s", hipGetErrorString(e));
-        if (rc == SML_OK && hipMemcpy(hinfo.data() + first, g_lu.info, sizeof(int) * nb, hipMemcpyDeviceToHost) != hipSuccess)
+        if (rc == SML_OK && hipMemcpy(hinfo.data() + first, S.info, sizeof(int) * nb, hipMemcpyDeviceToHost) != hipSuccess)
             rc = sml::fail(SML_ERR_HIP, "sml_train_fit_batched: reading info failed");
     }
     if (rc) return rc;
-    if (g_lu_stamps) {
+    if (g_lu_stamps && !chol) {
         std::vector<long long> h(32 * LU_STAMP_LEAVES);
         if (hipMemcpy(h.data(), g_lu_stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
             if (FILE *f = fopen(getenv("SML_LU_STAMP_FILE") ? getenv("SML_LU_STAMP_FILE") : "lu_stamps.bin", "wb")) {
@@ -1868,6 +2076,43 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
             }
         }
     }
+    return SML_OK;
+}
+
+int sml_train_fit_batched(int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res,
+                          double beta_model, double prior_val, int using_prior, double *const *wout, void *stream)
+{
+    SML_REQUIRE(count > 0 && c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit_batched: bad arguments");
+    for (int i = 0; i < count; ++i) SML_REQUIRE(c[i] && b[i] && wout[i], "sml_train_fit_batched: null system %d", i);
+    hipStream_t st = sml::as_stream(stream);
+    const int n_aug = n + n_model;
+    const int solver = sml_train_select_solver(-1);
+    // the pivoted LU keeps its panel in registers: LU_LEAF_MAX_ROWS rows at most (checked here, before anything is enqueued)
+    const bool lu_fits = n_aug <= LU_LEAF_MAX_ROWS;
+    if (solver == 1) SML_REQUIRE(lu_fits, "sml_train_fit: n_aug = %d exceeds the %d rows of the pivoted LU's register-resident panel (the Cholesky path has no such limit)",
+                                 n_aug, LU_LEAF_MAX_ROWS);
+    std::vector<int> hinfo;
+    int rc;
+    if (solver != 1) {
+        if ((rc = fit_run(true, count, c, b, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, st, hinfo))) return rc;
+        std::vector<int> redo;
+        for (int i = 0; i < count; ++i)
+            if (hinfo[i]) redo.push_back(i);
+        if (redo.empty()) return SML_OK;
+        if (solver == 2 || !lu_fits)
+            return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d is not positive definite (Cholesky pivot %d is not positive)%s", redo[0], hinfo[redo[0]],
+                             solver == 2 ? "" : "; its size is beyond the pivoted LU");
+        // the systems the Cholesky could not factorise (indefinite, or singular to working precision): dgesv's algorithm
+        std::vector<double *> c2, w2;
+        std::vector<const double *> b2;
+        for (int i : redo) { c2.push_back(c[i]); b2.push_back(b[i]); w2.push_back(wout[i]); }
+        std::vector<int> info2;
+        if ((rc = fit_run(false, (int)redo.size(), c2.data(), b2.data(), n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, w2.data(), st, info2))) return rc;
+        for (size_t t = 0; t < redo.size(); ++t)
+            if (info2[t]) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", redo[t], info2[t], info2[t], info2[t]);
+        return SML_OK;
+    }
+    if ((rc = fit_run(false, count, c, b, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, st, hinfo))) return rc;
     for (int i = 0; i < count; ++i)
         if (hinfo[i]) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", i, hinfo[i], hinfo[i], hinfo[i]);
     return SML_OK;

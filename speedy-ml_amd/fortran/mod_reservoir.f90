@@ -370,7 +370,7 @@ contains
   end subroutine
 
   ! train_reservoir (:214-320).  The reservoir is built here (data, A, W_in) and ENQUEUED for training with everything the device
-  ! needs (speedyml_train): the recurrences of up to SML_TRAIN_GROUP reservoirs share their per-column launches and the ridge
+  ! needs (speedyml_train): the recurrences of up to SML_TRAIN_RESIDENTS reservoirs share their per-column launches and the ridge
   ! systems of a size class are solved in lockstep.  The queue runs when it is full, when the rank's last reservoir has arrived, or
   ! when a result is needed (finish_training, called by every procedure that comes after training in program main).
   subroutine train_reservoir(reservoir, grid, model_parameters)

@@ -203,7 +203,7 @@ contains
     real(kind=dp), allocatable :: rand(:), pass_in(:,:), persistence(:,:)
     integer, allocatable :: trows(:)
     real(c_double) :: eigs
-    integer :: q, i, c, r, ncol, d, no, nm, step, total, id
+    integer :: q, i, c, r, ncol, d, no, nm, step, total
     call sml_check(sml_gen_res(int(reservoir%n, c_int), int(reservoir%k, c_int), reservoir%radius, &
                                int(30240000 + reservoir%assigned_region, c_int64_t), reservoir%rows, reservoir%cols, reservoir%vals, eigs), 'sml_gen_res')
     q = reservoir%n / reservoir%reservoir_numinputs
@@ -246,12 +246,25 @@ contains
       job%pass(i)%targ = pass_in(trows + 1, :)
       if (nm > 0) job%pass(i)%mdl = persistence(:, i:total:step)
     end do
-    id = train_enqueue(job)
-    call train_take(id, reservoir%wout)                                  ! (slab reservoirs train one at a time: 71 columns per pass)
-    call write_trained_res(reservoir, model_parameters, grid)
+    ! resident beside its atmosphere reservoir from now on; W_out arrives when the training queue runs (speedyml_train)
+    reservoir%wout = 0.0_dp
+    call load_slab_reservoir(reservoir, grid, model_parameters, reservoir%hip_slot)
+    job%bank = hip_slab_bank; job%slot = reservoir%hip_slot
     if (.not. allocated(reservoir%saved_state)) allocate(reservoir%saved_state(reservoir%n))
     reservoir%saved_state = 0.0_dp
-    call load_slab_reservoir(reservoir, grid, model_parameters, reservoir%hip_slot)
+    reservoir%hip_train_job = train_enqueue(job)
+  end subroutine
+
+  ! W_out of a slab reservoir that went through the training queue: into reservoir%wout and its weights file (fit_chunk_ml :1097)
+  subroutine finish_slab_training(reservoir, model_parameters, grid)
+    use speedyml_train
+    type(reservoir_type), intent(inout) :: reservoir
+    type(model_parameters_type), intent(in) :: model_parameters
+    type(grid_type), intent(in) :: grid
+    if (reservoir%hip_train_job <= 0) return
+    call train_take(reservoir%hip_train_job, reservoir%wout)
+    reservoir%hip_train_job = 0
+    call write_trained_res(reservoir, model_parameters, grid)
   end subroutine
 
   ! write_trained_res (:1531-1559): worker_RRRR_ocean_<trial>.nc through the reference's NetCDF helpers
@@ -369,6 +382,7 @@ contains
     type(model_parameters_type), intent(inout) :: model_parameters
     type(grid_type), intent(inout) :: grid, atmo_grid
     integer, parameter :: un_noisy_sync = 2160
+    call finish_slab_training(reservoir, model_parameters, grid)
     call get_prediction_data_from_atmo(reservoir, model_parameters, grid, atmo_reservoir, atmo_grid, model_parameters%traininglength - un_noisy_sync)
     if (.not. reservoir%sst_bool_prediction) return
     if (.not. allocated(reservoir%saved_state)) allocate(reservoir%saved_state(reservoir%n))

@@ -4,7 +4,7 @@
 ! the ridge solves of a size class in lockstep (sml_train_fit_batched).  So a call only ENQUEUES its reservoir, with everything the
 ! training needs (the interleaved passes of noisy inputs, targets and imperfect-model columns, drawn and laid out at enqueue time, in
 ! the caller's order: the random draws are those of the one-at-a-time path); the queue runs when it holds `group` jobs
-! (SML_TRAIN_GROUP, default 64), when the rank's last reservoir arrives, or when somebody needs a result (train_take).  A group of
+! (SML_TRAIN_RESIDENTS, default 64), when the rank's last reservoir arrives, or when somebody needs a result (train_take).  A group of
 ! one IS the one-at-a-time path, and larger groups give the same W_out bit for bit (fortran/test_train_batch.f90).
 module speedyml_train
   use iso_c_binding
@@ -40,7 +40,7 @@ contains
     character(len=32) :: env
     integer :: n, stat
     train_group_size = 64
-    call get_environment_variable('SML_TRAIN_GROUP', env, n, stat)
+    call get_environment_variable('SML_TRAIN_RESIDENTS', env, n, stat)
     if (stat == 0 .and. n > 0) read(env(1:n), *) train_group_size
     train_group_size = max(train_group_size, 1)
   end function

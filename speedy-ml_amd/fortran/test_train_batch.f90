@@ -2,7 +2,7 @@
 ! initializedomain, train_reservoir per region and level, then get_training_data_from_atmo / initialize_slab_ocean_model /
 ! train_slab_ocean_model for the regions with sea -- for the first SML_TEST_REGIONS regions of the rank (default 8) on a short
 ! synthetic training window (1440 h: 6 interleaved passes of 240 columns, 20 batches of 10 per pass; slab: 168 passes of 8-9 columns).
-! train_reservoir only enqueues (speedyml_train): with SML_TRAIN_GROUP=1 every reservoir is trained on its own as the reference does,
+! train_reservoir only enqueues (speedyml_train): with SML_TRAIN_RESIDENTS=1 every reservoir is trained on its own as the reference does,
 ! with the default the whole group shares its recurrence launches and its ridge solves run in lockstep.  The program writes every
 ! trained W_out to SML_TEST_DUMP; tests/test_fortran_host_gpu.py runs it in both modes and requires identical files, and prints the
 ! time per reservoir of both.  Checks here: every W_out is finite and non-zero, and the trained readout of the resident reservoir
@@ -11,7 +11,7 @@ program test_train_batch
   use iso_c_binding
   use mpires, only : mpi_res, startmpi, killmpi
   use mod_reservoir, only : initialize_model_parameters, train_reservoir, finish_training
-  use mod_slab_ocean_reservoir, only : initialize_slab_ocean_model, train_slab_ocean_model, get_training_data_from_atmo
+  use mod_slab_ocean_reservoir, only : initialize_slab_ocean_model, train_slab_ocean_model, get_training_data_from_atmo, finish_slab_training
   use resdomain, only : processor_decomposition, initializedomain
   use mod_utilities, only : main_type, dp, init_random_marker
   use mod_calendar
@@ -68,6 +68,7 @@ program test_train_batch
       print *, 'FAIL: W_out of region', res%reservoir(i,1)%assigned_region, 'is NaN or zero'; nfail = nfail + 1
     end if
     if (res%reservoir_special(i,1)%sst_bool_prediction) then
+      call finish_slab_training(res%reservoir_special(i,1), res%model_parameters, res%grid_special(i,1))
       if (.not. all(res%reservoir_special(i,1)%wout == res%reservoir_special(i,1)%wout) .or. maxval(abs(res%reservoir_special(i,1)%wout)) == 0.0_dp) then
         print *, 'FAIL: slab W_out of region', res%reservoir_special(i,1)%assigned_region, 'is NaN or zero'; nfail = nfail + 1
       end if

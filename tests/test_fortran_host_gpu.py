@@ -96,11 +96,11 @@ def test_fortran_main_loop_two_ranks_equal_one_rank(tmp_path):
 
 def test_fortran_training_in_groups_equals_one_at_a_time(tmp_path):
     """train_reservoir / train_slab_ocean_model of the drop-in through the training branch of program main (src/parallelmain.f90:72-137,
-    fortran/test_train_batch.f90): 8 regions, trained one at a time (SML_TRAIN_GROUP=1, the reference's granularity) and as one group
+    fortran/test_train_batch.f90): 8 regions, trained one at a time (SML_TRAIN_RESIDENTS=1, the reference's granularity) and as one group
     (shared recurrence launches, ridge solves in lockstep) give identical W_out files; the time per reservoir of both is printed."""
     base = dict(SML_RES_M="1200", SML_SLAB_M="400", SML_TEST_REGIONS="8")
-    o1 = _run("test_train_batch", dict(base, SML_TRAIN_GROUP="1", SML_TEST_DUMP=str(tmp_path / "single.bin")))
-    o8 = _run("test_train_batch", dict(base, SML_TRAIN_GROUP="64", SML_TEST_DUMP=str(tmp_path / "group.bin")))
+    o1 = _run("test_train_batch", dict(base, SML_TRAIN_RESIDENTS="1", SML_TEST_DUMP=str(tmp_path / "single.bin")))
+    o8 = _run("test_train_batch", dict(base, SML_TRAIN_RESIDENTS="64", SML_TEST_DUMP=str(tmp_path / "group.bin")))
     assert "training through the module API OK" in o1 and "training through the module API OK" in o8
     a, b = open(tmp_path / "single.bin", "rb").read(), open(tmp_path / "group.bin", "rb").read()
     assert len(a) > 8 * 136 * 600 * 8 and a == b
