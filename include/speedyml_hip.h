@@ -551,7 +551,7 @@ int sml_train_symmetrize(double *c_dev, int n_aug, void *stream);
  * interchanges (SURVEY 2.2 lists it as an allowed form; W_out parity is defined by backward error, H4).  A pivot that is not positive
  * (an indefinite matrix, or one singular to working precision) sends that system through the pivoted LU instead, which is dgesv's
  * algorithm (first maximum per column, row interchange), as mldivide is (src/mod_linalg.f90:109-151); sml_train_select_solver(1) makes
- * the LU the only solver.  Only the LU symmetrises c_dev in place (the Cholesky reads the lower triangle sml_train_accumulate fills).
+ * the LU the only solver.  c_dev is symmetrised in place either way (sml_train_accumulate fills the lower-triangle tiles only).
  * Limits: the LU keeps its panel in registers and takes n_aug <= 7168; the Cholesky has no size limit.  Any n_out (the back substitution
  * runs in groups of 136 right-hand sides).  Both are checked before anything is enqueued.
  * Returns SML_ERR_NUMERIC when a pivot of the LU is exactly zero (dgesv info > 0). */

@@ -980,8 +980,9 @@ constexpr size_t TRM_LDS = sizeof(double) * ((size_t)LU_NBO * TRM_LD + 2 * LU_NB
 template <int MODE>
 __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
                                                   int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
-                                                  long tri_stride, int bx, int by)
+                                                  long tri_stride, int bx, int by, const double *__restrict__ minv = nullptr)
 {
+    const long tri_stride_minv = ls.p;
     double *T = lu_dyn_lds;                                   // T[i * TRM_LD + k] = -L(i,k), k < i / -U(i,k), k > i; zero elsewhere
     double *dg = T + (size_t)LU_NBO * TRM_LD, *rdg = dg + LU_NBO;
     tri += tri_stride * by; w += ls.w * by;
@@ -1014,7 +1015,7 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
             T[i * TRM_LD + k] = i == k ? 0.0 : -v[u];
             if (!UNIT && i == k) {
                 const double d = i < nbp ? v[u] : 1.0;
-                dg[i] = d; rdg[i] = 1.0 / d;
+                dg[i] = d;
             }
         }
     };
@@ -1052,9 +1053,12 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
     }
     if (second) stage_store(threadIdx.x + nthr * SB);
     __syncthreads();
-    // the inverses of the 32 diagonal 4 x 4 triangles, one thread per column of one inverse (substitution on a unit vector)
+    // the inverses of the 32 diagonal 4 x 4 triangles, one thread per column of one inverse (substitution on a unit vector) -- or, for
+    // the Cholesky's split form, the inverses its diagonal-block kernel left behind (minv: the bits the fused panel kernel solves with)
     double *dinv = rdg + LU_NBO;                              // dinv[16 q + 4 i + k]
-    if (threadIdx.x < LU_NBO) {
+    if (MODE == 2 && minv) {
+        for (int e = threadIdx.x; e < 16 * NQ; e += nthr) dinv[e] = minv[(long)tri_stride_minv * by + 4 * K0 + e];
+    } else if (threadIdx.x < LU_NBO) {
         const int q = threadIdx.x >> 2, c = threadIdx.x & 3;
         const double *tq = T + (4 * q) * TRM_LD + 4 * q;      // (negated off-diagonal entries)
         double y[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1084,27 +1088,64 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
     __syncthreads();
     const double *ta = T + (lane & 3) * TRM_LD + (lane >> 4);                // A operand of quad pair (q2, q): ta[4 q2 * TRM_LD + 4 q]
     const double *ti = dinv + 4 * (lane & 3) + (lane >> 4);                  // A operand of quad q's inverse: ti[16 q]
-    // Straight-line code, all 32 quads whatever nbp: rows and coefficients past a short last block are zeros (diagonal 1), and a
-    // uniform branch around each MFMA put every one of them behind its own LDS round trip (53 us per launch).
+    // The 32 quads are walked as 8 groups of 4 in a real loop (LOWER: quad p at position p; UPPER: quad 31 - p): the group being
+    // solved always sits in r[0], the groups behind it rotate forward after every iteration, so every register index is static while
+    // the loop body is 4 quads long.  (Fully unrolled -- 528 MFMAs and as many LDS reads, 45 KB -- the kernel spent ~10 us of every
+    // launch fetching instructions it executes once: it sits in a chain of small kernels, its code is never warm.)  Rows and
+    // coefficients past a short last block are zeros (diagonal 1).  The operands of all later quads are read in ONE batch per solved
+    // quad (a read inside a uniform branch put every MFMA behind its own LDS round trip: 53 us per launch); groups past the end of
+    // the block are clamped to its last group and their MFMAs skipped.
+    double r[8][4];
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) {
-        const int q = LOWER ? s : NQ - 1 - s;
-        const double xa = __builtin_amdgcn_mfma_f64_4x4x4f64(ti[16 * q], a[q], 0.0, 0, 0, 0);
-        if (ok && 4 * q + ri < nbp) w[(long)(K0 + 4 * q + ri) * ld + j] = xa;
+    for (int g = 0; g < 8; ++g)
 #pragma unroll
-        for (int d = 1; d < NQ; ++d) {                        // nearest quad first: the next solve waits for it
-            const int q2 = LOWER ? q + d : q - d;
-            if (q2 >= 0 && q2 < NQ) a[q2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[4 * q2 * TRM_LD + 4 * q], xa, a[q2], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) r[g][t] = a[LOWER ? 4 * g + t : NQ - 1 - (4 * g + t)];
+#pragma unroll 1
+    for (int G = 0; G < 8; ++G) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pq = 4 * G + t, q = LOWER ? pq : NQ - 1 - pq;
+            const double xa = __builtin_amdgcn_mfma_f64_4x4x4f64(ti[16 * q], r[0][t], 0.0, 0, 0, 0);
+            if (ok && 4 * q + ri < nbp) w[(long)(K0 + 4 * q + ri) * ld + j] = xa;
+            double ag[4], av[7][4];
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const int p2 = 4 * G + t2, q2 = LOWER ? p2 : NQ - 1 - p2;
+                if (t2 > t) ag[t2] = ta[4 * q2 * TRM_LD + 4 * q];
+            }
+#pragma unroll
+            for (int g = 1; g < 8; ++g) {
+                const int gg = min(G + g, 7);
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    const int p2 = 4 * gg + t2, q2 = LOWER ? p2 : NQ - 1 - p2;
+                    av[g - 1][t2] = ta[4 * q2 * TRM_LD + 4 * q];
+                }
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2)                    // nearest quad first: the next solve waits for it
+                if (t2 > t) r[0][t2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ag[t2], xa, r[0][t2], 0, 0, 0);
+#pragma unroll
+            for (int g = 1; g < 8; ++g) {
+                if (G + g < 8) {                              // (uniform)
+#pragma unroll
+                    for (int t2 = 0; t2 < 4; ++t2) r[g][t2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[g - 1][t2], xa, r[g][t2], 0, 0, 0);
+                }
+            }
         }
+#pragma unroll
+        for (int g = 0; g < 7; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[g][t] = r[g + 1][t];
     }
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_lu_trsm_mfma(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
                                                        int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
-                                                       long tri_stride)
+                                                       long tri_stride, const double *__restrict__ minv)
 {
-    lu_trsm_mfma_body<MODE>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, src, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y);
+    lu_trsm_mfma_body<MODE>(tri, tri_ld_k, tri_ld_i, w, ld, K0, nbp, c0, ncols, ipiv, src, ls, tri_stride, (int)blockIdx.x, (int)blockIdx.y, minv);
 }
 
 // back substitution update: Y(i, :) -= sum_k U(i, K0 + k) X(K0 + k, :) for the rows i < K0 above a solved block (K = nb <= 128,
@@ -1274,80 +1315,168 @@ __global__ __launch_bounds__(TRL_T) void k_lu_backsub_step(double *__restrict__ 
 // wavefront solves its 16 columns of the row quad with ONE MFMA (M as the A operand) and stores them, (3) the solved row quad goes to
 // LDS and every later quad gets its rank-4 update as ONE MFMA (A operand = -U(quad rows, the later quad's columns)^T, a 16-address LDS
 // read).  Two barriers per quad (the LDS buffers alternate); wavefront w stops at quad 4 w + 3 (rows below its columns are never read).
-constexpr int CH_T = 512;
-__global__ __launch_bounds__(CH_T) void k_chol_potrf(double *__restrict__ w, long ld, int K0, int nb, int *__restrict__ info, LuStride ls)
+// 1 / sqrt(d): v_rsq_f64 and two Newton steps (the instruction alone is good to about 2^-26).  r = d * y is the square root; no
+// division anywhere in the chain (sqrt + 1 / r as the compiler expands them are ~35 dependent instructions per pivot).
+__device__ __forceinline__ double chol_rsqrt(double d)
 {
-    w += ls.w * blockIdx.x; info += blockIdx.x;
+    double y = __builtin_amdgcn_rsq(d);
+    double e = __builtin_fma(-d * y, y, 1.0);
+    y = __builtin_fma(y * 0.5, e, y);
+    e = __builtin_fma(-d * y, y, 1.0);
+    return __builtin_fma(y * 0.5, e, y);
+}
+
+// k_chol_panel: potrf of the diagonal block AND the U12 solve of 64 more columns per workgroup, in one launch.
+// Wavefronts 0-3 hold the diagonal block (every workgroup its own copy: the factorisation is repeated, not communicated -- 50 us of
+// one workgroup's time either way, and the solve that used to be a second launch of 25-45 us now rides on the same 32 steps);
+// wavefront w owns column groups w and 7 - w of it (a triangle cut this way gives every SIMD the same number of MFMAs).
+// Wavefronts 4-7 hold one group of 16 columns to the right of the block each (all 128 rows): per step they take the quad's
+// inverse M and the solved row quad's A operands from LDS, solve their own row quad (one MFMA) and update all later quads.
+// Workgroup 0 stores the factorised diagonal block -- into a side buffer (row K0 + i of u11[.][128]), because the other workgroups read
+// the unfactorised block from W during the same launch; k_chol_diag_to_w puts all of them into W before the back substitution.
+// Two barriers per row quad.
+constexpr int CP_T = 512, CP_COLS = 64;
+__global__ __launch_bounds__(256) void k_chol_diag_to_w(const double *__restrict__ u11, double *__restrict__ w, long ld, int n_aug, LuStride ls)
+{
+    u11 += ls.p * blockIdx.y; w += ls.w * blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(e >> 7), c = (int)(e & (LU_NBO - 1));
+    if (row >= n_aug) return;
+    const int K0 = row & ~(LU_NBO - 1), col = K0 + c;
+    if (col >= row && col < n_aug) w[(long)row * ld + col] = u11[e];
+}
+
+__global__ __launch_bounds__(CP_T) void k_chol_panel(double *__restrict__ w, long ld, int K0, int nb, int ncols, double *__restrict__ u11, int *__restrict__ info,
+                                                     LuStride ls, int direct, double *__restrict__ minv)
+{
+    w += ls.w * blockIdx.y; info += blockIdx.y; u11 += ls.p * blockIdx.y; minv += ls.p * blockIdx.y;
     __shared__ __attribute__((aligned(16))) double dq[2][4][4];
+    __shared__ __attribute__((aligned(16))) double mq[2][64];
     __shared__ __attribute__((aligned(16))) double xrow[2][4][LU_NBO + 4];
-    constexpr int NQ = LU_NBO / 4;
+    constexpr int NQ = LU_NBO / 4, NG = NQ / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ri = lane >> 4, cc = lane & 15, col = 16 * wave + cc;
-    double *const base = w + (long)K0 * ld + K0 + col;
-    double a[NQ];
+    const int ri = lane >> 4, cc = lane & 15;
+    const bool diag = wave < 4;
+    // column groups: diagonal wavefronts g0 = wave, g1 = 7 - wave (columns of the block); the others one group of W's columns
+    const int g0 = diag ? wave : NG, g1 = diag ? NG - 1 - wave : -1;         // "row group gi is needed by group g" <=> gi <= g
+    const int col0 = diag ? 16 * wave + cc : nb + CP_COLS * (int)blockIdx.x + 16 * (wave - 4) + cc;      // relative to K0
+    const int col1 = 16 * (NG - 1 - wave) + cc;
+    const bool ok0 = diag ? col0 < nb : K0 + col0 < ncols, ok1 = diag && col1 < nb;
+    const bool store_diag = blockIdx.x == 0;
+    double a0[NG][4], a1[NG][4];
+    {
+        const double *bp = w + (long)K0 * ld + K0;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int row = 4 * q + ri;
-        // (rows and columns past a short last block: the identity; below the diagonal: never used, kept finite)
-        a[q] = (row < nb && col < nb && row <= col) ? base[(long)row * ld] : (row == col ? 1.0 : 0.0);
+        for (int q = 0; q < NQ; ++q) {
+            const int row = 4 * q + ri;
+            // (rows and columns past a short last block: the identity; below the diagonal: never used, kept finite)
+            a0[q >> 2][q & 3] = (row < nb && ok0 && (!diag || row <= col0)) ? bp[(long)row * ld + col0] : ((diag && row == col0) ? 1.0 : 0.0);
+            a1[q >> 2][q & 3] = (row < nb && ok1 && row <= col1) ? bp[(long)row * ld + col1] : ((diag && row == col1) ? 1.0 : 0.0);
+        }
     }
     int bad = 0;
+    const double *xr0 = &xrow[0][lane >> 4][lane & 3], *xr1 = &xrow[1][lane >> 4][lane & 3];
+#pragma unroll 1
+    for (int G = 0; G < NG; ++G) {
+        const int ow = G < 4 ? G : NG - 1 - G;                                  // the wavefront that owns the diagonal quads of this row group
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int par = q & 1, wq = q >> 2, c0q = 4 * (q & 3);
-        if (wave == wq && cc >= c0q && cc < c0q + 4) dq[par][ri][cc - c0q] = a[q];
-        __syncthreads();
-        // R^T R = D (upper R), then M = R^-T (lower): m(i,k), k <= i
-        const double d00 = dq[par][0][0], d01 = dq[par][0][1], d02 = dq[par][0][2], d03 = dq[par][0][3];
-        const double d11 = dq[par][1][1], d12 = dq[par][1][2], d13 = dq[par][1][3];
-        const double d22 = dq[par][2][2], d23 = dq[par][2][3], d33 = dq[par][3][3];
-        if (!(d00 > 0.0)) bad = bad ? bad : 4 * q + 1;
-        const double r00 = sqrt(d00), i0 = 1.0 / r00;
-        const double r01 = d01 * i0, r02 = d02 * i0, r03 = d03 * i0;
-        const double e11 = d11 - r01 * r01;
-        if (!(e11 > 0.0)) bad = bad ? bad : 4 * q + 2;
-        const double r11 = sqrt(e11), i1 = 1.0 / r11;
-        const double r12 = (d12 - r01 * r02) * i1, r13 = (d13 - r01 * r03) * i1;
-        const double e22 = d22 - r02 * r02 - r12 * r12;
-        if (!(e22 > 0.0)) bad = bad ? bad : 4 * q + 3;
-        const double r22 = sqrt(e22), i2 = 1.0 / r22;
-        const double r23 = (d23 - r02 * r03 - r12 * r13) * i2;
-        const double e33 = d33 - r03 * r03 - r13 * r13 - r23 * r23;
-        if (!(e33 > 0.0)) bad = bad ? bad : 4 * q + 4;
-        const double r33 = sqrt(e33), i3 = 1.0 / r33;
-        // M = (R^T)^-1: column by column of the lower triangle
-        const double m10 = -(r01 * i0) * i1;
-        const double m20 = -(r02 * i0 + r12 * m10) * i2, m21 = -(r12 * i1) * i2;
-        const double m30 = -(r03 * i0 + r13 * m10 + r23 * m20) * i3, m31 = -(r13 * i1 + r23 * m21) * i3, m32 = -(r23 * i2) * i3;
-        // this lane's element of the MFMA's A operand: (i, k) = (lane & 3, lane >> 4)
-        const int mi = lane & 3, mk = lane >> 4;
-        double mv = 0.0;
-        mv = (mi == 0 && mk == 0) ? i0 : mv; mv = (mi == 1 && mk == 1) ? i1 : mv; mv = (mi == 2 && mk == 2) ? i2 : mv; mv = (mi == 3 && mk == 3) ? i3 : mv;
-        mv = (mi == 1 && mk == 0) ? m10 : mv; mv = (mi == 2 && mk == 0) ? m20 : mv; mv = (mi == 2 && mk == 1) ? m21 : mv;
-        mv = (mi == 3 && mk == 0) ? m30 : mv; mv = (mi == 3 && mk == 1) ? m31 : mv; mv = (mi == 3 && mk == 2) ? m32 : mv;
-        const double xa = __builtin_amdgcn_mfma_f64_4x4x4f64(mv, a[q], 0.0, 0, 0, 0);        // U(4 q + i, col)
-        const int row = 4 * q + ri;
-        if (row < nb && col < nb && row <= col) base[(long)row * ld] = xa;
-        xrow[par][ri][col] = xa;
-        __syncthreads();
-        // rank-4 update of the later quads this wavefront still needs (rows <= its last column): groups of four quads = 16 rows
-        const double *xr = &xrow[par][lane >> 4][lane & 3];                                  // A operand (i', k) = -U(4 q + k, 4 q2 + i')
-        double av[NQ];                              // every later quad's operand in ONE batch of reads (a read inside each branch below
-#pragma unroll                                      // would put every group of MFMAs behind its own LDS round trip)
-        for (int q2 = 0; q2 < NQ; ++q2)
-            if (q2 > q) av[q2] = -xr[4 * q2];
+        for (int t = 0; t < 4; ++t) {
+            const int par = t & 1, q = 4 * G + t, c0q = 4 * t;
+            if (wave == ow && cc >= c0q && cc < c0q + 4) dq[par][ri][cc - c0q] = G < 4 ? a0[0][t] : a1[0][t];
+            __syncthreads();
+            double mv;
+            const int row = 4 * q + ri;
+            if (diag) {
+                // R^T R = D (upper R), then M = R^-T (lower): m(i,k), k <= i
+                const double d00 = dq[par][0][0], d01 = dq[par][0][1], d02 = dq[par][0][2], d03 = dq[par][0][3];
+                const double d11 = dq[par][1][1], d12 = dq[par][1][2], d13 = dq[par][1][3];
+                const double d22 = dq[par][2][2], d23 = dq[par][2][3], d33 = dq[par][3][3];
+                const double i0 = chol_rsqrt(d00);
+                const double r01 = d01 * i0, r02 = d02 * i0, r03 = d03 * i0;
+                const double e11 = __builtin_fma(-r01, r01, d11);
+                const double i1 = chol_rsqrt(e11);
+                const double r12 = __builtin_fma(-r01, r02, d12) * i1, r13 = __builtin_fma(-r01, r03, d13) * i1;
+                const double e22 = __builtin_fma(-r12, r12, __builtin_fma(-r02, r02, d22));
+                const double i2 = chol_rsqrt(e22);
+                const double r23 = __builtin_fma(-r12, r13, __builtin_fma(-r02, r03, d23)) * i2;
+                const double e33 = __builtin_fma(-r23, r23, __builtin_fma(-r13, r13, __builtin_fma(-r03, r03, d33)));
+                const double i3 = chol_rsqrt(e33);
+                if (!(d00 > 0.0 && e11 > 0.0 && e22 > 0.0 && e33 > 0.0) && !bad) bad = 4 * q + (!(d00 > 0.0) ? 1 : !(e11 > 0.0) ? 2 : !(e22 > 0.0) ? 3 : 4);
+                // M = (R^T)^-1, the lower triangle column by column
+                const double m10 = -(r01 * i0) * i1;
+                const double m21 = -(r12 * i1) * i2, m20 = -__builtin_fma(r12, m10, r02 * i0) * i2;
+                const double m32 = -(r23 * i2) * i3, m31 = -__builtin_fma(r23, m21, r13 * i1) * i3;
+                const double m30 = -__builtin_fma(r23, m20, __builtin_fma(r13, m10, r03 * i0)) * i3;
+                // this lane's element of the MFMA's A operand: (i, k) = (lane & 3, lane >> 4)
+                const int mi = lane & 3, mk = lane >> 4;
+                const double row0 = mk == 0 ? i0 : 0.0;
+                const double row1 = mk == 0 ? m10 : mk == 1 ? i1 : 0.0;
+                const double row2 = mk == 0 ? m20 : mk == 1 ? m21 : mk == 2 ? i2 : 0.0;
+                const double row3 = mk == 0 ? m30 : mk == 1 ? m31 : mk == 2 ? m32 : i3;
+                mv = mi == 0 ? row0 : mi == 1 ? row1 : mi == 2 ? row2 : row3;
+                if (wave == 0) {
+                    mq[par][lane] = mv;
+                    // (the split form's U12 solve takes the quad inverses from here: the same bits as the fused form's)
+                    if (direct && store_diag && lane < 64 && ((lane >> 2) & 3) == 0) minv[4 * K0 + 16 * q + 4 * mi + mk] = mv;
+                }
+                const double xa0 = __builtin_amdgcn_mfma_f64_4x4x4f64(mv, a0[0][t], 0.0, 0, 0, 0);       // U(4 q + i, col)
+                const double xa1 = __builtin_amdgcn_mfma_f64_4x4x4f64(mv, a1[0][t], 0.0, 0, 0, 0);
+                if (store_diag) {        // (not into W: the other workgroups of this launch may still be loading the block from there --
+                    // unless this launch is the diagonal block alone, `direct`)
+                    double *dst = direct ? w + (long)(K0 + row) * ld + K0 : u11 + (long)(K0 + row) * LU_NBO;
+                    if (row < nb && ok0 && row <= col0) dst[col0] = xa0;
+                    if (row < nb && ok1 && row <= col1) dst[col1] = xa1;
+                }
+                (par ? xrow[1] : xrow[0])[ri][col0] = xa0;
+                (par ? xrow[1] : xrow[0])[ri][col1] = xa1;
+                a0[0][t] = -xa0; a1[0][t] = -xa1;                             // (the solved quad's registers now hold the update's B operand)
+            }
+            __syncthreads();
+            if (!diag) {
+                mv = mq[par][lane];
+                const double xa0 = __builtin_amdgcn_mfma_f64_4x4x4f64(mv, a0[0][t], 0.0, 0, 0, 0);
+                if (row < nb && ok0) w[(long)(K0 + row) * ld + K0 + col0] = xa0;
+                a0[0][t] = -xa0;
+            }
+            // rank-4 update of the later quads a column group still needs: A operand (i', k) = U(4 q + k, 4 q2 + i') from LDS, B operand
+            // -U(quad rows, this group's columns); all operands of the step in one batch of reads, row groups past the end clamped
+            const double *xr = par ? xr1 : xr0;
+            const double nx0 = a0[0][t], nx1 = a1[0][t];
+            double ag[4], av[NG - 1][4];
 #pragma unroll
-        for (int g = 0; g < NQ / 4; ++g) {
-            if (4 * g + 3 > q && g <= wave) {                                                // (uniform)
+            for (int t2 = 0; t2 < 4; ++t2)
+                if (t2 > t) ag[t2] = xr[4 * (4 * G + t2)];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int q2 = 4 * g + t;
-                    if (q2 > q) a[q2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q2], xa, a[q2], 0, 0, 0);
+            for (int g = 1; g < NG; ++g) {
+                const int gg = min(G + g, NG - 1);
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) av[g - 1][t2] = xr[4 * (4 * gg + t2)];
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                if (t2 > t) {
+                    if (G <= g0) a0[0][t2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ag[t2], nx0, a0[0][t2], 0, 0, 0);
+                    if (G <= g1) a1[0][t2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ag[t2], nx1, a1[0][t2], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                if (G + g < NG && (G + g <= g0 || G + g <= g1)) {                 // (uniform)
+                    const bool u0 = G + g <= g0, u1 = G + g <= g1;
+#pragma unroll
+                    for (int t2 = 0; t2 < 4; ++t2) {
+                        if (u0) a0[g][t2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[g - 1][t2], nx0, a0[g][t2], 0, 0, 0);
+                        if (u1) a1[g][t2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[g - 1][t2], nx1, a1[g][t2], 0, 0, 0);
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int g = 0; g < NG - 1; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { a0[g][t] = a0[g + 1][t]; a1[g][t] = a1[g + 1][t]; }
     }
-    if (bad && threadIdx.x == 0 && *info == 0) *info = K0 + bad;
+    if (bad && store_diag && threadIdx.x == 0 && *info == 0) *info = K0 + bad;
 }
 
 template <bool A_KC, bool B_KC>
@@ -1683,7 +1812,7 @@ static void lu_sys_free(LuSys &s)
 static inline long lu_pad16(long v) { return (v + 15) & ~15L; }
 static inline bool lu_dma() { static const bool v = !(getenv("SML_LU_DMA") && atoi(getenv("SML_LU_DMA")) == 0); return v; }
 
-static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
+static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch, bool chol = false)
 {
     const long ld = lu_pad16(ncols), np = lu_pad16(n_aug);
     s.nbatch = nbatch;
@@ -1706,8 +1835,12 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch)
         // A single solve: the panel stream is confined to the reserved CUs and does only what fits there (leaves, panel updates and
         // the NEXT panel's 128 columns); what it writes it reads back from the same L2s instead of through a memory system the
         // trailing update keeps busy.  Batches keep the unconfined panel stream: their strip work is nbatch times larger.
-        s.confined = confine_env == 2 || (confine_env && nbatch == 1);
-        const int reserve = reserve_env >= 0 ? reserve_env : s.confined ? 64 : std::max(16, 2 * nbatch);   // (confined: 32 / 48 / 64 / 96 CUs -> 27.2 / 27.5 / 26.9 / 26.9 ms)
+        // (the Cholesky's single solve: no CU masks at all -- 7.1 ms against 7.7 with the LU's confined layout, whose 64-96 reserved CUs
+        //  its 93-workgroup panel kernel over- or under-fills)
+        s.confined = confine_env == 2 || (confine_env && nbatch == 1 && !chol);
+        // (LU, confined: 32 / 48 / 64 / 96 CUs -> 27.2 / 27.5 / 26.9 / 26.9 ms.  The Cholesky's panel kernel is 93 one-per-CU workgroups at
+        //  the first panel: 96 reserved CUs hold them in one round; with 64 it ran in two: 133 instead of ~70 us)
+        const int reserve = reserve_env >= 0 ? reserve_env : s.confined ? 64 : (chol && nbatch == 1) ? 0 : std::max(16, 2 * nbatch);
         int dev = 0, ncu = 0;
         SML_HIP(hipGetDevice(&dev));
         SML_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1811,7 +1944,7 @@ static int backsub_enqueue(LuSys &S, int nb, int n_aug, int n_out, long ld)
         // U(i,k) = W[(K0 + i) * ld + K0 + k]; the right-hand sides are columns rhs0 .. rhs0 + nr of W
         auto solve_block = [&](int K0) {
             hipLaunchKernelGGL(k_lu_trsm_mfma<0>, dim3((nr + 63) / 64, nb), dim3(256), TRM_LDS, S.sg, S.w + (long)K0 * ld + K0, 1L, ld, S.w, ld, K0,
-                               std::min(LU_NBO, n_aug - K0), rhs0, rhs0 + nr, (const int *)nullptr, (const int *)nullptr, ls, ls.w);
+                               std::min(LU_NBO, n_aug - K0), rhs0, rhs0 + nr, (const int *)nullptr, (const int *)nullptr, ls, ls.w, (const double *)nullptr);
         };
         // per step: the 128 rows of the next block get the update first (they are what the chain waits for), then ONE launch solves that
         // block and updates the rows above it (one workgroup per CU: at most as many far-update workgroups as S.sg has CUs left)
@@ -1893,7 +2026,7 @@ static int fit_enqueue(double *const *c, const double *const *b, int first, int 
         auto gather_and_u12 = [&](int j0, int j1, hipStream_t st) {
             if (j1 <= j0) return;
             hipLaunchKernelGGL(k_lu_trsm_mfma<1>, dim3((j1 - j0 + 63) / 64, nb), dim3(256), TRM_LDS, st, Pk + K0, np, 1L, S.w, ld, K0, nbp, j0, j1, S.ipiv,
-                               S.src, ls, ls.p);
+                               S.src, ls, ls.p, (const double *)nullptr);
         };
         if (S.confined) {                                                    // S.sg needs the permutation; it is long done with panel k-1
             SML_HIP(hipEventRecord(S.ev_panel, S.sp));
@@ -1960,34 +2093,65 @@ static int chol_enqueue(double *const *c, const double *const *b, int first, int
     SML_HIP(hipGetLastError());
     SML_HIP(hipEventRecord(S.ev_strip, S.sg));
     SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));
-    // Streams.  S.sp carries what the next diagonal block waits for: potrf(k), the U12 solve, block row k+1's update.  S.sg (CU-masked)
-    // carries the rest of panel k's trailing update, block row k+2 first: S.sp waits for THAT part only (ev_strip) before it touches
-    // block row k+2 itself one panel later; the rows below were last written by S.sg, in order.
-    for (int K0 = 0, k = 0; K0 < n_aug; K0 += LU_NBO, ++k) {
+    // Streams and grouping.  S.sp carries what the next diagonal block waits for: the panel kernel (potrf + U12) and the update of
+    // the NEXT block row by every panel of the current group (K = 128, 256, ...).  The rest of the trailing matrix is updated once
+    // per GROUP of `grp` panels, at K = 128 grp, on S.sg: a 128-deep update reads and writes all of C for 128 columns' worth of
+    // flops (half of either roof), two panels per pass halve that traffic.  The group's update starts with the `grp` block rows the
+    // next group's S.sp updates touch; S.sp waits for that part only (ev_strip), the rows below were last written by S.sg, in order.
+    static const int grp = getenv("SML_CHOL_GROUP") ? std::max(1, atoi(getenv("SML_CHOL_GROUP"))) : 1;     // (measured: single 7.05 / 7.33 / 7.69 / 7.94 ms at 1 / 2 / 3 / 4, 16 in lockstep 3.16 / 3.20 ms per system at 1 / 2)
+    // One system: the fused panel kernel (every workgroup repeats the diagonal block's factorisation: one launch less in the chain).
+    // A batch: the diagonal blocks alone (one workgroup per system) and the MFMA solve as a second launch -- 93 x nb workgroups that
+    // each occupy a CU for the whole factorisation would take the chip from the trailing updates the batch is there to fill it with
+    // (16 in lockstep: 3.5 against 3.16 ms per system).
+    static const int fused_env = getenv("SML_CHOL_FUSED") ? atoi(getenv("SML_CHOL_FUSED")) : -1;
+    const bool fused = fused_env >= 0 ? fused_env != 0 : nb == 1;
+    int g_K0 = 0, gi = 0, ngroups = 0;
+    for (int K0 = 0; K0 < n_aug; K0 += LU_NBO) {
         const int nbp = std::min(LU_NBO, n_aug - K0), c0 = K0 + nbp;
-        hipLaunchKernelGGL(k_chol_potrf, dim3(nb), dim3(CH_T), 0, S.sp, S.w, ld, K0, nbp, S.info, ls);
-        hipLaunchKernelGGL(k_lu_trsm_mfma<2>, dim3((ncols - c0 + 63) / 64, nb), dim3(256), TRM_LDS, S.sp, S.w + (long)K0 * ld + K0, ld, 1L, S.w, ld, K0, nbp, c0, ncols,
-                           (const int *)nullptr, (const int *)nullptr, ls, ls.w);
+        if (fused)
+            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (ncols - c0 + CP_COLS - 1) / CP_COLS), nb), dim3(CP_T), 0, S.sp, S.w, ld, K0, nbp, ncols, S.p[0], S.info, ls, 0, S.p[1]);
+        else {
+            // (a launch of the diagonal block alone: ncols = c0 leaves the other wavefronts without columns)
+            hipLaunchKernelGGL(k_chol_panel, dim3(1, nb), dim3(CP_T), 0, S.sp, S.w, ld, K0, nbp, c0, S.p[0], S.info, ls, 1, S.p[1]);
+            hipLaunchKernelGGL(k_lu_trsm_mfma<2>, dim3((ncols - c0 + 63) / 64, nb), dim3(256), TRM_LDS, S.sp, S.w + (long)K0 * ld + K0, ld, 1L, S.w, ld, K0, nbp, c0, ncols,
+                               (const int *)nullptr, (const int *)nullptr, ls, ls.w, (const double *)S.p[1]);
+        }
         SML_HIP(hipGetLastError());
         if (c0 >= n_aug) break;
-        SML_HIP(hipEventRecord(S.ev_panel, S.sp));
-        SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
-        if (k > 0) SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));          // S.sg is done with block row k+1 (panel k-1's first part)
+        const int kacc = c0 - g_K0;                                            // rows of U the group has produced so far
+        if (gi == 0 && ngroups > 0) SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));   // S.sg is done with the block rows this group's S.sp updates
         const int nb1 = std::min(LU_NBO, n_aug - c0);
-        if ((rc = chol_update(S, nb, ld, ncols, K0, nbp, c0, nb1, S.sp, true))) return rc;
         const int r1 = c0 + nb1;
-        if (r1 < n_aug) {
-            const int nb2 = std::min(LU_NBO, n_aug - r1);
-            if ((rc = chol_update(S, nb, ld, ncols, K0, nbp, r1, nb2, S.sg, true))) return rc;
-            SML_HIP(hipEventRecord(S.ev_strip, S.sg));
-            const int r2 = r1 + nb2;
-            if (r2 < n_aug && (rc = chol_update(S, nb, ld, ncols, K0, nbp, r2, n_aug - r2, S.sg, false))) return rc;
+        const bool close = gi == grp - 1 || r1 >= n_aug;
+        if (close) {                                                           // (recorded before the strip: S.sg needs the panels only)
+            SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+            SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
         }
+        if ((rc = chol_update(S, nb, ld, ncols, g_K0, kacc, c0, nb1, S.sp, true))) return rc;
+        if (close) {
+            if (r1 < n_aug) {
+                const int na = std::min(grp * LU_NBO, n_aug - r1);
+                if ((rc = chol_update(S, nb, ld, ncols, g_K0, kacc, r1, na, S.sg, na <= LU_NBO))) return rc;
+                SML_HIP(hipEventRecord(S.ev_strip, S.sg));
+                const int r2 = r1 + na;
+                if (r2 < n_aug && (rc = chol_update(S, nb, ld, ncols, g_K0, kacc, r2, n_aug - r2, S.sg, false))) return rc;
+            }
+            g_K0 = c0; gi = 0; ++ngroups;
+        } else
+            ++gi;
     }
+    // the factorised diagonal blocks go into W (they were kept aside while their launch's other workgroups read the originals)
+    SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+    SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+    if (fused) hipLaunchKernelGGL(k_chol_diag_to_w, dim3((unsigned)(((long)n_aug * LU_NBO + 255) / 256), nb), dim3(256), 0, S.sg, S.p[0], S.w, ld, n_aug, ls);
     if ((rc = backsub_enqueue(S, nb, n_aug, n_out, ld))) return rc;
     const long tw = (long)n_aug * n_out;
     hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256), nb), dim3(256), 0, S.sg, S.w, ld, S.wout_list, n_aug, n_out, ls);
     SML_HIP(hipGetLastError());
+    // the caller's C leaves as the full symmetric matrix the reference's states_x_states_aug is (the factorisation read its lower
+    // triangle only): mirrored last, off the chain
+    for (int i = 0; i < nb; ++i)
+        if ((rc = sml_train_symmetrize(c[first + i], n_aug, (void *)S.sg))) return rc;
     return SML_OK;
 }
 
@@ -2000,7 +2164,7 @@ static int chol_enqueue(double *const *c, const double *const *b, int first, int
 // layouts differ (lu_sys_alloc) -- each tied to the device it was made on.  sml_train_release_workspace frees them.
 constexpr int FIT_BATCH = 16;            // (8 / 16 / 32 systems in lockstep: 7.3 / 6.3 / 6.5 ms per 5892-row system, profiles/micro/fit_batch_sizes.py)
 struct FitWorkspace { LuSys sys; int n_aug = 0, ncols = 0, dev = -1; };
-static FitWorkspace g_ws[2];             // [0] single solves, [1] batches
+static FitWorkspace g_ws[4];             // [0] single solves, [1] batches of the LU; [2], [3] the same for the Cholesky (other stream layouts)
 static int g_solver = -1;                // 0 auto (Cholesky, LU where it breaks down), 1 LU, 2 Cholesky only; -1: not read from the environment yet
 
 int sml_train_release_workspace(void)
@@ -2034,11 +2198,11 @@ static int fit_run(bool chol, int count, double *const *c, const double *const *
     const int nbmax = std::min(count, fit_batch);
     int rc = SML_OK, dev = 0;
     SML_HIP(hipGetDevice(&dev));
-    FitWorkspace &ws = g_ws[nbmax == 1 ? 0 : 1];
+    FitWorkspace &ws = g_ws[(chol ? 2 : 0) + (nbmax == 1 ? 0 : 1)];
     if (ws.n_aug != n_aug || ws.ncols != ncols || ws.sys.nbatch < nbmax || ws.dev != dev) {
         lu_sys_free(ws.sys);
         ws.n_aug = ws.ncols = 0; ws.dev = -1;
-        if ((rc = lu_sys_alloc(ws.sys, n_aug, ncols, nbmax))) { lu_sys_free(ws.sys); return rc; }
+        if ((rc = lu_sys_alloc(ws.sys, n_aug, ncols, nbmax, chol))) { lu_sys_free(ws.sys); return rc; }
         ws.n_aug = n_aug; ws.ncols = ncols; ws.dev = dev;
     }
     LuSys &S = ws.sys;

@@ -338,3 +338,65 @@ def test_full_size_ridge_fit_of_a_driven_reservoir():
     print(f"backward error {eta:.3e} (LAPACK on the host: {eta_ref:.3e}), prediction difference {pred:.3e}")
     assert pred <= 1e-9, pred
     assert np.max(np.abs(dw)) <= 1e-5 * np.max(np.abs(want)), np.max(np.abs(dw)) / np.max(np.abs(want))
+
+
+def _select_solver(which):
+    from speedy_ml_amd import _lib
+    return _lib.lib().sml_train_select_solver(which)
+
+
+@pytest.mark.parametrize("n,n_model,n_out,nsys", [(5760, 132, 136, 1), (1000, 12, 200, 3), (130, 2, 5, 2)])
+def test_cholesky_is_the_solver_of_spd_ridge_systems(n, n_model, n_out, nsys):
+    """The blocked Cholesky (solver 2: no LU behind it, so a failure cannot hide) against the pivoted LU (solver 1 = dgesv's
+    algorithm) on ridge systems of a driven-reservoir-like Gram matrix: the full 5892 x 5892 system, one with more right-hand sides
+    than one back-substitution group holds (200 > 136), one barely larger than a 128-row block; single and batched.  Both solve
+    the same regularised system: compared by normwise backward error and by what the two W_out predict."""
+    rng = np.random.default_rng(n + n_out)
+    n_aug, m = n + n_model, min(2 * n, 1500)
+    prev = _select_solver(-1)
+    try:
+        cs, bs = [], []
+        for _ in range(nsys):
+            states = np.tanh(rng.standard_normal((n, m)) * (0.995 ** np.arange(n))[:, None] * 2.0)
+            model, y = rng.standard_normal((n_model, m)), rng.standard_normal((n_out, m))
+            c, b = train.fortran_zeros(n_aug, n_aug), train.fortran_zeros(n_out, n_aug)
+            train.chunking_matmul(to_dev(states), to_dev(model), to_dev(y), c, b)
+            cs.append(c); bs.append(b)
+        _select_solver(2)
+        wc = [to_host(w) for w in train.fit_chunk_hybrid_batched(cs, bs, n, n_model, n_out)] if nsys > 1 else \
+             [to_host(train.fit_chunk_hybrid(cs[0], bs[0], n, n_model, n_out))]
+        _select_solver(1)
+        wl = [to_host(w) for w in train.fit_chunk_hybrid_batched(cs, bs, n, n_model, n_out)] if nsys > 1 else \
+             [to_host(train.fit_chunk_hybrid(cs[0], bs[0], n, n_model, n_out))]
+        for c, b, w1, w2 in zip(cs, bs, wc, wl):
+            ch, bh = to_host(c), to_host(b)
+            a = ch + np.diag(np.r_[np.full(n_model, 1.0), np.full(n, 1e-6)])
+            eta = lambda w: np.linalg.norm(w @ a - bh) / (np.linalg.norm(a) * np.linalg.norm(w) + np.linalg.norm(bh))
+            assert np.isfinite(w1).all()
+            assert eta(w1) <= 1e-15 + 4.0 * eta(w2), (eta(w1), eta(w2))
+            dw = w1 - w2
+            assert np.sqrt(max(np.trace(dw @ ch @ dw.T), 0.0) / np.trace(w2 @ ch @ w2.T)) <= 1e-9
+    finally:
+        _select_solver(prev)
+
+
+def test_cholesky_only_rejects_an_indefinite_system_and_auto_falls_back():
+    from speedy_ml_amd._lib import SmlError
+    rng = np.random.default_rng(5)
+    n, n_model, n_out = 300, 4, 6
+    n_aug = n + n_model
+    s = rng.standard_normal((n_aug, n_aug))
+    sym = s + s.T                                       # symmetric, indefinite
+    c, b = to_dev(sym), to_dev(rng.standard_normal((n_out, n_aug)))
+    prev = _select_solver(-1)
+    try:
+        _select_solver(2)
+        with pytest.raises(SmlError, match="not positive definite"):
+            train.fit_chunk_hybrid(c.clone(), b, n, n_model, n_out, 1e-3, 1.0, 0.0, True)
+        _select_solver(0)                               # auto: the pivoted LU takes over
+        w = to_host(train.fit_chunk_hybrid(c.clone(), b, n, n_model, n_out, 1e-3, 1.0, 0.0, True))
+        a = sym + np.diag(np.r_[np.full(n_model, 1.0), np.full(n, 1e-6)])
+        want = np.linalg.solve(a.T, to_host(b).T).T
+        assert np.max(np.abs(w - want)) <= 1e-8 * np.max(np.abs(want))
+    finally:
+        _select_solver(prev)
