@@ -508,7 +508,16 @@ int sml_phys_diag(sml_phys *phys, int which, double *out_host);
  * =================================================================================================== */
 /* makesparse: k COO entries, rows and cols each a concatenation of random permutations of 1..n, vals ~ U(0,1) */
 int sml_makesparse(int n, int k, uint64_t seed, int32_t *rows, int32_t *cols, double *vals);
-/* largest-magnitude eigenvalue of the (non-negative) COO matrix by power iteration (ARPACK 'LM' replacement) */
+/* the same construction on uniform deviates in [0,1) the caller supplies, consumed in the reference's order: RANDOM_NUMBER(vals)
+ * first (k of them), then one per iteration of every shuffle call (rows before cols inside each block of n) --
+ * sml_makesparse_draws(n, k) of them in all.  A host with the reference's own RANDOM_NUMBER stream gets its own matrices. */
+long sml_makesparse_draws(int n, int k);
+int sml_makesparse_from_draws(int n, int k, const double *draws, long ndraws, int32_t *rows, int32_t *cols, double *vals);
+/* largest-magnitude eigenvalue of the (non-negative) COO matrix by power iteration: what sparse_eigen asks ARPACK-NG for
+ * (dnaupd / dneupd, 'LM', src/mod_linalg.f90:351,405; the library is not in the image).  Quirk Q4 -- the reference's
+ * eigs = maxval(d) also scans the imaginary-part and residual columns of a partly uninitialised d(30,3), :246,511 -- reads
+ * undefined memory and is not reproduced: the Perron root is what that code intends, and what tests/test_genres.py checks against
+ * scipy's ARPACK to 1e-8. */
 int sml_spectral_radius(int n, int k, const int32_t *rows, const int32_t *cols, const double *vals, double tol, int maxit,
                         double *lambda, int *iterations);
 /* gen_res: makesparse, then vals <- vals / lambda_max * radius */

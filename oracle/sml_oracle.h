@@ -190,4 +190,7 @@ void do_step_dry(const do_tables *d, const so_tables *s, int j1, int j2, double 
 #ifdef __cplusplus
 }
 #endif
+/* genres_oracle.c: makesparse + shuffle (src/mod_linalg.f90:180-218, src/mod_utilities.f90:1569-1596) on supplied uniform deviates */
+int go_makesparse(int n, int k, const double *draws, int32_t *rows, int32_t *cols, double *vals);
+
 #endif

@@ -70,7 +70,7 @@ EXPORTS = [
     "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_attach_physics", "sml_dyn_set_lradsw", "sml_dyn_set_range_guard", "sml_dyn_physics_diag", "sml_dyn_select_physics_form", "sml_dyn_select_window_form",
     "sml_phys_create", "sml_phys_destroy", "sml_phys_set_surface", "sml_phys_set_sst_dev", "sml_phys_bind_sst_dev", "sml_phys_sol_oz", "sml_phys_get_tables",
     "sml_phys_tendencies", "sml_phys_tendencies_sfcwind", "sml_phys_diag",
-    "sml_makesparse", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",
+    "sml_makesparse", "sml_makesparse_draws", "sml_makesparse_from_draws", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",
     "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit", "sml_train_fit_batched", "sml_train_select_solver", "sml_train_release_workspace",
 ]
 

@@ -25,14 +25,22 @@ struct SplitMix64 {
     double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }   // [0,1)
 };
 
+// the source of uniform deviates: the library's own stream, or an array the caller supplies (sml_makesparse_from_draws)
+struct Draws {
+    SplitMix64 *rng;
+    const double *given;
+    long used;
+    double next() { ++used; return given ? given[used - 1] : rng->uniform(); }
+};
+
 // K-shuffle "random choice without repeat" exactly as shuffle(n, returnsize, out): 1-based values
-void kshuffle(SplitMix64 &rng, int n, int returnsize, int32_t *out, std::vector<int> &choices)
+void kshuffle(Draws &rng, int n, int returnsize, int32_t *out, std::vector<int> &choices)
 {
     choices.resize(n);
     for (int i = 0; i < n; ++i) choices[i] = i + 1;
     int n_chosen = 0;
     for (int i = 0; i < n; ++i) {
-        const int pick = (int)(rng.uniform() * (n - n_chosen));        // `this` - 1
+        const int pick = (int)(rng.next() * (n - n_chosen));           // `this` - 1
         const int tmp = choices[pick];
         if (i < returnsize) out[i] = tmp;
         choices[pick] = choices[n - n_chosen - 1];
@@ -45,11 +53,15 @@ void kshuffle(SplitMix64 &rng, int n, int returnsize, int32_t *out, std::vector<
 
 extern "C" {
 
-int sml_makesparse(int n, int k, uint64_t seed, int32_t *rows, int32_t *cols, double *vals)
+static long makesparse_draw_count(int n, int k)
 {
-    SML_REQUIRE(n > 0 && k >= 0 && rows && cols && vals, "sml_makesparse: bad arguments");
-    SplitMix64 rng{seed};
-    for (int e = 0; e < k; ++e) vals[e] = rng.uniform();
+    const long calls = k > n ? 2L * (k / n) + (k % n ? 2 : 0) : 2;
+    return (long)k + calls * n;
+}
+
+static int makesparse_impl(int n, int k, Draws &rng, int32_t *rows, int32_t *cols, double *vals)
+{
+    for (int e = 0; e < k; ++e) vals[e] = rng.next();
     std::vector<int> scratch;
     if (k > n) {
         const int counter = k / n, leftover = k % n;
@@ -66,6 +78,27 @@ int sml_makesparse(int n, int k, uint64_t seed, int32_t *rows, int32_t *cols, do
         kshuffle(rng, n, k, cols, scratch);
     }
     return SML_OK;
+}
+
+int sml_makesparse(int n, int k, uint64_t seed, int32_t *rows, int32_t *cols, double *vals)
+{
+    SML_REQUIRE(n > 0 && k >= 0 && rows && cols && vals, "sml_makesparse: bad arguments");
+    SplitMix64 sm{seed};
+    Draws rng{&sm, nullptr, 0};
+    return makesparse_impl(n, k, rng, rows, cols, vals);
+}
+
+/* makesparse on uniform deviates the caller supplies, consumed in the reference's order (RANDOM_NUMBER(vals), then one per
+ * iteration of every shuffle call): a host that owns a Fortran RANDOM_NUMBER stream reproduces its own matrices, and the index
+ * construction can be compared bit for bit.  ndraws must be at least sml_makesparse_draws(n, k). */
+long sml_makesparse_draws(int n, int k) { return (n > 0 && k >= 0) ? makesparse_draw_count(n, k) : -1; }
+
+int sml_makesparse_from_draws(int n, int k, const double *draws, long ndraws, int32_t *rows, int32_t *cols, double *vals)
+{
+    SML_REQUIRE(n > 0 && k >= 0 && draws && rows && cols && vals, "sml_makesparse_from_draws: bad arguments");
+    SML_REQUIRE(ndraws >= makesparse_draw_count(n, k), "sml_makesparse_from_draws: %ld deviates supplied, %ld needed", ndraws, makesparse_draw_count(n, k));
+    Draws rng{nullptr, draws, 0};
+    return makesparse_impl(n, k, rng, rows, cols, vals);
 }
 
 int sml_spectral_radius(int n, int k, const int32_t *rows, const int32_t *cols, const double *vals, double tol, int maxit,

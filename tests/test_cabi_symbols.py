@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "speedyml_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|double|char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|long|void|double|char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 
