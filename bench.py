@@ -219,28 +219,44 @@ def training_block(with_cpu):
         executed = 2.0 * 128 * 128 * m * tiles + 2.0 * m * n_aug * (n_model + n_out)
         out[f"gram_m{m}"] = {"ms": dt * 1e3, "tflops": executed / dt / 1e12, "frac": executed / dt / 1e12 / PEAK,
                              "tflops_full_dgemm_convention": (2.0 * n_aug * n_aug * m + 2.0 * n_out * n_aug * m) / dt / 1e12}
-    # the ridge solve on the Gram matrix just accumulated (6 batches of 2920 columns) + the reference's regularisation
+    # the ridge solve on the Gram matrix just accumulated (6 batches of 2920 columns) + the reference's regularisation.
+    # Algorithmic flops: SURVEY 8d's K9 count, what the reference's dgesv does: (2/3) n_aug^3 + 2 n_aug^2 n_out = 146 GFLOP.  The
+    # default solver is a blocked Cholesky of the symmetric positive definite system (pivoted LU where a pivot is not positive):
+    # it EXECUTES (1/3) n_aug^3 + 2 n_aug^2 n_out = 77.6 GFLOP; both rates are reported, `frac` is the algorithmic one.
+    from speedy_ml_amd import _lib
+    L = _lib.lib()
     flops_lu = (2.0 / 3.0) * n_aug ** 3 + 2.0 * n_aug ** 2 * n_out
-    train.fit_chunk_hybrid(c, b, n, n_model, n_out)                                   # allocates the workspace
-    dt1 = timed(lambda: train.fit_chunk_hybrid(c, b, n, n_model, n_out), 3)
-    w = train.fit_chunk_hybrid(c, b, n, n_model, n_out)
+    flops_chol = (1.0 / 3.0) * n_aug ** 3 + 2.0 * n_aug ** 2 * n_out
     reg = torch.diag(torch.cat([torch.full((n_model,), 1.0), torch.full((n,), 1e-6)])).to(dev, torch.float64)
-    resid = (c + reg) @ w - b                                                          # column-major buffers: torch [n_aug, n_out] = Z; C symmetric
-    berr = float(resid.norm() / (torch.linalg.matrix_norm(c + reg) * w.norm() + b.norm()))
-    del reg, resid
-    cs = [c.clone() for _ in range(8)]
-    train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out)                     # grows the workspace to 8 systems
-    dt8 = timed(lambda: train.fit_chunk_hybrid_batched(cs, [b] * 8, n, n_model, n_out), 2)
-    cs16 = cs + [c.clone() for _ in range(8)]
-    train.fit_chunk_hybrid_batched(cs16, [b] * 16, n, n_model, n_out)
-    dt16 = timed(lambda: train.fit_chunk_hybrid_batched(cs16, [b] * 16, n, n_model, n_out), 2)
-    out["ridge_solve_5892"] = {"ms": dt1 * 1e3, "tflops": flops_lu / dt1 / 1e12, "frac": flops_lu / dt1 / 1e12 / PEAK,
-                               "normwise_backward_error": berr,
-                               "batched8": {"ms_per_system": dt8 * 1e3 / 8, "tflops": 8 * flops_lu / dt8 / 1e12,
-                                            "frac": 8 * flops_lu / dt8 / 1e12 / PEAK},
-                               "batched16": {"ms_per_system": dt16 * 1e3 / 16, "tflops": 16 * flops_lu / dt16 / 1e12,
-                                             "frac": 16 * flops_lu / dt16 / 1e12 / PEAK}}
-    del cs, cs16
+
+    def solve_block(executed):
+        train.fit_chunk_hybrid(c, b, n, n_model, n_out)                                   # allocates the workspace
+        dt1 = timed(lambda: train.fit_chunk_hybrid(c, b, n, n_model, n_out), 3)
+        w = train.fit_chunk_hybrid(c, b, n, n_model, n_out)
+        resid = (c + reg) @ w - b                                                      # column-major buffers: torch [n_aug, n_out] = Z; C symmetric
+        berr = float(resid.norm() / (torch.linalg.matrix_norm(c + reg) * w.norm() + b.norm()))
+        out = {"ms": dt1 * 1e3, "tflops": flops_lu / dt1 / 1e12, "frac": flops_lu / dt1 / 1e12 / PEAK,
+               "tflops_executed": executed / dt1 / 1e12, "frac_executed": executed / dt1 / 1e12 / PEAK, "normwise_backward_error": berr}
+        for nsys in (8, 16):
+            cs = [c.clone() for _ in range(nsys)]
+            train.fit_chunk_hybrid_batched(cs, [b] * nsys, n, n_model, n_out)           # grows the workspace
+            dtn = timed(lambda: train.fit_chunk_hybrid_batched(cs, [b] * nsys, n, n_model, n_out), 2)
+            out[f"batched{nsys}"] = {"ms_per_system": dtn * 1e3 / nsys, "tflops": nsys * flops_lu / dtn / 1e12, "frac": nsys * flops_lu / dtn / 1e12 / PEAK,
+                                     "tflops_executed": nsys * executed / dtn / 1e12, "frac_executed": nsys * executed / dtn / 1e12 / PEAK}
+            del cs
+        return out, out["batched16"]["ms_per_system"] * 16e-3
+
+    prev = L.sml_train_select_solver(0)
+    out["ridge_solve_5892"], dt16 = solve_block(flops_chol)
+    out["ridge_solve_5892"]["solver"] = "blocked Cholesky (k_chol_panel + lower-trapezoid MFMA updates); pivoted LU on a non-positive pivot"
+    out["ridge_solve_5892"]["algorithmic_gflop"] = flops_lu / 1e9
+    out["ridge_solve_5892"]["executed_gflop"] = flops_chol / 1e9
+    L.sml_train_select_solver(1)                                                       # dgesv's algorithm alone, for comparison
+    train.release_workspace()
+    out["ridge_solve_5892_pivoted_lu"], _ = solve_block(flops_lu)
+    L.sml_train_select_solver(prev)
+    train.release_workspace()
+    del reg
     # the training pass (reservoir_layer_chunking_hybrid, :1067-1175) of resident full-size reservoirs: one pass of the shipped
     # configuration = 20 batches of 98 columns (traininglength 12000 h / 6 passes / timestep 6)
     # 32 resident reservoirs: the recurrence's one launch per time column is a fixed cost shared by the residents (per reservoir and
@@ -264,7 +280,7 @@ def training_block(with_cpu):
     per_res = shipped_batches * per_batch + dt16 / 16
     out["train_pass"] = {"ms_per_reservoir_batch": per_batch * 1e3, "resident_reservoirs": nres, "batch_size": batch,
                          "reservoirs_per_s_shipped_config": 1.0 / per_res,
-                         "note": "shipped config: 120 batches of m = 98 per reservoir (12000 h, 6 interleaved passes) + one ridge solve (16 systems in lockstep)"}
+                         "note": "shipped config: 120 batches of m = 98 per reservoir (12000 h, 6 interleaved passes) + one ridge solve (16 systems in lockstep, Cholesky)"}
     bank.close()
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -285,8 +301,28 @@ def training_block(with_cpu):
         t0 = time.perf_counter()
         o.fit_chunk_hybrid(ns, n_model, n_out, 1e-3, 1.0, 0.0, True, cc, bb)
         t_fit = (time.perf_counter() - t0) * (n_aug / na) ** 3
+        # ... and the library the reference itself calls for the solve: LAPACK dgesv (numpy.linalg.solve -> the BLAS numpy ships with),
+        # full size, all the threads that BLAS takes: the oracle's unblocked C loop above is several times slower than any LAPACK
+        t_lapack, lapack_threads = None, None
+        try:
+            aa = rng.standard_normal((n_aug, 2048))
+            cc_full = aa @ aa.T + np.diag(np.r_[np.full(n_model, 1.0), np.full(n, 1e-6)])
+            bb_full = rng.standard_normal((n_aug, n_out))
+            t0 = time.perf_counter()
+            np.linalg.solve(cc_full, bb_full)
+            t_lapack = time.perf_counter() - t0
+            try:
+                from threadpoolctl import threadpool_info
+                lapack_threads = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+            except Exception:
+                lapack_threads = None
+            del aa, cc_full, bb_full
+        except Exception:
+            pass
         out["cpu_baseline"] = {"kind": "port", "cores": 1, "gram_m98_s": t_gram, "ridge_solve_5892_s": t_fit,
+                               "ridge_solve_5892_lapack_dgesv_s": t_lapack, "lapack_threads": lapack_threads,
                                "reservoirs_per_s_shipped_config": 1.0 / (shipped_batches * t_gram + t_fit),
+                               "reservoirs_per_s_shipped_config_with_lapack_solve": (1.0 / (shipped_batches * t_gram + t_lapack)) if t_lapack else None,
                                "sample": f"oracle ro_chunking_matmul at full n with {mm} columns scaled to 98 (linear in m); oracle "
                                          f"ro_fit_chunk_hybrid (unblocked LU) at n_aug = {na} scaled by (5892/{na})^3; recurrence not priced"}
     return out

@@ -5,7 +5,7 @@
 program test_driver
   use iso_c_binding
   use speedyml_hip
-  use mod_reservoir_hip
+  use test_percall
   use speedy_dyn_hip
   implicit none
 

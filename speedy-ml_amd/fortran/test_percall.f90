@@ -1,20 +1,10 @@
-! The PER-CALL binding of round 1 (one reservoir per bank, x and outvec on the host): a minimal patch for a tree that keeps the
-! reference's own mod_reservoir and only swaps the bodies below.  The drop-in with the reference's module names, argument lists
-! and derived types -- what program main compiles against unchanged -- is mod_reservoir.f90 / mpires.f90 / resdomain.f90 /
-! mod_utilities.f90 / mod_slab_ocean_reservoir.f90 in this directory (INTEGRATION.md section 2b).
-!
-! Drop-in bodies for the prediction hot path of the reference's mod_reservoir / mod_linalg, forwarding to the
-! MI355X library.  Same subroutine names and argument meaning as the reference:
-!     mklsparse(reservoir)                      src/mod_linalg.f90:10-25     (build the device-resident operator)
-!     synchronize(reservoir, input, x, length)  src/mod_reservoir.f90:1354-1381
-!     predict(reservoir, x, local_model_in)     src/mod_reservoir.f90:1418-1489
-!     chunking_matmul(reservoir, states, model, targets)   src/mod_reservoir.f90:1645-1701 (Gram accumulation on the device)
-!     fit_chunk_hybrid(reservoir)               src/mod_reservoir.f90:1235-1334 + mldivide src/mod_linalg.f90:109-151
-! The reference's reservoir_type (src/mod_utilities.f90:168-330) carries MKL handles (cooA, descrA); the patch shown
-! in INTEGRATION.md replaces them by the two fields hip_bank / hip_slot below.  This module defines a reduced
-! reservoir_type with exactly the fields those three routines touch so that it builds stand-alone (the full type
-! needs MKL_SPBLAS / mpi modules that are not part of this repository).
-module mod_reservoir_hip
+! TEST SUPPORT ONLY (used by test_driver.f90): per-call wrappers over the C-ABI -- one reservoir in a private one-slot bank, x and outvec
+! on the host -- so that the parity driver can put single library calls (mklsparse, synchronize, predict, chunking_matmul,
+! fit_chunk_hybrid) next to the reference's own statements written out in Fortran.  This is NOT a binding to integrate against: the
+! drop-in with the reference's module names, argument lists and derived types, which program main compiles against unchanged, is
+! mod_reservoir.f90 / mpires.f90 / resdomain.f90 / mod_utilities.f90 / mod_slab_ocean_reservoir.f90 (INTEGRATION.md section 2).
+! The reduced reservoir_type below holds exactly the fields these wrappers touch.
+module test_percall
   use iso_c_binding
   use speedyml_hip
   implicit none
@@ -134,4 +124,4 @@ contains
     call sml_check(sml_dev_free(dw), 'sml_dev_free')
   end subroutine
 
-end module mod_reservoir_hip
+end module test_percall

@@ -418,14 +418,14 @@ class HybridRank:
         window and one gather; results equal the sequential form up to the association of the readout's column sum."""
         if self.mode == "sweep":
             self.bank.predict(stream=stream)
-            return
+            return True
         if self.mode == "ml_only":
             self.bank.predict(stream=stream)                     # predict_ml of every resident reservoir
             allv = self.exchange_outvec(stream)
             self.scatter_all(allv, stream)
             self.next_tisr()
             self.ex.gather(self.G, None, stream=stream)          # feedback only: there is no forecast to tile
-            return
+            return True                                          # (no SPEEDY hand-off, hence no range guard, in the ML-only loop)
         if not self.pipeline:
             if self.stop_on_unsafe and self.aborted():                   # run_speedy == .false. ends the forecast loop
                 return False                                             # (src/mpires.f90:744, src/parallelmain.f90:269-271)
@@ -448,14 +448,18 @@ class HybridRank:
             self._post_safe(stream)
             return True
         assert self.slab is None, "the pipelined schedule does not carry the slab-ocean coupling"
+        if self.stop_on_unsafe and self.aborted():
+            return False
         if self.main is not None:                               # CU-partitioned form: the whole main leg runs on the masked stream
             caller = stream
             self.main.wait_stream(caller)
             with self.torch.cuda.stream(self.main):
                 self._pipelined_body(self.main)
             caller.wait_stream(self.main)
-            return
-        self._pipelined_body(stream)
+        else:
+            self._pipelined_body(stream)
+        self._post_safe(stream)
+        return True
 
     def _pipelined_body(self, stream):
         stream.wait_event(self.ev_partial)                      # state block of this step's readout (side stream)
@@ -482,7 +486,15 @@ class HybridRank:
     # replicated and deterministic, so all ranks see the same flag: no broadcast).  The flag lives on the device; each step copies
     # it asynchronously into a pinned ring, and step() polls the COMPLETED copies without blocking -- the host stays ahead of the
     # GPU and the loop stops within the few steps that were already enqueued.
+    # Every ring entry carries the index of the step it belongs to, so that a caller can truncate its output at the first
+    # unphysical state (first_unsafe_step; the reference stops AT that step, this loop a few enqueued steps later).
     SAFE_RING = 8
+    first_unsafe_step = None
+
+    def _note_unsafe(self, k):
+        self._aborted = True
+        if self.first_unsafe_step is None or self._safe_step[k] < self.first_unsafe_step:
+            self.first_unsafe_step = self._safe_step[k]
 
     def _post_safe(self, stream):
         if getattr(self, "safe", None) is None:
@@ -490,14 +502,16 @@ class HybridRank:
         if self._safe_ring is None:
             self._safe_ring = self.torch.ones(self.SAFE_RING, dtype=self.torch.int32).pin_memory()
             self._safe_ev = [None] * self.SAFE_RING
+            self._safe_step = [0] * self.SAFE_RING
         k = self._safe_n % self.SAFE_RING
         if self._safe_ev[k] is not None:
             self._safe_ev[k].synchronize()                               # 8 steps old
             if int(self._safe_ring[k]) == 0:
-                self._aborted = True
+                self._note_unsafe(k)
         else:
             self._safe_ev[k] = self.torch.cuda.Event()
         self._safe_ring[k:k + 1].copy_(self.safe, non_blocking=True)
+        self._safe_step[k] = self.t                                      # (1-based index of the step just enqueued)
         self._safe_ev[k].record(stream)
         self._safe_n += 1
 
@@ -511,7 +525,7 @@ class HybridRank:
             if wait:
                 ev.synchronize()
             if ev.query() and int(self._safe_ring[k]) == 0:
-                self._aborted = True
+                self._note_unsafe(k)
         return self._aborted
 
     # ------------------------------------------------------------------ timing
