@@ -223,6 +223,10 @@ contains
     call get_current_time_delta_hour(calendar, start_index + length)
     call read_era(reservoir, grid, model_parameters, start_year, calendar%currentyear, era, 1)
     t0 = hours0; t1 = t0 + length; step = model_parameters%timestep; ncol = length / step
+    if (t1 > size(era%eravariables, 5)) then
+      write(*,'(a,i0,a,i0,a)') ' mod_reservoir: the window ends at hour ', t1, ' of the data read_era returned, which hold ', size(era%eravariables, 5), ' hours'
+      stop 1
+    end if
     ! units and floors as the reference applies them (:660-690): q in g/kg with a floor, no negative radiation or rain, SST >= 272 K,
     ! precipitation accumulated over a time step and log-transformed
     era%eravariables(4,:,:,:,:) = max(era%eravariables(4,:,:,:,:) * 1000.0_dp, 0.000001_dp)
@@ -264,7 +268,7 @@ contains
       natm = reservoir%local_predictvars * grid%resxchunk * grid%resychunk * grid%reszchunk
       model_states(1:natm, :) = reshape(spd%speedyvariables(:,:,:,:,t0:t1:step), [natm, ncol])
       if (reservoir%logp_bool) model_states(natm+1:reservoir%chunk_size_speedy, :) = reshape(spd%speedy_logp(:,:,t0:t1:step), [grid%resxchunk * grid%resychunk, ncol])
-    end if
+      end if
   end subroutine
 
   ! the statistics standardize_data leaves in grid%mean / grid%std (src/mod_reservoir.f90:443-470): per 3-d variable and level,
@@ -414,19 +418,19 @@ contains
     job%rows = reservoir%rows; job%cols = reservoir%cols; job%vals = reservoir%vals; job%win = reservoir%win
     job%mean = grid%mean; job%std = grid%std
     job%bank = hip_bank; job%slot = reservoir%hip_slot
-    allocate(job%pass(step))
+    call train_job_passes(job, step, ncol)
     do i = 1, step                                                       ! the interleaved passes (:298-305)
       pass_in = reservoir%trainingdata(:, i:model_parameters%traininglength:step)
-      allocate(job%pass(i)%noisy(d, ncol))
-      job%pass(i)%noisy = pass_in
+      job%ncol(i) = ncol
+      job%noisy(:, :, i) = pass_in
       if (model_parameters%noisy) then                                   ! one noisy copy per column the recurrence reads (:1091-1166)
         do c = 1, ncol - 1
           call noisy_column(pass_in(:, c), reservoir%noisemag, grid, model_parameters, model_parameters%precip_bool .and. reservoir%precip_bool, &
-                            job%pass(i)%noisy(:, c))
+                            job%noisy(:, c, i))
         end do
       end if
-      job%pass(i)%targ = pass_in(tpos(1:no) + 1, :)                      ! chunking_matmul's targets (tile_full_input_to_target_data)
-      if (nm > 0) job%pass(i)%mdl = reservoir%imperfect_model_states(:, i:model_parameters%traininglength:step)
+      job%targ(:, :, i) = pass_in(tpos(1:no) + 1, :)                     ! chunking_matmul's targets (tile_full_input_to_target_data)
+      if (nm > 0) job%mdl(:, :, i) = reservoir%imperfect_model_states(:, i:model_parameters%traininglength:step)
     end do
     reservoir%hip_train_job = train_enqueue(job)
     if (.not. (model_parameters%slab_ocean_model_bool .and. grid%bottom)) deallocate(reservoir%trainingdata)

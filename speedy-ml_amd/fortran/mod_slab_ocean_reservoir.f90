@@ -233,18 +233,19 @@ contains
     job%leakage = reservoir%leakage; job%beta_res = reservoir%beta_res; job%beta_model = reservoir%beta_model; job%prior_val = reservoir%prior_val
     job%rows = reservoir%rows; job%cols = reservoir%cols; job%vals = reservoir%vals; job%win = reservoir%win
     job%mean = grid%mean; job%std = grid%std
-    allocate(job%pass(step))
+    call train_job_passes(job, step, (total - 1) / step + 1)
     do i = 1, step
       pass_in = reservoir%trainingdata(:, i:total:step)
       ncol = size(pass_in, 2)
-      job%pass(i)%noisy = pass_in
+      job%ncol(i) = ncol
+      job%noisy(:, 1:ncol, i) = pass_in
       do c = 1, ncol - 1                                                  ! gaussian_noise_1d_function per column read (:893,:918)
         do r = 1, d
-          job%pass(i)%noisy(r, c) = pass_in(r, c) + box_muller() * reservoir%noisemag * pass_in(r, c)
+          job%noisy(r, c, i) = pass_in(r, c) + box_muller() * reservoir%noisemag * pass_in(r, c)
         end do
       end do
-      job%pass(i)%targ = pass_in(trows + 1, :)
-      if (nm > 0) job%pass(i)%mdl = persistence(:, i:total:step)
+      job%targ(:, 1:ncol, i) = pass_in(trows + 1, :)
+      if (nm > 0) job%mdl(:, 1:ncol, i) = persistence(:, i:total:step)
     end do
     ! resident beside its atmosphere reservoir from now on; W_out arrives when the training queue runs (speedyml_train)
     reservoir%wout = 0.0_dp

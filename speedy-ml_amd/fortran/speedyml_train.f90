@@ -11,18 +11,16 @@ module speedyml_train
   use speedyml_hip
   implicit none
   private
-  public :: train_job, pass_data, train_enqueue, train_flush, train_take, train_pending, train_group_size, train_last_seconds, train_last_count
-
-  type pass_data                                 ! one interleaved pass: columns i, i + step, i + 2 step ... of the hourly arrays
-    real(c_double), allocatable :: noisy(:,:), targ(:,:), mdl(:,:)      ! (d, ncol), (n_out, ncol), (n_model, ncol)
-  end type
+  public :: train_job, train_job_passes, train_enqueue, train_flush, train_take, train_pending, train_group_size, train_last_seconds, train_last_count
 
   type train_job
     integer :: n = 0, d = 0, k = 0, n_model = 0, n_out = 0, discard = 0, batch = 0, ml_variant = 0, using_prior = 0
     real(c_double) :: leakage = 1.0_c_double, beta_res = 0.0_c_double, beta_model = 0.0_c_double, prior_val = 0.0_c_double
     integer(c_int), allocatable :: rows(:), cols(:)
     real(c_double), allocatable :: vals(:), win(:,:), mean(:), std(:)
-    type(pass_data), allocatable :: pass(:)
+    ! the interleaved passes (columns i, i + step, i + 2 step ... of the hourly arrays): pass p has ncol(p) columns
+    integer, allocatable :: ncol(:)
+    real(c_double), allocatable :: noisy(:,:,:), targ(:,:,:), mdl(:,:,:)      ! (d, max ncol, npass), (n_out, ., .), (n_model, ., .)
     type(c_ptr) :: bank = c_null_ptr             ! the prediction bank that receives W_out (sml_bank_set_wout), or null
     integer(c_int) :: slot = -1
     real(c_double), allocatable :: wout(:,:)     ! (n_out, n_model + n): the result
@@ -62,6 +60,12 @@ contains
       end do
       call move_alloc(grown, jobs)
     end if
+    ! a Gram matrix of non-finite columns fails much later, inside the ridge solve: refuse them here, where the region is still known
+    if (.not. (all(abs(job%noisy) <= huge(1.0_c_double)) .and. all(abs(job%targ) <= huge(1.0_c_double)) .and. all(abs(job%mdl) <= huge(1.0_c_double)))) then
+      write(*,'(a,i0,a,3l2)') ' speedyml_train: job ', njobs + 1, ': training columns are not finite (inputs, targets, model states finite =', &
+            all(abs(job%noisy) <= huge(1.0_c_double)), all(abs(job%targ) <= huge(1.0_c_double)), all(abs(job%mdl) <= huge(1.0_c_double))
+      stop 1
+    end if
     njobs = njobs + 1
     call move_job(job, jobs(njobs))
     train_enqueue = njobs
@@ -79,7 +83,10 @@ contains
     if (allocated(a%win)) call move_alloc(a%win, b%win)
     if (allocated(a%mean)) call move_alloc(a%mean, b%mean)
     if (allocated(a%std)) call move_alloc(a%std, b%std)
-    if (allocated(a%pass)) call move_alloc(a%pass, b%pass)
+    if (allocated(a%ncol)) call move_alloc(a%ncol, b%ncol)
+    if (allocated(a%noisy)) call move_alloc(a%noisy, b%noisy)
+    if (allocated(a%targ)) call move_alloc(a%targ, b%targ)
+    if (allocated(a%mdl)) call move_alloc(a%mdl, b%mdl)
     if (allocated(a%wout)) call move_alloc(a%wout, b%wout)
   end subroutine
 
@@ -93,14 +100,18 @@ contains
     deallocate(jobs(id)%wout)
   end subroutine
 
+  ! storage of a job's passes: npass passes of at most max_col columns
+  subroutine train_job_passes(job, npass, max_col)
+    type(train_job), intent(inout) :: job
+    integer, intent(in) :: npass, max_col
+    allocate(job%ncol(npass), job%noisy(job%d, max_col, npass), job%targ(job%n_out, max_col, npass), job%mdl(max(job%n_model, 1), max_col, npass))
+    job%ncol = 0; job%noisy = 0.0_c_double; job%targ = 0.0_c_double; job%mdl = 0.0_c_double
+  end subroutine
+
   logical function same_schedule(a, b)
     type(train_job), intent(in) :: a, b
-    integer :: p
-    same_schedule = a%discard == b%discard .and. a%batch == b%batch .and. a%ml_variant == b%ml_variant .and. size(a%pass) == size(b%pass)
-    if (.not. same_schedule) return
-    do p = 1, size(a%pass)
-      if (size(a%pass(p)%noisy, 2) /= size(b%pass(p)%noisy, 2)) same_schedule = .false.
-    end do
+    same_schedule = a%discard == b%discard .and. a%batch == b%batch .and. a%ml_variant == b%ml_variant .and. size(a%ncol) == size(b%ncol)
+    if (same_schedule) same_schedule = all(a%ncol == b%ncol)
   end function
 
   logical function same_system(a, b)
@@ -143,51 +154,53 @@ contains
     integer, intent(in) :: m(:)
     type(c_ptr) :: tbank, dnoisy
     type(c_ptr), allocatable :: dmodel(:), dtarg(:), dc(:), db(:), dw(:), cc(:), bb(:), ww(:)
-    real(c_double), allocatable :: stage(:,:,:), zero_wout(:,:)
+    real(c_double), allocatable :: stage(:,:,:), zero_wout(:,:), buf(:,:)
     integer(c_int), allocatable :: nostat(:)
     logical, allocatable :: solved(:)
-    integer :: cap, s, p, i, j, max_d, max_nm, max_no, max_col, ncol, n_aug, cnt
+    integer :: cap, s, p, i, j, k, max_d, max_nm, max_no, max_col, ncol, n_aug, cnt, npass
     integer(c_int) :: nb
     integer(c_int64_t) :: b8
     cap = size(m)
-    max_d = 0; max_nm = 1; max_no = 0; max_col = 0
+    k = m(1)
+    npass = size(jobs(k)%ncol)
+    max_col = maxval(jobs(k)%ncol)
+    max_d = 0; max_nm = 1; max_no = 0
     do s = 1, cap
       max_d = max(max_d, jobs(m(s))%d); max_nm = max(max_nm, jobs(m(s))%n_model); max_no = max(max_no, jobs(m(s))%n_out)
-    end do
-    do p = 1, size(jobs(m(1))%pass)
-      max_col = max(max_col, size(jobs(m(1))%pass(p)%noisy, 2))
     end do
     ! a bank of `cap` slots for the recurrences (W_out plays no part in training: zeros)
     call sml_check(sml_bank_create(int(cap, c_int), int(max_d, c_int), int(max_nm, c_int), int(max_no, c_int), tbank), 'sml_bank_create')
     allocate(dmodel(cap), dtarg(cap), dc(cap), db(cap), dw(cap))
     b8 = 8
     do s = 1, cap
-      associate (q => jobs(m(s)))
-        n_aug = q%n + q%n_model
-        allocate(zero_wout(q%n_out, n_aug), nostat(q%n_out))
-        zero_wout = 0.0_c_double; nostat = -1
-        call sml_check(sml_bank_load(tbank, int(s - 1, c_int), int(q%n, c_int), int(q%d, c_int), int(q%k, c_int), int(q%n_model, c_int), &
-                                     int(q%n_out, c_int), q%rows, q%cols, q%vals, q%win, zero_wout, q%leakage, q%mean, q%std, &
-                                     int(size(q%mean), c_int), nostat), 'sml_bank_load')
-        deallocate(zero_wout, nostat)
-        call sml_check(sml_dev_alloc(b8 * n_aug * n_aug, dc(s)), 'sml_dev_alloc'); call sml_check(sml_dev_zero(dc(s), b8 * n_aug * n_aug), 'sml_dev_zero')
-        call sml_check(sml_dev_alloc(b8 * q%n_out * n_aug, db(s)), 'sml_dev_alloc'); call sml_check(sml_dev_zero(db(s), b8 * q%n_out * n_aug), 'sml_dev_zero')
-        call sml_check(sml_dev_alloc(b8 * q%n_out * n_aug, dw(s)), 'sml_dev_alloc')
-        call sml_check(sml_dev_alloc(b8 * q%n_out * max_col, dtarg(s)), 'sml_dev_alloc')
-        call sml_check(sml_dev_alloc(b8 * max(q%n_model, 1) * max_col, dmodel(s)), 'sml_dev_alloc')
-      end associate
+      k = m(s)
+      n_aug = jobs(k)%n + jobs(k)%n_model
+      allocate(zero_wout(jobs(k)%n_out, n_aug), nostat(jobs(k)%n_out))
+      zero_wout = 0.0_c_double; nostat = -1
+      call sml_check(sml_bank_load(tbank, int(s - 1, c_int), int(jobs(k)%n, c_int), int(jobs(k)%d, c_int), int(jobs(k)%k, c_int), int(jobs(k)%n_model, c_int), &
+                                   int(jobs(k)%n_out, c_int), jobs(k)%rows, jobs(k)%cols, jobs(k)%vals, jobs(k)%win, zero_wout, jobs(k)%leakage, jobs(k)%mean, &
+                                   jobs(k)%std, int(size(jobs(k)%mean), c_int), nostat), 'sml_bank_load')
+      deallocate(zero_wout, nostat)
+      call sml_check(sml_dev_alloc(b8 * n_aug * n_aug, dc(s)), 'sml_dev_alloc'); call sml_check(sml_dev_zero(dc(s), b8 * n_aug * n_aug), 'sml_dev_zero')
+      call sml_check(sml_dev_alloc(b8 * jobs(k)%n_out * n_aug, db(s)), 'sml_dev_alloc'); call sml_check(sml_dev_zero(db(s), b8 * jobs(k)%n_out * n_aug), 'sml_dev_zero')
+      call sml_check(sml_dev_alloc(b8 * jobs(k)%n_out * n_aug, dw(s)), 'sml_dev_alloc')
+      call sml_check(sml_dev_alloc(b8 * jobs(k)%n_out * max_col, dtarg(s)), 'sml_dev_alloc')
+      call sml_check(sml_dev_alloc(b8 * max(jobs(k)%n_model, 1) * max_col, dmodel(s)), 'sml_dev_alloc')
     end do
     call sml_check(sml_dev_alloc(b8 * max_d * cap * max_col, dnoisy), 'sml_dev_alloc')
-    do p = 1, size(jobs(m(1))%pass)
-      ncol = size(jobs(m(1))%pass(p)%noisy, 2)
+    do p = 1, npass
+      ncol = jobs(m(1))%ncol(p)
       allocate(stage(max_d, cap, ncol))              ! = [ncol][capacity][max_d] as the library reads it
       stage = 0.0_c_double
       do s = 1, cap
-        associate (q => jobs(m(s)))
-          stage(1:q%d, s, :) = q%pass(p)%noisy
-          call sml_check(sml_dev_upload(dtarg(s), q%pass(p)%targ, b8 * q%n_out * ncol), 'sml_dev_upload')
-          if (q%n_model > 0) call sml_check(sml_dev_upload(dmodel(s), q%pass(p)%mdl, b8 * q%n_model * ncol), 'sml_dev_upload')
-        end associate
+        k = m(s)
+        stage(1:jobs(k)%d, s, 1:ncol) = jobs(k)%noisy(:, 1:ncol, p)
+        buf = jobs(k)%targ(:, 1:ncol, p)               ! (contiguous copies: the library reads (rows, ncol) column-major blocks)
+        call sml_check(sml_dev_upload(dtarg(s), buf, b8 * jobs(k)%n_out * ncol), 'sml_dev_upload')
+        if (jobs(k)%n_model > 0) then
+          buf = jobs(k)%mdl(:, 1:ncol, p)
+          call sml_check(sml_dev_upload(dmodel(s), buf, b8 * jobs(k)%n_model * ncol), 'sml_dev_upload')
+        end if
       end do
       call sml_check(sml_dev_upload(dnoisy, stage, b8 * max_d * cap * ncol), 'sml_dev_upload')
       deallocate(stage)
@@ -208,20 +221,21 @@ contains
           end if
         end if
       end do
-      associate (q => jobs(m(i)))
-        call sml_check(sml_train_fit_batched(int(cnt, c_int), cc, bb, int(q%n, c_int), int(q%n_model, c_int), int(q%n_out, c_int), q%beta_res, &
-                                             q%beta_model, q%prior_val, int(q%using_prior, c_int), ww, c_null_ptr), 'sml_train_fit_batched')
-      end associate
+      k = m(i)
+      write(*,'(a,i0,a,i0,a,i0,a,i0,a,i0,a)') ' speedyml_train: ridge solves of ', cnt, ' system(s) with n = ', jobs(k)%n, ', n_model = ', jobs(k)%n_model, &
+            ', n_out = ', jobs(k)%n_out, ' (', npass, ' passes accumulated)'
+      call sml_check(sml_train_fit_batched(int(cnt, c_int), cc, bb, int(jobs(k)%n, c_int), int(jobs(k)%n_model, c_int), int(jobs(k)%n_out, c_int), &
+                                           jobs(k)%beta_res, jobs(k)%beta_model, jobs(k)%prior_val, int(jobs(k)%using_prior, c_int), ww, c_null_ptr), &
+                     'sml_train_fit_batched')
     end do
     do s = 1, cap
-      associate (q => jobs(m(s)))
-        n_aug = q%n + q%n_model
-        allocate(q%wout(q%n_out, n_aug))
-        call sml_check(sml_dev_download(q%wout, dw(s), b8 * q%n_out * n_aug), 'sml_dev_download')
-        if (c_associated(q%bank)) call sml_check(sml_bank_set_wout(q%bank, q%slot, q%wout), 'sml_bank_set_wout')
-        q%done = .true.
-        deallocate(q%pass, q%rows, q%cols, q%vals, q%win)
-      end associate
+      k = m(s)
+      n_aug = jobs(k)%n + jobs(k)%n_model
+      allocate(jobs(k)%wout(jobs(k)%n_out, n_aug))
+      call sml_check(sml_dev_download(jobs(k)%wout, dw(s), b8 * jobs(k)%n_out * n_aug), 'sml_dev_download')
+      if (c_associated(jobs(k)%bank)) call sml_check(sml_bank_set_wout(jobs(k)%bank, jobs(k)%slot, jobs(k)%wout), 'sml_bank_set_wout')
+      jobs(k)%done = .true.
+      deallocate(jobs(k)%ncol, jobs(k)%noisy, jobs(k)%targ, jobs(k)%mdl, jobs(k)%rows, jobs(k)%cols, jobs(k)%vals, jobs(k)%win)
       call sml_check(sml_dev_free(dc(s)), 'sml_dev_free'); call sml_check(sml_dev_free(db(s)), 'sml_dev_free'); call sml_check(sml_dev_free(dw(s)), 'sml_dev_free')
       call sml_check(sml_dev_free(dtarg(s)), 'sml_dev_free'); call sml_check(sml_dev_free(dmodel(s)), 'sml_dev_free')
     end do

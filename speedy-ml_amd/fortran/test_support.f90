@@ -58,10 +58,13 @@ contains
   subroutine hours_covered(start_year, end_year, nh)
     integer, intent(in) :: start_year, end_year
     integer, intent(out) :: nh
-    integer :: into
-    ! the reference's readers return whole calendar years; the stand-in stops at the last hour the caller can index
+    integer :: into, whole
+    ! the reference's readers return whole calendar years (leap years with 8784 hours); the stand-in stops just after the last hour
+    ! the caller can index
     call numof_hours_into_year(calendar%currentyear, calendar%currentmonth, calendar%currentday, calendar%currenthour, into)
-    nh = (end_year - start_year) * 8760 + into + 8
+    whole = 0
+    if (end_year > start_year) call numof_hours(start_year, end_year - 1, whole)
+    nh = whole + into + 8
   end subroutine
 
   ! read_era (src/speedy_res_interface.f90): the region's INPUT patch, hourly, periodic in x

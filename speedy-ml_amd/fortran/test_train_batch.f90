@@ -34,6 +34,7 @@ program test_train_batch
   res%model_parameters%num_of_regions_on_proc = nreg
   call init_random_marker(33)
   allocate(res%reservoir(nreg, 1), res%grid(nreg, 1), res%reservoir_special(nreg, 1), res%grid_special(nreg, 1))
+  res%reservoir_special(:,1)%sst_bool_prediction = .false.
   call initialize_calendar(calendar, 1981, 1, 1, 0)
 
   do i = 1, nreg
