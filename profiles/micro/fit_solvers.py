@@ -14,6 +14,9 @@ states = torch.randn((m, n), dtype=torch.float64, device="cuda")
 model = torch.randn((m, n_model), dtype=torch.float64, device="cuda")
 y = torch.randn((m, n_out), dtype=torch.float64, device="cuda")
 c = train.fortran_zeros(n_aug, n_aug); b = train.fortran_zeros(n_out, n_aug)
+if os.environ.get("FIT_PRE98"):          # the bench's order: the m = 98 product (k_gemm_nt_dma + side streams) first
+    s98, m98, y98 = states[:98].contiguous(), model[:98].contiguous(), y[:98].contiguous()
+    for _ in range(23): train.chunking_matmul(s98, m98, y98, c, b)
 for _ in range(3): train.chunking_matmul(states, model, y, c, b)
 torch.cuda.synchronize()
 flops = (2.0 / 3.0) * n_aug ** 3 + 2.0 * n_aug ** 2 * n_out

@@ -1825,7 +1825,10 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch, bool chol = 
     SML_HIP(hipMalloc((void **)&s.c_list, (size_t)nbatch * sizeof(double *)));
     SML_HIP(hipMalloc((void **)&s.b_list, (size_t)nbatch * sizeof(double *)));
     SML_HIP(hipMalloc((void **)&s.wout_list, (size_t)nbatch * sizeof(double *)));
-    SML_HIP(hipStreamCreateWithFlags(&s.sp, hipStreamNonBlocking));
+    // Both streams are created with an explicit CU mask even where the mask is "every CU": a masked stream owns its hardware queue,
+    // while plain streams share the runtime's small pool of queues with every other stream of the process, and two streams on one
+    // queue run in order -- the panel chain then no longer overlaps the trailing update (measured: the Cholesky single solve took
+    // 10.3 ms instead of 7.2 once two more plain streams existed in the process, profiles/micro/fit_solvers.py with FIT_PRE98=1).
     // The trailing updates run on a stream whose CU mask leaves a few compute units free: a leaf workgroup needs a whole CU
     // (all of its registers), and behind an unmasked GEMM grid it waited for one to drain (measured: 250 us instead of 30).
     {
@@ -1857,13 +1860,22 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch, bool chol = 
             if (rcm) return rcm;
             s.sg_masked = true;
             if (s.confined) {
-                (void)hipStreamDestroy(s.sp);
-                s.sp = nullptr;
                 if ((rcm = sml::masked_stream_create(&s.sp, pm.data(), (int)pm.size()))) return rcm;
                 s.sp_masked = true;
             }
-        } else
-            SML_HIP(hipStreamCreateWithFlags(&s.sg, hipStreamNonBlocking));
+        }
+        std::vector<uint32_t> every((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu; ++i) every[i / 32] |= 1u << (i % 32);
+        if (!s.sg) {
+            int rcm = sml::masked_stream_create(&s.sg, every.data(), (int)every.size());
+            if (rcm) return rcm;
+            s.sg_masked = true;
+        }
+        if (!s.sp) {
+            int rcm = sml::masked_stream_create(&s.sp, every.data(), (int)every.size());
+            if (rcm) return rcm;
+            s.sp_masked = true;
+        }
     }
     SML_HIP(hipEventCreateWithFlags(&s.ev_panel, hipEventDisableTiming));
     SML_HIP(hipEventCreateWithFlags(&s.ev_strip, hipEventDisableTiming));
