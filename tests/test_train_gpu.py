@@ -181,17 +181,34 @@ def test_long_gram_shapes_and_determinism(n, n_model, n_out, m):
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
 
 
-def test_single_solve_stream_layouts_agree_bitwise(tmp_path):
-    """A single ridge solve confines its panel chain to reserved CUs and sends the interchanges / U12 of the far columns to the
-    trailing stream; batches (and SML_LU_CONFINE=0) keep everything on one chain.  Same arithmetic, different stream ordering: the
-    weights must agree bit for bit (a missing dependency between the two streams shows up here), for a system with a ragged last
-    panel and right-hand sides that straddle it."""
+@pytest.mark.parametrize("n", [1500, 5760])
+def test_single_solve_stream_layouts_agree_bitwise(tmp_path, n):
+    """The pivoted LU (SML_FIT_SOLVER=lu): a single ridge solve confines its panel chain to reserved CUs and sends the interchanges /
+    U12 of the far columns to the trailing stream; batches (and SML_LU_CONFINE=0) keep everything on one chain.  Same arithmetic,
+    different stream ordering: the weights must agree bit for bit (a missing dependency between the two streams shows up here), for a
+    system with a ragged last panel and right-hand sides that straddle it (n = 1500) and at the full size of config 4 (n_aug = 5892)."""
     import subprocess, sys
     outs = []
     for confine in ("1", "0"):
         f = tmp_path / f"w{confine}.npy"
-        env = dict(os.environ, SML_LU_CONFINE=confine)
-        subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_fit_dump.py"), str(f), "1500"], check=True, env=env, timeout=600)
+        env = dict(os.environ, SML_LU_CONFINE=confine, SML_FIT_SOLVER="lu")
+        subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_fit_dump.py"), str(f), str(n)], check=True, env=env, timeout=600)
+        outs.append(np.load(f))
+    assert np.all(np.isfinite(outs[0]))
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n", [1500, 5760])
+def test_cholesky_fused_and_split_panel_forms_agree_bitwise(tmp_path, n):
+    """The Cholesky (default solver): a single solve factors a panel and solves its U12 rows in ONE launch (k_chol_panel), batches use
+    a factor-only launch and the MFMA triangular solve with the exported quad inverses.  Both forms must give the same bits (this is
+    what makes a batched fit equal to single fits), at a ragged size and at the full size of config 4."""
+    import subprocess, sys
+    outs = []
+    for fused in ("1", "0"):
+        f = tmp_path / f"c{fused}.npy"
+        env = dict(os.environ, SML_CHOL_FUSED=fused, SML_FIT_SOLVER="chol")
+        subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_fit_dump.py"), str(f), str(n)], check=True, env=env, timeout=600)
         outs.append(np.load(f))
     assert np.all(np.isfinite(outs[0]))
     assert np.array_equal(outs[0], outs[1])
