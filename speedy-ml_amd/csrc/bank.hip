@@ -534,7 +534,7 @@ int download_state(const HostRes &R, const double *src, double *x_host)
 }
 
 int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, hipStream_t st, int square_input = 0,
-                  const TrainSlot *train_slots = nullptr, int train_col = 0)
+                  const TrainSlot *train_slots = nullptr, int train_col = 0, int parts_cap = 4)
 {
     // 512-thread workgroups: three per CU (3 x 50.7 KB LDS, 24 waves).  A workgroup's life is latency-bound (29 us for a whole
     // reservoir on an idle chip: staging + ~11 dependent slice batches per wave) and staging [x ; u] costs 18 us per copy
@@ -558,7 +558,7 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
         whole = (nres8 / slots) * slots;                     // multiples of 8 as long as the CU count is
         whole -= whole % 8;
         const int rem = nres8 - whole;
-        parts = rem ? std::max(1, std::min(4, slots / rem)) : 1;
+        parts = rem ? std::max(1, std::min(parts_cap, slots / rem)) : 1;
     }
     const int nblocks = whole + (nres8 - whole) * parts;
     const size_t lds = (size_t)b->max_nd * sizeof(double);
@@ -1085,8 +1085,10 @@ int sml_bank_train_pass(sml_bank *b, const double *noisy_inputs_dev, int T, int 
     for (int i = 1; i <= training_length - 1 && rc == SML_OK; ++i) {
         // the running (unsquared) state lives in the bank, so "restart from saved_state after a flush" (quirk Q6) is implicit;
         // the ML-only loop instead feeds the squared column into A x on the step after a flush (:1031-1044)
+        // (up to 12 workgroups per reservoir: a pass has few residents and one launch per time column, so the launch is as long as its
+        //  slowest workgroup -- 32 / 64 residents: 63.2 -> 59.2 / 112.2 -> 109.3 ms per 20-batch pass, profiles/micro/sweep_train_parts.sh)
         rc = launch_update(b, 0, b->capacity, noisy_inputs_dev + step * (discard + i - 1), st, ml_variant && i % batch == 0, d_ts,
-                           pending * batch + i % batch);                  // the new state goes into its states column from the same launch
+                           pending * batch + i % batch, 12);              // the new state goes into its states column from the same launch
         if (rc) break;
         if ((i + 1) % batch == 0) {
             ++flushed; ++pending;

@@ -208,19 +208,23 @@ def _engine_worker(rank, world, name, out_dir, slab):
         check(L.sml_comm_destroy(comm))
 
 
-@pytest.mark.parametrize("slab", [False, True])
-def test_native_engine_two_ranks_equal_one_rank(tmp_path, slab):
+@pytest.mark.parametrize("world,slab", [(2, False), (2, True), (5, True)])
+def test_native_engine_ranks_equal_one_rank(tmp_path, world, slab):
     """The C-ABI's own rank exchange inside the engine (sml_hybrid_set_comm -> sml_comm_allgather_outvec, for the atmosphere and
-    the slab bank): two processes, each with its share of processor_decomposition and its own engine, reproduce the single-rank run
-    bit for bit.  Two ranks on ONE GPU: the communicator is the host-staged rehearsal transport (SML_COMM_TRANSPORT=shm); with one GPU
-    per rank the same calls run over RCCL."""
+    the slab bank): `world` processes, each with its share of processor_decomposition and its own engine, reproduce the single-rank
+    run bit for bit.  Five ranks split 1152 regions raggedly (231, 231, 230, 230, 230): the padded staging buffer and
+    sml_comm_unpack_regions are on the path.  All ranks share ONE GPU: the communicator is the host-staged rehearsal transport
+    (SML_COMM_TRANSPORT=shm); with one GPU per rank the same calls run over RCCL."""
     import torch.multiprocessing as mp
-    name = f"sml_test_{os.getpid()}_{int(slab)}"
-    mp.spawn(_engine_worker, args=(2, name, str(tmp_path), slab), nprocs=2, join=True)
+    name = f"sml_test_{os.getpid()}_{world}_{int(slab)}"
+    mp.spawn(_engine_worker, args=(world, name, str(tmp_path), slab), nprocs=world, join=True)
     _engine_worker(0, 1, name, str(tmp_path), slab)
     one = np.load(tmp_path / "eng1_0.npz")
-    for r in range(2):
-        d = np.load(tmp_path / f"eng2_{r}.npz")
+    seen = 0
+    for r in range(world):
+        d = np.load(tmp_path / f"eng{world}_{r}.npz")
         assert np.array_equal(d["G"], one["G"]) and np.array_equal(d["F"], one["F"]), r
         regs = d["regions"]
+        seen += len(regs)
         assert np.array_equal(d["fb"], one["fb"][regs]) and np.array_equal(d["lm"], one["lm"][regs]), r
+    assert seen == NREG
