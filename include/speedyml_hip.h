@@ -561,8 +561,8 @@ int sml_train_symmetrize(double *c_dev, int n_aug, void *stream);
  * (an indefinite matrix, or one singular to working precision) sends that system through the pivoted LU instead, which is dgesv's
  * algorithm (first maximum per column, row interchange), as mldivide is (src/mod_linalg.f90:109-151); sml_train_select_solver(1) makes
  * the LU the only solver.  c_dev is symmetrised in place either way (sml_train_accumulate fills the lower-triangle tiles only).
- * Limits: the LU keeps its panel in registers and takes n_aug <= 7168; the Cholesky has no size limit.  Any n_out (the back substitution
- * runs in groups of 136 right-hand sides).  Both are checked before anything is enqueued.
+ * No size limits: the LU's register-resident panel kernel holds 7168 rows and taller panels go through a slower in-memory leaf; any
+ * n_out (the back substitution runs in groups of 136 right-hand sides).
  * Returns SML_ERR_NUMERIC when a pivot of the LU is exactly zero (dgesv info > 0). */
 int sml_train_fit(double *c_dev, const double *b_dev, int n, int n_model, int n_out, double beta_res, double beta_model,
                   double prior_val, int using_prior, double *wout_dev, void *stream);

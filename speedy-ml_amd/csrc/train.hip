@@ -875,6 +875,83 @@ __global__ __launch_bounds__(LEAF_T) void k_lu_leaf(double *__restrict__ P, long
 }
 #undef LEAF_STAMP
 
+// The leaf for panels taller than the register-resident form holds (more than 14 x 512 rows): the same factorisation -- pivot rule,
+// multipliers, fused updates, interchanges and the U rows of the panel's other columns, in the same operation order -- on the panel in
+// memory, one 512-thread workgroup striding over the rows.  Slow (every pivot is a pass over the column through L2) and rare: systems
+// this size are not positive definite ones of the shipped region layouts; it exists so that the LU has no size limit.
+__global__ __launch_bounds__(512) void k_lu_leaf_tall(double *__restrict__ P, long np, int n, int K0, int c, int lw, int nbp, int *__restrict__ ipiv,
+                                                      int *__restrict__ info, LuStride ls)
+{
+    P += ls.p * blockIdx.x; ipiv += ls.ipiv * blockIdx.x; info += blockIdx.x;
+    constexpr int T = 512, NWV = T / 64;
+    __shared__ double sval[NWV];
+    __shared__ int sidx[NWV];
+    __shared__ int s_piv;
+    __shared__ double rowp[LU_LEAF];                         // the pivot row's entries in the leaf's columns
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = c - K0;
+    for (int j = 0; j < lw; ++j) {
+        const int col = c + j;
+        double *cj = P + (long)(q0 + j) * np;
+        // first maximum of |a| from the diagonal on, lowest row among ties
+        double best = -1.0;
+        int brow = 0x7fffffff;
+        for (int r = col + tid; r < n; r += T) {
+            const double v = fabs(cj[r]);
+            if (v > best) { best = v; brow = r; }            // (rows ascend per thread: the first maximum is the lowest row)
+        }
+        const double mw = wave_max_f64(best);
+        const int iw = wave_min_i32(best == mw ? brow : 0x7fffffff);
+        if (lane == 0) { sval[wave] = mw; sidx[wave] = iw; }
+        __syncthreads();
+        if (tid == 0) {
+            double b2 = sval[0];
+            for (int w2 = 1; w2 < NWV; ++w2) b2 = fmax(b2, sval[w2]);
+            int p = 0x7fffffff;
+            for (int w2 = 0; w2 < NWV; ++w2) p = min(p, sval[w2] == b2 ? sidx[w2] : 0x7fffffff);
+            if (p == 0x7fffffff) p = col;                     // (no finite candidate: NaN column)
+            ipiv[col] = p;
+            s_piv = p;
+            if (b2 == 0.0 && *info == 0) *info = col + 1;
+        }
+        __syncthreads();
+        const int p = s_piv;
+        if (p != col && tid < nbp) {                          // the interchange, in every column of the panel
+            double *cq = P + (long)tid * np;
+            const double a = cq[col], b = cq[p];
+            cq[col] = b; cq[p] = a;
+        }
+        __syncthreads();
+        if (tid < lw) rowp[tid] = P[(long)(q0 + tid) * np + col];
+        __syncthreads();
+        const double pv = rowp[j];
+        if (pv != 0.0) {
+            const double inv = 1.0 / pv;
+            for (int r = col + 1 + tid; r < n; r += T) {
+                const double l = cj[r] * inv;
+                cj[r] = l;
+                for (int jj = j + 1; jj < lw; ++jj) {
+                    double *cjj = P + (long)(q0 + jj) * np;
+                    cjj[r] = __builtin_fma(-l, rowp[jj], cjj[r]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the U rows of the panel's columns to the right of the leaf: forward substitution with the leaf's unit lower triangle
+    const int q = q0 + lw + tid;
+    if (q < nbp) {
+        double *cq = P + (long)q * np;
+        double u[LU_LEAF];
+        for (int r = 0; r < lw; ++r) {
+            double v = cq[c + r];
+            for (int k = 0; k < r; ++k) v = __builtin_fma(-P[(long)(q0 + k) * np + c + r], u[k], v);
+            u[r] = v;
+            cq[c + r] = v;
+        }
+    }
+}
+
 // rank-lw update of the panel's columns to the right of a leaf: P[q][r] -= sum_k L(r,k) U(k,q), r >= c+lw, q >= q0+lw.
 // 256 rows x 16 columns per workgroup; the 16 x 8 U block goes through LDS, all loads are issued before the arithmetic.
 constexpr int PU_COLS = 16;
@@ -1884,11 +1961,11 @@ static int lu_sys_alloc(LuSys &s, int n_aug, int ncols, int nbatch, bool chol = 
 
 // leaf shape by height: (threads, rows per thread, columns); R x LW doubles + ~56 registers must stay within 256
 struct LeafShape { int threads, slots, width; };
-constexpr int LU_LEAF_MAX_ROWS = 14 * 512;
 static LeafShape leaf_shape(int rows_left)
 {
     if (rows_left <= 14 * 256) return {256, (rows_left + 255) / 256, 8};
     const int r = (rows_left + 511) / 512;
+    if (r > 14) return {512, 0, 8};                  // taller than the registers hold: k_lu_leaf_tall (slots = 0)
     return {512, r, r <= 12 ? 8 : 6};
 }
 
@@ -1908,7 +1985,9 @@ static int launch_leaf(LuSys &S, int nb, long np, int n, int K0, int c, int lw, 
         if (lw == LW) hipLaunchKernelGGL((k_lu_leaf<T, R, LW, true>), dim3(nb), dim3(T), 0, st, Pk, np, n, K0, c, lw, nbp, S.ipiv, S.info, stamps, S.ls);  \
         else hipLaunchKernelGGL((k_lu_leaf<T, R, LW, false>), dim3(nb), dim3(T), 0, st, Pk, np, n, K0, c, lw, nbp, S.ipiv, S.info, stamps, S.ls);          \
         break
-    if (sh.threads == 256) {
+    if (sh.slots == 0)
+        hipLaunchKernelGGL(k_lu_leaf_tall, dim3(nb), dim3(512), 0, st, Pk, np, n, K0, c, lw, nbp, S.ipiv, S.info, S.ls);
+    else if (sh.threads == 256) {
         switch (sh.slots) {
             LEAF_CASE(256, 1, 8); LEAF_CASE(256, 2, 8); LEAF_CASE(256, 3, 8); LEAF_CASE(256, 4, 8); LEAF_CASE(256, 5, 8); LEAF_CASE(256, 6, 8);
             LEAF_CASE(256, 7, 8); LEAF_CASE(256, 8, 8); LEAF_CASE(256, 9, 8); LEAF_CASE(256, 10, 8); LEAF_CASE(256, 11, 8); LEAF_CASE(256, 12, 8);
@@ -2261,12 +2340,8 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
     SML_REQUIRE(count > 0 && c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit_batched: bad arguments");
     for (int i = 0; i < count; ++i) SML_REQUIRE(c[i] && b[i] && wout[i], "sml_train_fit_batched: null system %d", i);
     hipStream_t st = sml::as_stream(stream);
-    const int n_aug = n + n_model;
     const int solver = sml_train_select_solver(-1);
-    // the pivoted LU keeps its panel in registers: LU_LEAF_MAX_ROWS rows at most (checked here, before anything is enqueued)
-    const bool lu_fits = n_aug <= LU_LEAF_MAX_ROWS;
-    if (solver == 1) SML_REQUIRE(lu_fits, "sml_train_fit: n_aug = %d exceeds the %d rows of the pivoted LU's register-resident panel (the Cholesky path has no such limit)",
-                                 n_aug, LU_LEAF_MAX_ROWS);
+    // (no size limit: panels taller than 14 x 512 rows go through k_lu_leaf_tall instead of the register-resident leaf)
     std::vector<int> hinfo;
     int rc;
     if (solver != 1) {
@@ -2275,9 +2350,8 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
         for (int i = 0; i < count; ++i)
             if (hinfo[i]) redo.push_back(i);
         if (redo.empty()) return SML_OK;
-        if (solver == 2 || !lu_fits)
-            return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d is not positive definite (Cholesky pivot %d is not positive)%s", redo[0], hinfo[redo[0]],
-                             solver == 2 ? "" : "; its size is beyond the pivoted LU");
+        if (solver == 2)
+            return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d is not positive definite (Cholesky pivot %d is not positive)", redo[0], hinfo[redo[0]]);
         // the systems the Cholesky could not factorise (indefinite, or singular to working precision): dgesv's algorithm
         std::vector<double *> c2, w2;
         std::vector<const double *> b2;

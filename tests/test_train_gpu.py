@@ -417,3 +417,26 @@ def test_cholesky_only_rejects_an_indefinite_system_and_auto_falls_back():
         assert np.max(np.abs(w - want)) <= 1e-8 * np.max(np.abs(want))
     finally:
         _select_solver(prev)
+
+
+def test_lu_of_a_system_taller_than_the_register_leaf():
+    """The pivoted LU has no size limit: panels taller than the 7168 rows its register-resident leaf holds go through k_lu_leaf_tall
+    (the same pivot rule and arithmetic on the panel in memory).  A 7400-row symmetric INDEFINITE system (so the default solver's
+    Cholesky gives up and the LU takes over) with 140 right-hand sides (two groups of the back substitution), against LAPACK."""
+    rng = np.random.default_rng(17)
+    n, n_model, n_out = 7396, 4, 140
+    n_aug = n + n_model
+    s = rng.standard_normal((n_aug, 64))
+    sym = s @ s.T - 0.5 * np.diag(rng.uniform(1.0, 2.0, n_aug)) * 64          # symmetric with eigenvalues of both signs
+    bm = rng.standard_normal((n_out, n_aug))
+    c, b = to_dev(sym), to_dev(bm)
+    prev = _select_solver(-1)
+    try:
+        _select_solver(0)
+        w = to_host(train.fit_chunk_hybrid(c, b, n, n_model, n_out, 1e-3, 1.0, 0.0, True))
+    finally:
+        _select_solver(prev)
+    a = sym + np.diag(np.r_[np.full(n_model, 1.0), np.full(n, 1e-6)])
+    resid = w @ a.T - bm                                                       # W (C + reg) = B   (C symmetric)
+    berr = np.linalg.norm(resid) / (np.linalg.norm(a) * np.linalg.norm(w) + np.linalg.norm(bm))
+    assert np.all(np.isfinite(w)) and berr <= 1e-14, berr
