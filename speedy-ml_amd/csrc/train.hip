@@ -1866,6 +1866,7 @@ struct LuSys {                 // scratch and streams of one batch of factorisat
     int sg_cus = 0;                // CUs S.sg may use
     bool confined = false;         // the panel stream has the reserved CUs to itself (single solves: see lu_sys_alloc)
     bool sp_masked = false, sg_masked = false;     // created through sml::masked_stream_create
+    bool latency_form = false;     // this call came through sml_train_fit (one system, latency first): see backsub_enqueue
     LuStride ls{};
 };
 
@@ -2018,7 +2019,30 @@ static int lu_trailing(LuSys &S, int nb, long ld, long np, int n_aug, int K0, in
 
 // Back substitution U X = Y on the right-hand-side columns of W (U = the upper triangle of W's rows, from the LU or the Cholesky), on
 // S.sg behind everything S.sp did; right-hand sides in groups of BS_CG * 8 = 136 columns (one group for the shipped 132 / 136 outputs).
-static int backsub_enqueue(LuSys &S, int nb, int n_aug, int n_out, long ld)
+// L = U^T into the strictly lower triangle of W (free after the Cholesky factorisation: the trailing updates only ever touched
+// col >= row): W[c][r] = W[r][c] for r < c < n_aug.  The back substitution of a BATCH reads U(rows above, block) through it as the
+// row-contiguous operand of the LDS-DMA GEMM.  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void k_chol_mirror_u(double *__restrict__ w, long ld, int n_aug, LuStride ls)
+{
+    if (blockIdx.y > blockIdx.x) return;                     // tile (row block by, column block bx) of the upper triangle
+    w += ls.w * blockIdx.z;
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < n_aug && c < n_aug) ? w[(long)r * ld + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;           // element (row c, column r) of the lower triangle
+        if (c < n_aug && r < c) w[(long)c * ld + r] = t[tx][ty + 8 * i];
+    }
+}
+
+static int backsub_enqueue(LuSys &S, int nb, int n_aug, int n_out, long ld, bool chol = false)
 {
     const LuStride ls = S.ls;
     SML_HIP(hipEventRecord(S.ev_panel, S.sp));
@@ -2029,6 +2053,19 @@ static int backsub_enqueue(LuSys &S, int nb, int n_aug, int n_out, long ld)
         SML_HIP(hipFuncSetAttribute((const void *)k_lu_backsub_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bs_lds, TRM_LDS)));
         SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
         bs_attr = true;
+    }
+    static const int far_env = getenv("SML_CHOL_BACKSUB_GEMM") ? atoi(getenv("SML_CHOL_BACKSUB_GEMM")) : -1;
+    static const int far_half_env = getenv("SML_CHOL_BACKSUB_HALF") ? atoi(getenv("SML_CHOL_BACKSUB_HALF")) : 0;
+    static const int two_env = getenv("SML_CHOL_BACKSUB_2S") ? atoi(getenv("SML_CHOL_BACKSUB_2S")) : 1;
+    // The far rows' update after a Cholesky: a product on the matrix cores for everything that came through sml_train_fit_batched (any
+    // count: one arithmetic, so a queue that trains in groups of 1 or 64 gets the same bits); sml_train_fit, the one-system latency
+    // form, keeps the launch that solves a block beside the vector-FMA update of the far rows (7.1 against 7.7 ms; its W_out differs
+    // from the batched form's in the last bits, both at a backward error of 3-4e-17).
+    const bool far_gemm = chol && (far_env >= 0 ? far_env != 0 : !S.latency_form), far_half = far_half_env != 0;
+    if (far_gemm) {
+        const int nt = (n_aug + 31) / 32;
+        hipLaunchKernelGGL(k_chol_mirror_u, dim3(nt, nt, nb), dim3(256), 0, S.sg, S.w, ld, n_aug, ls);
+        SML_HIP(hipGetLastError());
     }
     for (int r0 = 0; r0 < n_out; r0 += BS_CG * 8) {
         const int nr = std::min(BS_CG * 8, n_out - r0), rhs0 = n_aug + r0;
@@ -2045,7 +2082,25 @@ static int backsub_enqueue(LuSys &S, int nb, int n_aug, int n_out, long ld)
             const int Kn = K0 - LU_NBO;
             hipLaunchKernelGGL(k_lu_backsub_near, dim3(LU_NBO / BN_ROWS, (nr + BN_COLS - 1) / BN_COLS, nb), dim3(256), 0, S.sg, S.w + rhs0, S.w, ld, K0,
                                std::min(LU_NBO, n_aug - K0), nr, Kn, ls);
-            if (Kn > 0) {
+            if (Kn > 0 && far_gemm) {
+                // the block at Kn is solved by its own launch and the rows above it get the block at K0's update as a product on the
+                // matrix cores (U through its mirror image below the diagonal) instead of vector FMAs in the same launch (16 systems:
+                // 253 us per step) -- on S.sp, beside the solve: they touch different rows
+                const int nbu = std::min(LU_NBO, n_aug - K0);
+                hipStream_t fst = two_env ? S.sp : S.sg;
+                if (two_env) {
+                    SML_HIP(hipEventRecord(S.ev_strip, S.sg));
+                    SML_HIP(hipStreamWaitEvent(S.sp, S.ev_strip, 0));
+                }
+                int rcg = gemm_nt(S.w + (long)K0 * ld + rhs0, ld, S.w + (long)K0 * ld, ld, S.w + rhs0, ld, nr, Kn, nbu, -1.0, 0, fst, lu_dma(), /*padded=*/true, nb,
+                                  GemmBatch{S.ls.w, S.ls.w, S.ls.w}, far_half);
+                if (rcg) return rcg;
+                solve_block(Kn);
+                if (two_env) {
+                    SML_HIP(hipEventRecord(S.ev_panel, S.sp));
+                    SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
+                }
+            } else if (Kn > 0) {
                 const int groups = (Kn + BS_ROWS - 1) / BS_ROWS;
                 const int nwu = nb == 1 ? std::min(groups, std::max(1, S.sg_cus - ntm)) : groups;
                 hipLaunchKernelGGL(k_lu_backsub_step, dim3(ntm + nwu, nb), dim3(TRL_T), std::max(bs_lds, TRM_LDS), S.sg, S.w, ld, rhs0, nr, Kn, LU_NBO, K0,
@@ -2235,7 +2290,7 @@ static int chol_enqueue(double *const *c, const double *const *b, int first, int
     SML_HIP(hipEventRecord(S.ev_panel, S.sp));
     SML_HIP(hipStreamWaitEvent(S.sg, S.ev_panel, 0));
     if (fused) hipLaunchKernelGGL(k_chol_diag_to_w, dim3((unsigned)(((long)n_aug * LU_NBO + 255) / 256), nb), dim3(256), 0, S.sg, S.p[0], S.w, ld, n_aug, ls);
-    if ((rc = backsub_enqueue(S, nb, n_aug, n_out, ld))) return rc;
+    if ((rc = backsub_enqueue(S, nb, n_aug, n_out, ld, true))) return rc;
     const long tw = (long)n_aug * n_out;
     hipLaunchKernelGGL(k_extract_wout, dim3((unsigned)((tw + 255) / 256), nb), dim3(256), 0, S.sg, S.w, ld, S.wout_list, n_aug, n_out, ls);
     SML_HIP(hipGetLastError());
@@ -2282,7 +2337,7 @@ int sml_train_select_solver(int solver)
 }
 
 static int fit_run(bool chol, int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res, double beta_model,
-                   double prior_val, int using_prior, double *const *wout, hipStream_t st, std::vector<int> &hinfo)
+                   double prior_val, int using_prior, double *const *wout, hipStream_t st, std::vector<int> &hinfo, bool latency_form)
 {
     const int n_aug = n + n_model, ncols = n_aug + n_out;
     static const int fit_batch = getenv("SML_FIT_BATCH") ? std::max(1, atoi(getenv("SML_FIT_BATCH"))) : FIT_BATCH;
@@ -2297,6 +2352,7 @@ static int fit_run(bool chol, int count, double *const *c, const double *const *
         ws.n_aug = n_aug; ws.ncols = ncols; ws.dev = dev;
     }
     LuSys &S = ws.sys;
+    S.latency_form = latency_form;
     static const bool want_stamps = getenv("SML_LU_STAMP") && atoi(getenv("SML_LU_STAMP"));
     if (want_stamps && !g_lu_stamps) {
         SML_HIP(hipMalloc((void **)&g_lu_stamps, sizeof(long long) * 32 * LU_STAMP_LEAVES));
@@ -2334,8 +2390,8 @@ static int fit_run(bool chol, int count, double *const *c, const double *const *
     return SML_OK;
 }
 
-int sml_train_fit_batched(int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res,
-                          double beta_model, double prior_val, int using_prior, double *const *wout, void *stream)
+static int fit_systems(int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res,
+                       double beta_model, double prior_val, int using_prior, double *const *wout, void *stream, bool latency_form)
 {
     SML_REQUIRE(count > 0 && c && b && wout && n > 0 && n_model >= 0 && n_out > 0, "sml_train_fit_batched: bad arguments");
     for (int i = 0; i < count; ++i) SML_REQUIRE(c[i] && b[i] && wout[i], "sml_train_fit_batched: null system %d", i);
@@ -2345,7 +2401,7 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
     std::vector<int> hinfo;
     int rc;
     if (solver != 1) {
-        if ((rc = fit_run(true, count, c, b, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, st, hinfo))) return rc;
+        if ((rc = fit_run(true, count, c, b, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, st, hinfo, latency_form))) return rc;
         std::vector<int> redo;
         for (int i = 0; i < count; ++i)
             if (hinfo[i]) redo.push_back(i);
@@ -2357,15 +2413,21 @@ int sml_train_fit_batched(int count, double *const *c, const double *const *b, i
         std::vector<const double *> b2;
         for (int i : redo) { c2.push_back(c[i]); b2.push_back(b[i]); w2.push_back(wout[i]); }
         std::vector<int> info2;
-        if ((rc = fit_run(false, (int)redo.size(), c2.data(), b2.data(), n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, w2.data(), st, info2))) return rc;
+        if ((rc = fit_run(false, (int)redo.size(), c2.data(), b2.data(), n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, w2.data(), st, info2, latency_form))) return rc;
         for (size_t t = 0; t < redo.size(); ++t)
             if (info2[t]) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", redo[t], info2[t], info2[t], info2[t]);
         return SML_OK;
     }
-    if ((rc = fit_run(false, count, c, b, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, st, hinfo))) return rc;
+    if ((rc = fit_run(false, count, c, b, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, st, hinfo, latency_form))) return rc;
     for (int i = 0; i < count; ++i)
         if (hinfo[i]) return sml::fail(SML_ERR_NUMERIC, "sml_train_fit: system %d: U(%d,%d) is exactly zero; the factorisation is singular (dgesv info=%d)", i, hinfo[i], hinfo[i], hinfo[i]);
     return SML_OK;
+}
+
+int sml_train_fit_batched(int count, double *const *c, const double *const *b, int n, int n_model, int n_out, double beta_res,
+                          double beta_model, double prior_val, int using_prior, double *const *wout, void *stream)
+{
+    return fit_systems(count, c, b, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, wout, stream, /*latency_form=*/false);
 }
 
 int sml_train_fit(double *c, const double *b, int n, int n_model, int n_out, double beta_res, double beta_model,
@@ -2375,7 +2437,7 @@ int sml_train_fit(double *c, const double *b, int n, int n_model, int n_out, dou
     double *cc[1] = {c};
     const double *bb[1] = {b};
     double *ww[1] = {wout};
-    return sml_train_fit_batched(1, cc, bb, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, ww, stream);
+    return fit_systems(1, cc, bb, n, n_model, n_out, beta_res, beta_model, prior_val, using_prior, ww, stream, /*latency_form=*/true);
 }
 
 }  // extern "C"
