@@ -2244,7 +2244,12 @@ static int chol_enqueue(double *const *c, const double *const *b, int first, int
     // per GROUP of `grp` panels, at K = 128 grp, on S.sg: a 128-deep update reads and writes all of C for 128 columns' worth of
     // flops (half of either roof), two panels per pass halve that traffic.  The group's update starts with the `grp` block rows the
     // next group's S.sp updates touch; S.sp waits for that part only (ev_strip), the rows below were last written by S.sg, in order.
-    static const int grp = getenv("SML_CHOL_GROUP") ? std::max(1, atoi(getenv("SML_CHOL_GROUP"))) : 1;     // (measured: single 7.05 / 7.33 / 7.69 / 7.94 ms at 1 / 2 / 3 / 4, 16 in lockstep 3.16 / 3.20 ms per system at 1 / 2)
+    // Measured: one system (sml_train_fit) 7.05 / 7.33 / 7.69 / 7.94 ms at grp = 1 / 2 / 3 / 4 -- its chain is what it waits for, and the
+    // chain's part of a grouped update still runs per panel; 16 in lockstep 2.83 / 2.54 / 2.45 / 2.49 / 2.54 / 2.61 ms per system at
+    // 1 / 2 / 3 / 4 / 5 / 8, 8 in lockstep 3.27 / 3.03 at 1 / 3 (at K = 128 a trailing update sits on the ridge between the two roofs: 11
+    // flop per byte of C).  Everything that comes through sml_train_fit_batched uses 3 whatever its count (one arithmetic).
+    static const int grp_env = getenv("SML_CHOL_GROUP") ? std::max(1, atoi(getenv("SML_CHOL_GROUP"))) : 0;
+    const int grp = grp_env ? grp_env : S.latency_form ? 1 : 3;
     // One system: the fused panel kernel (every workgroup repeats the diagonal block's factorisation: one launch less in the chain).
     // A batch: the diagonal blocks alone (one workgroup per system) and the MFMA solve as a second launch -- 93 x nb workgroups that
     // each occupy a CU for the whole factorisation would take the chip from the trailing updates the batch is there to fill it with
