@@ -1217,8 +1217,8 @@ __device__ __forceinline__ void lu_trsm_mfma_body(const double *__restrict__ tri
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_lu_trsm_mfma(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
+template <int MODE, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void k_lu_trsm_mfma(const double *__restrict__ tri, long tri_ld_k, long tri_ld_i, double *__restrict__ w, long ld, int K0,
                                                        int nbp, int c0, int ncols, const int *__restrict__ ipiv, const int *__restrict__ src, LuStride ls,
                                                        long tri_stride, const double *__restrict__ minv)
 {
@@ -2225,6 +2225,7 @@ static int chol_enqueue(double *const *c, const double *const *b, int first, int
     static bool attr = false;
     if (!attr) {
         SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
+        SML_HIP(hipFuncSetAttribute((const void *)k_lu_trsm_mfma<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRM_LDS));
         attr = true;
     }
     SML_HIP(hipMemsetAsync(S.info, 0, sizeof(int) * nb, S.sg));
@@ -2264,6 +2265,13 @@ static int chol_enqueue(double *const *c, const double *const *b, int first, int
         else {
             // (a launch of the diagonal block alone: ncols = c0 leaves the other wavefronts without columns)
             hipLaunchKernelGGL(k_chol_panel, dim3(1, nb), dim3(CP_T), 0, S.sp, S.w, ld, K0, nbp, c0, S.p[0], S.info, ls, 1, S.p[1]);
+            // (512 threads: the triangle's 136 KB of LDS allow one workgroup per CU, so eight wavefronts give every SIMD two dependent MFMA
+            //  chains to interleave; 16 / 8 in lockstep 2.43 -> 2.40 / 2.92 -> 2.86 ms per system.  SML_CHOL_TRSM_T=256: four wavefronts)
+            static const int trsm_t = getenv("SML_CHOL_TRSM_T") ? atoi(getenv("SML_CHOL_TRSM_T")) : 512;
+            if (trsm_t == 512)
+                hipLaunchKernelGGL((k_lu_trsm_mfma<2, 512>), dim3((ncols - c0 + 127) / 128, nb), dim3(512), TRM_LDS, S.sp, S.w + (long)K0 * ld + K0, ld, 1L, S.w, ld, K0, nbp,
+                                   c0, ncols, (const int *)nullptr, (const int *)nullptr, ls, ls.w, (const double *)S.p[1]);
+            else
             hipLaunchKernelGGL(k_lu_trsm_mfma<2>, dim3((ncols - c0 + 63) / 64, nb), dim3(256), TRM_LDS, S.sp, S.w + (long)K0 * ld + K0, ld, 1L, S.w, ld, K0, nbp, c0, ncols,
                                (const int *)nullptr, (const int *)nullptr, ls, ls.w, (const double *)S.p[1]);
         }
