@@ -48,6 +48,12 @@ def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, 
     the synthetic climate (+-5 % per region), so closed-loop runs stay on physical states; False = random W_out/statistics."""
     bank = ReservoirBank(len(regions))
     base, sizes, keep = {}, {}, {}
+    # the seed of a size class is its position in the order of first appearance over ALL regions, so that a rank holding any subset
+    # builds the reservoirs the single-rank run builds
+    class_index = {}
+    for r in range(NREG):
+        sz = domain.allocate_res_sizes(domain.initializedomain(NREG, r), sst_bool_input=classes[r][1])
+        class_index.setdefault(sz.reservoir_numinputs, len(class_index))
     for slot, r in enumerate(regions):
         pole, sst = classes[r]
         g = domain.initializedomain(NREG, r)
@@ -58,7 +64,7 @@ def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, 
         if key not in base:
             # ml_only: chunk_size_speedy = 0 (predict_ml, src/mod_reservoir.f90:1491-1535): W_out acts on the reservoir state alone
             b = make_reservoir(n=n, d=d, n_model=0 if ml_only else s.chunk_size_speedy, n_out=s.chunk_size_prediction,
-                               seed=seed + len(base), dense_win=False, passthrough=physical and not ml_only)
+                               seed=seed + class_index[d], dense_win=False, passthrough=physical and not ml_only)
             b.win_rows = np.arange(1, n + 1, dtype=np.int32)
             b.win_cols = (np.arange(n, dtype=np.int32) // b.win_q + 1).astype(np.int32)
             base[key] = b
@@ -294,6 +300,10 @@ class HybridRank:
         max_out = max(s.chunk_size_prediction for s in sizes)
         self.slab_bank = ReservoirBank(len(self.regions), max_d=max_d, max_n_model=1, max_n_out=max_out)
         base = {}
+        class_index = {}                                        # (as in build_bank: first appearance over ALL regions with a slab model)
+        for r in range(NREG):
+            if classes[r][1]:
+                class_index.setdefault(slab_sizes(domain.initializedomain(NREG, r)).reservoir_numinputs, len(class_index))
         for slot, r in enumerate(self.regions):
             if not sea_slot[slot]:
                 continue
@@ -301,7 +311,7 @@ class HybridRank:
             d = s.reservoir_numinputs
             n = s.n if n_override is None else n_override * d
             if (n, d) not in base:
-                b = make_reservoir(n=n, d=d, n_model=0, n_out=s.chunk_size_prediction, seed=seed + 500 + len(base), deg=6, m=4000,
+                b = make_reservoir(n=n, d=d, n_model=0, n_out=s.chunk_size_prediction, seed=seed + 500 + class_index[d], deg=6, m=4000,
                                    radius=SLAB_RADIUS, sigma=SLAB_SIGMA, dense_win=False)
                 if physical:
                     b.wout *= 1e-2          # small anomalies around the region's mean SST
