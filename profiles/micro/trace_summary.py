@@ -5,6 +5,10 @@ tr = list(csv.DictReader(open(sys.argv[1])))
 nshow = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 idx = [i for i, r in enumerate(tr) if 'k_build_system' in r['Kernel_Name']]
 seg = tr[idx[-1]:]
+# the solve ends with its last own kernel (what follows in the trace is the script's residual check)
+own = ('k_extract_wout', 'k_symmetrize', 'k_lu_', 'k_chol', 'k_gemm_nt_dma', 'k_gemm_acc', 'k_build_system')
+last = max(i for i, r in enumerate(seg) if any(k in r['Kernel_Name'] for k in own))
+seg = seg[:last + 1]
 t0 = int(seg[0]['Start_Timestamp'])
 end = max(int(r['End_Timestamp']) for r in seg)
 print(f"last solve: {len(seg)} launches, span {(end - t0) / 1e6:.3f} ms")
