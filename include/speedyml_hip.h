@@ -34,6 +34,8 @@ const char *sml_last_error(void);
 int sml_version(void);
 /* number of visible HIP devices (0 on a CPU-only box; never initialises a context) */
 int sml_device_count(void);
+/* selects the GPU of this process.  One process drives one GPU (one rank per GPU): a later call with another ordinal returns
+ * SML_ERR_STATE -- the library's cached streams, launch attributes and solver workspaces belong to the first device. */
 int sml_set_device(int ordinal);
 /* device memory for hosts without a HIP binding of their own (the Fortran drop-ins of speedy-ml_amd/fortran/): hipMalloc,
  * hipFree, hipMemset(0), synchronous hipMemcpy in either direction */

@@ -726,7 +726,13 @@ int sml_device_count(void)
 
 int sml_set_device(int ordinal)
 {
+    // One process drives ONE GPU (one rank per GPU): the library's cached streams, launch attributes and solver workspaces belong to
+    // the device that was current when they were made.  A second device in the same process is refused rather than served wrongly.
+    static int chosen = -1;
+    if (chosen >= 0 && chosen != ordinal)
+        return sml::fail(SML_ERR_STATE, "sml_set_device(%d): this process already drives device %d (one process per GPU)", ordinal, chosen);
     SML_HIP(hipSetDevice(ordinal));
+    chosen = ordinal;
     return SML_OK;
 }
 
