@@ -457,7 +457,7 @@ def main():
             "data": "synthetic",
             "config": model.describe(),
             "per_rank": ranks,
-            "roofline": {"bound": "hbm", "kernel": "k_readout<17> (W_out [local_model;x~] GEMV, all resident reservoirs)",
+            "roofline": {"bound": "hbm", "kernel": "k_readout<4,512> (W_out [local_model;x~] GEMV, all resident reservoirs)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": ro_b, "avg_launch_ms": ro_ms,

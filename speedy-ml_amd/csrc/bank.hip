@@ -586,19 +586,19 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
 
 int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream_t st)
 {
-    // measured on MI355X (1152 reservoirs, event-timed): <17,64> 1.40 ms, <17,128> 1.46, <17,256> 1.58, <8,128> 1.57,
-    // <17,512> 1.89, <34,256> 1.84, <34,128> 2.03 ms; non-temporal vs plain loads within 1 %.  One wavefront per workgroup wins.
-    // With few resident reservoirs (a rank of an 8-GPU run holds 144) one wavefront per 17 rows leaves the chip short of
-    // loads in flight (144 reservoirs: 0.44 ms = 2.1 TB/s); the columns of a row group are then split over 2 / 4 / 8 wavefronts.
+    // <rows per workgroup, threads>, non-temporal 16-byte loads.  Round 3 (profiles/micro/sweep_readout_variants.sh, event-timed, ms at
+    // 1152 / 576 / 288 / 144 resident reservoirs): <4,512> 1.071 / 0.550 / 0.283 / 0.148 -- the default at every size, so a rank of
+    // an N-GPU run sums its rows exactly as the single-GPU run does -- against <17,64> 1.141-1.157 / 0.614 / 0.307 / 0.163 (the default
+    // of rounds 1-2), <8,64> 1.143-1.152 / 0.600 / 0.308 / 0.157, <4,1024> 1.077 / 0.560 / 0.284 / 0.149, <8,512> 1.110, <17,512> 1.104,
+    // <8,256> 1.117, <4,256> 1.107, <4,384> 1.079, <4,768> 1.083, <6,512> 1.082, <2,512> 1.142, <2,1024> 1.278, <17,1024> 1.167,
+    // <34,256> 1.276; plain instead of non-temporal loads <4,512> 1.186.  A read-only stream of the same 7.5 GB reaches 6.85-7.15 TB/s
+    // on this part (profiles/micro/read_bw_ceiling.hip); <4,512> is at 7.03.
+    // (Round 1 found the opposite order -- one wavefront per workgroup best, <17,256> 1.58 ms -- while every workgroup still copied
+    //  the reservoir descriptor through scratch and the rows started 32 bytes off a cache line; both were fixed in round 2 without
+    //  the sweep being repeated.)
     static const int forced = getenv("SML_RO_VARIANT") ? atoi(getenv("SML_RO_VARIANT")) : -1;
     const int nres8 = ((res_end - res_begin + 7) / 8) * 8;
-    int variant = forced;
-    if (variant < 0) {
-        const int groups = nres8 * ((b->max_n_out_loaded + 16) / 17);       // workgroups of the one-wavefront form
-        // (after the row stride was padded to whole lines: <8,64> matches <17,64> at 576-1152 reservoirs within the box-to-box noise
-        // and beats the column-split forms below that: 288 reservoirs 0.333 ms, 144 reservoirs 0.172-0.180 against 0.191 ms)
-        variant = groups >= 4608 ? 7 : 11;
-    }
+    const int variant = forced >= 0 ? forced : 18;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = b->timing && !(flags & 4);       // the small physics-model block (part 2) is not the roofline kernel
     if (flags & (8 | 16)) {
@@ -651,6 +651,19 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
     case 14: RO_LAUNCH(4, 64, true) break;
     case 15: RO_LAUNCH(8, 64, false) break;
     case 16: RO_LAUNCH(6, 64, true) break;
+    case 17: RO_LAUNCH(8, 512, true) break;
+    case 18: RO_LAUNCH(4, 512, true) break;
+    case 19: RO_LAUNCH(4, 1024, true) break;
+    case 20: RO_LAUNCH(8, 1024, true) break;
+    case 21: RO_LAUNCH(17, 1024, true) break;
+    case 22: RO_LAUNCH(4, 256, true) break;
+    case 23: RO_LAUNCH(2, 1024, true) break;
+    case 24: RO_LAUNCH(4, 768, true) break;
+    case 25: RO_LAUNCH(6, 512, true) break;
+    case 26: RO_LAUNCH(2, 512, true) break;
+    case 27: RO_LAUNCH(4, 384, true) break;
+    case 28: RO_LAUNCH(8, 384, true) break;
+    case 29: RO_LAUNCH(4, 512, false) break;
     case 0: RO_LAUNCH(RO_ROWS, 256, true) break;
     default: RO_LAUNCH(RO_ROWS, 64, true) break;
     }

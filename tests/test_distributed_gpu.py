@@ -182,9 +182,6 @@ def _engine_worker(rank, world, name, out_dir, slab):
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.join(root, "tests"))
     os.environ["SML_COMM_TRANSPORT"] = "shm"
-    # (the readout picks its rows-per-workgroup form by the number of resident reservoirs -- 8 rows below 576 residents, 17 from there
-    #  on -- and the two associate a row's partial sums differently: pin the single-rank form so that five ranks can be compared bit for bit)
-    os.environ["SML_RO_VARIANT"] = "7"
     from __graft_entry__ import load_package
     load_package()
     from speedy_ml_amd import _lib, domain, hybrid, synth
