@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trainprof_${T
 for solver in chol lu; do
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fittrace_${solver}_${TAG} -- python3 profiles/micro/fit_solvers.py ${solver} 3 \
         > gpurun_out/fittrace_${solver}_${TAG}.log 2> gpurun_out/fittrace_${solver}_${TAG}.err
-    f=$(ls gpurun_out/fittrace_${solver}_${TAG}/*/*kernel_trace.csv | head -1)
+    f=$(ls -t gpurun_out/fittrace_${solver}_${TAG}/*/*kernel_trace.csv | head -1)
     {
         echo "== single ridge solve, 5892 x 5892 + 136 right-hand sides, solver = ${solver} (rocprofv3 --kernel-trace of profiles/micro/fit_solvers.py ${solver} 3; the last solve) =="
         cat gpurun_out/fittrace_${solver}_${TAG}.log

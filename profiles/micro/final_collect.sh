@@ -1,4 +1,8 @@
-timeout -k 10 600 python bench.py > gpurun_out/bench_r3c.json 2> gpurun_out/bench_r3c.err; tail -c 300 gpurun_out/bench_r3c.err
+#!/usr/bin/env bash
+# End-of-round refresh of the committed evidence (run from the repo root through gpurun): the default bench line, the hybrid step's
+# kernel stats + FETCH/WRITE passes (collect.sh), the SPEEDY-window counter passes, the training kernels' stats and timelines.
+TAG="${1:-r3}"
+timeout -k 10 600 python bench.py > gpurun_out/bench_${TAG}_final.json 2> gpurun_out/bench_${TAG}_final.err
 python -c "
-import json; d=json.loads(open('gpurun_out/bench_r3c.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac']); t=d['training']; r=t['ridge_solve_5892']; print(r['ms'], r['frac'], r['batched8'], r['batched16']); print(t['train_pass']); print(t['gram_m2920'], t['gram_m98'])" && timeout -k 10 300 bash profiles/collect_train.sh r3 && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/ridge_pmc_r3b -- python3 profiles/micro/fit_batch16.py > gpurun_out/ridge_pmc_r3b.log 2>&1
+import json; d=json.loads(open('gpurun_out/bench_${TAG}_final.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms']); print(d['per_rank'][0])" && timeout -k 10 500 bash profiles/collect.sh ${TAG} && timeout -k 10 300 bash profiles/collect_speedy_pmc.sh ${TAG} && timeout -k 10 300 bash profiles/collect_train.sh ${TAG}
 echo done
