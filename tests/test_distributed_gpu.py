@@ -208,7 +208,7 @@ def _engine_worker(rank, world, name, out_dir, slab):
         check(L.sml_comm_destroy(comm))
 
 
-@pytest.mark.parametrize("world,slab", [(2, False), (2, True), (5, False), (5, True)])
+@pytest.mark.parametrize("world,slab", [(2, False), (2, True), (5, True)])
 def test_native_engine_ranks_equal_one_rank(tmp_path, world, slab):
     """The C-ABI's own rank exchange inside the engine (sml_hybrid_set_comm -> sml_comm_allgather_outvec, for the atmosphere and
     the slab bank): `world` processes, each with its share of processor_decomposition and its own engine, reproduce the single-rank
@@ -216,6 +216,9 @@ def test_native_engine_ranks_equal_one_rank(tmp_path, world, slab):
     sml_comm_unpack_regions are on the path.  All ranks share ONE GPU: the communicator is the host-staged rehearsal transport
     (SML_COMM_TRANSPORT=shm); with one GPU per rank the same calls run over RCCL."""
     import torch.multiprocessing as mp
+    # (five ranks + this process = the six GPU processes a box allows at once: SML_TEST_MAX_GPU_PROCS lowers the cap on a stricter pool)
+    if world + 1 > int(os.environ.get("SML_TEST_MAX_GPU_PROCS", "6")):
+        pytest.skip("more GPU processes than SML_TEST_MAX_GPU_PROCS allows")
     name = f"sml_test_{os.getpid()}_{world}_{int(slab)}"
     mp.spawn(_engine_worker, args=(world, name, str(tmp_path), slab), nprocs=world, join=True)
     _engine_worker(0, 1, name, str(tmp_path), slab)
