@@ -131,6 +131,13 @@ module mod_utilities
     integer :: currentyear, currentmonth, currentday, currenthour
   end type calendar_type
 
+  type opened_netcdf_type                                         ! src/mod_utilities.f90:631-638 (an argument type of read_era_netcdf_opened)
+    logical :: is_opened
+    logical :: is_closed
+    integer :: ncid
+    character(len=:), allocatable :: filename
+  end type opened_netcdf_type
+
   type mpi_type
     integer :: ierr, numprocs, proc_num
     logical :: is_root = .false., is_serial = .false.

@@ -90,7 +90,7 @@ contains
   ! The engine is built at the first exchange: by then every reservoir of the rank is resident (speedyml_state).  Every forecast
   ! (timestep == 1) starts from the analysis of its own start hour: traininglength + prediction marker + synclength.
   subroutine start_forecast(res, ocean_model)
-    use speedy_res_interface, only : hybrid_boundary_fields
+    use speedyml_data_source, only : hybrid_boundary_fields
     type(main_type), intent(inout) :: res
     logical, intent(in) :: ocean_model
     real(kind=dp), allocatable :: g(:), phi0(:,:), tisr(:,:,:), fmask(:,:), tland(:,:), swav(:,:), alb_l(:,:), alb_s(:,:), albsfc(:,:), snowc(:,:)

@@ -272,7 +272,7 @@ contains
 
   ! G's TISR segment after step 1 of a forecast = the slice get_tisr_by_date(timestep - 1) picks for that forecast's start hour
   subroutine tisr_check(prediction_num, g, nfail)
-    use speedy_res_interface, only : field2d
+    use speedyml_data_source, only : field2d
     integer, intent(in) :: prediction_num
     real(kind=dp), intent(in) :: g(:)
     integer, intent(inout) :: nfail

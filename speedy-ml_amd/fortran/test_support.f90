@@ -1,11 +1,12 @@
 ! Test support for the module-API drop-ins: synthetic stand-ins of exactly the reference procedures the drop-ins call for DATA --
-!   speedy_res_interface :: read_era, read_model_states   (src/speedy_res_interface.f90: ERA5 / SPEEDY NetCDF readers)
+!   speedyml_data_source :: source_read_era, source_read_model_states -- what speedy_res_interface::read_era / read_model_states
+!                           (src/speedy_res_interface.f90:439-723: ERA5 / SPEEDY NetCDF readers) forward to in the drop-in
 !   mod_io               :: read_trained_res, read_trained_ocean_res, read_3d_file_parallel, write_netcdf_2d_non_met_data,
 !                           write_netcdf_1d_non_met_data_int / _real (src/mod_io.f90)
 ! -- with the reference's argument lists, plus hybrid_boundary_fields, the one procedure a host adds to hand SPEEDY's boundary
 ! arrays to the engine (INTEGRATION.md).  A maintainer links the reference's modules instead of this file.  The fields are
 ! deterministic, smooth and ERA5-shaped (SURVEY 8d); nothing here is part of the product.
-module speedy_res_interface
+module speedyml_data_source
   use iso_c_binding
   use mod_utilities, only : dp, reservoir_type, grid_type, model_parameters_type, era_data_type, speedy_data_type, xgrid, ygrid, zgrid
   use mod_calendar
@@ -68,10 +69,10 @@ contains
   end subroutine
 
   ! read_era (src/speedy_res_interface.f90): the region's INPUT patch, hourly, periodic in x
-  subroutine read_era(reservoir, grid, model_parameters, start_year, end_year, era_data, timestep_arg)
+  subroutine source_read_era(reservoir, grid, model_parameters, start_year, end_year, era_data, timestep_arg)
     type(reservoir_type), intent(inout) :: reservoir
     type(grid_type), intent(inout) :: grid
-    type(model_parameters_type), intent(inout) :: model_parameters
+    type(model_parameters_type), intent(in) :: model_parameters
     integer, intent(in) :: start_year, end_year
     type(era_data_type), intent(inout) :: era_data
     integer, intent(in), optional :: timestep_arg
@@ -103,10 +104,10 @@ contains
   end subroutine
 
   ! read_model_states: SPEEDY's forecast of the region's RES patch (an imperfect copy of the truth)
-  subroutine read_model_states(reservoir, grid, model_parameters, start_year, end_year, speedy_data, timestep_arg)
+  subroutine source_read_model_states(reservoir, grid, model_parameters, start_year, end_year, speedy_data, timestep_arg)
     type(reservoir_type), intent(inout) :: reservoir
     type(grid_type), intent(inout) :: grid
-    type(model_parameters_type), intent(inout) :: model_parameters
+    type(model_parameters_type), intent(in) :: model_parameters
     integer, intent(in) :: start_year, end_year
     type(speedy_data_type), intent(inout) :: speedy_data
     integer, intent(in), optional :: timestep_arg
@@ -173,13 +174,7 @@ contains
       end do
     end do
   end subroutine
-
-  subroutine startspeedy(model_parameters, grid, runspeedy)
-    type(model_parameters_type), intent(inout) :: model_parameters
-    type(grid_type), intent(inout) :: grid
-    logical, intent(in) :: runspeedy
-  end subroutine
-end module speedy_res_interface
+end module speedyml_data_source
 
 module mod_io
   use iso_c_binding

@@ -51,3 +51,21 @@ def test_every_name_the_driver_imports_is_exported():
             assert re.search(r"\b" + re.escape(name) + r"\b", body), f"{module} does not export {name}"
             checked += 1
     assert checked >= 36          # 8 + 8 + 8 + 1 + 3 + 8 names in the six `only` lists
+
+
+@needs_reference
+def test_speedy_res_interface_exports_what_the_reference_tree_imports():
+    """every `use speedy_res_interface, only : ...` of the reference tree (program main, dyn_stloop, ppo_iogrid, mod_reservoir,
+    mod_slab_ocean_reservoir) against the drop-in's module: startspeedy, getspeedyvariable, write_restart_new,
+    truncate_letkf_code_version, read_era, read_model_states (+ read_era_netcdf_opened)"""
+    import glob
+    subprocess.check_call(["make", "-C", FDIR, "api"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    body = open(os.path.join(FDIR, "api_build", "speedy_res_interface.mod"), errors="replace").read().lower()
+    wanted = {"read_era_netcdf_opened"}
+    for f in glob.glob("/root/reference/src/*.f90"):
+        text = open(f, errors="replace").read()
+        for names in re.findall(r"^\s*use\s+speedy_res_interface\s*,\s*only\s*:\s*((?:.*&\s*\n)*.*)$", text, flags=re.M | re.I):
+            wanted |= {n.strip().lower() for n in names.replace("&", " ").replace("\n", " ").split(",") if n.strip()}
+    assert {"startspeedy", "getspeedyvariable", "write_restart_new", "truncate_letkf_code_version", "read_era", "read_model_states"} <= wanted
+    for name in sorted(wanted):
+        assert re.search(r"\b" + re.escape(name) + r"\b", body), f"speedy_res_interface does not export {name}"
