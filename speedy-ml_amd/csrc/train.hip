@@ -1443,12 +1443,22 @@ __global__ __launch_bounds__(CP_T) void k_chol_panel(double *__restrict__ w, lon
     double a0[NG][4], a1[NG][4];
     {
         const double *bp = w + (long)K0 * ld + K0;
+        // every load is issued unconditionally from a clamped (valid) address and the selection follows: 64 independent loads in
+        // flight per lane instead of loads behind per-lane conditions
+        const int cmax = ncols - 1 - K0, c0c = min(col0, cmax), c1c = min(max(col1, 0), cmax);
+        double v0[NQ], v1[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const long ro = (long)min(4 * q + ri, nb - 1) * ld;
+            v0[q] = bp[ro + c0c];
+            v1[q] = diag ? bp[ro + c1c] : 0.0;                                 // (wave-uniform)
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int row = 4 * q + ri;
             // (rows and columns past a short last block: the identity; below the diagonal: never used, kept finite)
-            a0[q >> 2][q & 3] = (row < nb && ok0 && (!diag || row <= col0)) ? bp[(long)row * ld + col0] : ((diag && row == col0) ? 1.0 : 0.0);
-            a1[q >> 2][q & 3] = (row < nb && ok1 && row <= col1) ? bp[(long)row * ld + col1] : ((diag && row == col1) ? 1.0 : 0.0);
+            a0[q >> 2][q & 3] = (row < nb && ok0 && (!diag || row <= col0)) ? v0[q] : ((diag && row == col0) ? 1.0 : 0.0);
+            a1[q >> 2][q & 3] = (row < nb && ok1 && row <= col1) ? v1[q] : ((diag && row == col1) ? 1.0 : 0.0);
         }
     }
     int bad = 0;
