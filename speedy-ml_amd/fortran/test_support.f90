@@ -56,6 +56,16 @@ contains
     end select
   end function
 
+  ! hours at the end of the returned window that carry data (SML_TEST_ERA_HOURS; 2300 covers the 1440-hour training window of
+  ! test_train_batch, a forecast needs its synchronisation window only)
+  integer function filled_hours()
+    character(len=16) :: v
+    integer :: n, st
+    filled_hours = 2300
+    call get_environment_variable('SML_TEST_ERA_HOURS', v, n, st)
+    if (st == 0 .and. n > 0) read(v(1:n), *) filled_hours
+  end function
+
   subroutine hours_covered(start_year, end_year, nh)
     integer, intent(in) :: start_year, end_year
     integer, intent(out) :: nh
@@ -79,7 +89,7 @@ contains
     integer :: nh, ix, iy, iz, v, h, x, y, h0, hfirst
     call hours_covered(start_year, end_year, nh)
     h0 = 0
-    hfirst = max(1, nh - 2300)                                   ! (earlier hours stay zero: no caller of this test reads them)
+    hfirst = max(1, nh - filled_hours())                         ! (earlier hours stay zero: no caller of this test reads them)
     allocate(era_data%eravariables(4, grid%inputxchunk, grid%inputychunk, grid%inputzchunk, nh), era_data%era_logp(grid%inputxchunk, grid%inputychunk, nh), &
              era_data%era_tisr(grid%inputxchunk, grid%inputychunk, nh), era_data%era_sst(grid%inputxchunk, grid%inputychunk, nh), &
              era_data%era_precip(grid%inputxchunk, grid%inputychunk, nh))
@@ -115,7 +125,7 @@ contains
     call hours_covered(start_year, end_year, nh)
     allocate(speedy_data%speedyvariables(4, grid%resxchunk, grid%resychunk, grid%reszchunk, nh), speedy_data%speedy_logp(grid%resxchunk, grid%resychunk, nh))
     speedy_data%speedyvariables = 0.0_dp; speedy_data%speedy_logp = 0.0_dp
-    do h = max(1, nh - 2300), nh
+    do h = max(1, nh - filled_hours()), nh
       do iy = 1, grid%resychunk
         do ix = 1, grid%resxchunk
           do iz = 1, grid%reszchunk
@@ -181,6 +191,13 @@ module mod_io
   use speedyml_hip
   use mod_utilities, only : dp, reservoir_type, grid_type, model_parameters_type
   implicit none
+  type cached_adjacency
+    integer :: n = 0, k = 0, seed = 0
+    integer(c_int), allocatable :: rows(:), cols(:)
+    real(c_double), allocatable :: vals(:)
+  end type
+  type(cached_adjacency), save :: cache(64)
+  integer, save :: ncached = 0
 contains
 
   ! read_trained_res (src/mod_io.f90:2938-2983): win, wout, rows, cols, vals, mean, std of worker_RRRR_level_L_<trial>.nc -- here a
@@ -206,7 +223,24 @@ contains
     if (allocated(reservoir%win)) deallocate(reservoir%win, reservoir%wout, reservoir%rows, reservoir%cols, reservoir%vals)
     allocate(reservoir%win(s%n, s%reservoir_numinputs), reservoir%wout(s%chunk_size_prediction, s%n + s%chunk_size_speedy), &
              reservoir%rows(s%k), reservoir%cols(s%k), reservoir%vals(s%k))
-    call sml_check(sml_gen_res(s%n, s%k, 0.6_c_double, int(777 + mod(reservoir%assigned_region, 7), c_int64_t), reservoir%rows, reservoir%cols, reservoir%vals, eigs), 'sml_gen_res')
+    ! (28 distinct synthetic adjacency matrices -- 7 seeds x 4 size classes -- for 1152 regions: generated once each)
+    block
+      integer :: c, hit
+      hit = 0
+      do c = 1, ncached
+        if (cache(c)%n == s%n .and. cache(c)%k == s%k .and. cache(c)%seed == 777 + mod(reservoir%assigned_region, 7)) hit = c
+      end do
+      if (hit == 0) then
+        call sml_check(sml_gen_res(s%n, s%k, 0.6_c_double, int(777 + mod(reservoir%assigned_region, 7), c_int64_t), reservoir%rows, reservoir%cols, reservoir%vals, eigs), 'sml_gen_res')
+        if (ncached < size(cache)) then
+          ncached = ncached + 1
+          cache(ncached)%n = s%n; cache(ncached)%k = s%k; cache(ncached)%seed = 777 + mod(reservoir%assigned_region, 7)
+          cache(ncached)%rows = reservoir%rows; cache(ncached)%cols = reservoir%cols; cache(ncached)%vals = reservoir%vals
+        end if
+      else
+        reservoir%rows = cache(hit)%rows; reservoir%cols = cache(hit)%cols; reservoir%vals = cache(hit)%vals
+      end if
+    end block
     q = s%n / s%reservoir_numinputs
     allocate(r(q))
     reservoir%win = 0.0_dp
@@ -267,8 +301,24 @@ contains
     if (allocated(reservoir%win)) deallocate(reservoir%win, reservoir%wout, reservoir%rows, reservoir%cols, reservoir%vals)
     allocate(reservoir%win(s%n, s%reservoir_numinputs), reservoir%wout(s%chunk_size_prediction, s%n), reservoir%rows(s%k), reservoir%cols(s%k), &
              reservoir%vals(s%k))
-    call sml_check(sml_gen_res(s%n, s%k, 0.6_c_double, int(555 + mod(reservoir%assigned_region, 5), c_int64_t), reservoir%rows, reservoir%cols, reservoir%vals, eigs), &
-                   'sml_gen_res')
+    block                                                             ! (cached as in read_trained_res)
+      integer :: c, hit
+      hit = 0
+      do c = 1, ncached
+        if (cache(c)%n == s%n .and. cache(c)%k == s%k .and. cache(c)%seed == 555 + mod(reservoir%assigned_region, 5)) hit = c
+      end do
+      if (hit == 0) then
+        call sml_check(sml_gen_res(s%n, s%k, 0.6_c_double, int(555 + mod(reservoir%assigned_region, 5), c_int64_t), reservoir%rows, reservoir%cols, reservoir%vals, eigs), &
+                       'sml_gen_res')
+        if (ncached < size(cache)) then
+          ncached = ncached + 1
+          cache(ncached)%n = s%n; cache(ncached)%k = s%k; cache(ncached)%seed = 555 + mod(reservoir%assigned_region, 5)
+          cache(ncached)%rows = reservoir%rows; cache(ncached)%cols = reservoir%cols; cache(ncached)%vals = reservoir%vals
+        end if
+      else
+        reservoir%rows = cache(hit)%rows; reservoir%cols = cache(hit)%cols; reservoir%vals = cache(hit)%vals
+      end if
+    end block
     q = s%n / s%reservoir_numinputs
     reservoir%win = 0.0_dp
     do i = 1, s%reservoir_numinputs

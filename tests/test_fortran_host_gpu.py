@@ -58,7 +58,7 @@ def test_fortran_module_api_runs_program_mains_loop(tmp_path):
     behind the per-region predict calls against a per-region predict, the next feedback against the host-side tiling of the global
     state, run_speedy, the batched predict_slab_ml against the slab step written out on the host and its SST in the hybrid state, and
     the TISR slice after the engine's restart for the second forecast."""
-    out = _run("test_main_loop", dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="30", SML_TEST_PREDICTIONS="2",
+    out = _run("test_main_loop", dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="30", SML_TEST_PREDICTIONS="2", SML_TEST_ERA_HOURS="800",
                                       SML_TEST_DUMP=str(tmp_path / "one.bin")))
     assert "main loop parity OK" in out and "slab predict_slab_ml of region" in out
 
@@ -69,7 +69,7 @@ def test_fortran_main_loop_two_ranks_equal_one_rank(tmp_path):
     the engine -- here over the host-staged rehearsal transport, because both ranks share the box's one GPU (with one GPU per rank the
     same calls go over RCCL).  G, F and every region's next feedback / local_model after 3 steps equal the 1-rank run bit for bit."""
     import numpy as np
-    base = dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="3", SML_TEST_PREDICTIONS="1")
+    base = dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="3", SML_TEST_PREDICTIONS="1", SML_TEST_ERA_HOURS="800")
     _run("test_main_loop", dict(base, SML_TEST_DUMP=str(tmp_path / "one.bin")))
     exe = os.path.join(FDIR, "test_main_loop")
     name = f"sml_f90_{os.getpid()}"
