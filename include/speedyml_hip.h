@@ -253,7 +253,11 @@ int sml_comm_create(int nranks, int rank, const char *id128, sml_comm **out);
  * and leaves it in /dev/shm/<name>.id for the others -- what MPI_Bcast does in an MPI build -- then sml_comm_create.
  * SML_COMM_TRANSPORT=shm: a host-staged all-gather through a POSIX shared-memory segment, for REHEARSING the multi-rank path with
  * several ranks on one GPU (RCCL refuses two ranks on one device); never used for numbers.  max_doubles_per_rank bounds one rank's
- * contribution to a collective (shm only; 0 = 512 Ki doubles). */
+ * contribution to a collective (shm only; 0 = 512 Ki doubles).
+ * Leftovers of an earlier run under the same name are never picked up: the id file / segment carries a per-launch token --
+ * SML_COMM_NONCE when the launcher exports one (a job id), else the ranks' common parent process id -- and a peer waits for one with its
+ * own token (SML_COMM_TIMEOUT_S, default 120); rank 0 removes the name as soon as the collective init / first barrier has returned, and
+ * an exit handler removes whatever a dying process had published. */
 int sml_comm_bootstrap(int nranks, int rank, const char *name, uint64_t max_doubles_per_rank, sml_comm **out);
 int sml_comm_destroy(sml_comm *comm);
 int sml_comm_allgather_outvec(sml_comm *comm, sml_bank *bank, int number_of_regions, double *all_outvec_dev, void *stream);
@@ -266,9 +270,12 @@ int sml_comm_unpack_regions(const double *stage_dev, int nranks, int slots_per_r
  * the leapfrog steps of one window with phypar inside grtend, iogrid(31)), get_tisr_by_date, tile + standardise the next feedback /
  * local_model of every reservoir resident in `bank` (slot i holds region_of_slot[i]).  Global state G = grid4d(4,96,48,8) | logp |
  * precip | sst | tisr (SML_G4_OFF ...); F = SPEEDY's forecast in the same layout.
- *   set_orography : phi0(96,48) -> phis, tcorh (src/ini_fordate.f90:72-113)
+ *   set_orography : phi0(96,48) -> phis = trunct(spec(phi0)), phis0 = grid(phis) (src/ini_invars.f90:31-34; get_phis0 returns it for
+ *                   the physics' phis0), tcorh = spec(gamlat phis0) (src/ini_fordate.f90:72-86)
  *   set_tisr_table: full_tisr [8760][48][96] (src/mod_reservoir.f90:890-909) + hours since 1 Jan 1981 00h of the first step
- *   attach_physics: phypar inside every time step with these surface fields ((96,48) each); sst_am = G's SST grid
+ *   attach_physics: phypar inside every time step with these surface fields ((96,48) each); sst_am = G's SST grid.  From then on
+ *                   every window starts with fordate(0) on the device (sml_phys_fordate: tcorh, and qcorh from the hybrid SST;
+ *                   fmask_s = 1 - fmask unless set_fordate_fields gives it; with alb0 / snowd_am / sice_am also the albedos)
  *   initial_inputs: TISR slice 0 into G, feedback and local_model of every slot gathered from G
  *   exchange_and_speedy: all_outvec_dev = region-ordered slab [number_of_regions][max_n_out] after the all-gather, or NULL to take
  *                   the bank's own outvec buffer; leapfrog_steps = 24 for the 6-hour window (< 0: hand-off only)
@@ -285,6 +292,8 @@ int sml_hybrid_set_tisr_table(sml_hybrid *h, const double *tisr_8760x48x96, int 
 int sml_hybrid_attach_physics(sml_hybrid *h, const double *hsg9, const double *radang48, const double *fmask, const double *phis0,
                               const double *tland, const double *swav, const double *alb_l, const double *alb_s, const double *albsfc,
                               const double *snowc, int nstrad);
+int sml_hybrid_get_phis0(sml_hybrid *h, double *phis0_host);
+int sml_hybrid_set_fordate_fields(sml_hybrid *h, const double *fmask_s, const double *alb0, const double *snowd_am, const double *sice_am);
 int sml_hybrid_initial_inputs(sml_hybrid *h, void *stream);
 int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream);
 int sml_hybrid_safe(sml_hybrid *h, int *safe_out);
@@ -421,6 +430,8 @@ int sml_dyn_impint(sml_dyn *dyn, double dt, double alph);
 int sml_dyn_get_table(sml_dyn *dyn, int which, double *out_host, int capacity);
 /* phis (mod_surfcon / mod_dynvar), tcorh, qcorh (mod_hdifcon.f90:19, set by ini_fordate.f90:86,113): spectral [32][62] */
 int sml_dyn_set_boundary(sml_dyn *dyn, const double *phis_dev, const double *tcorh_dev, const double *qcorh_dev, void *stream);
+/* the handle's own device copy, [3][32][62] = phis | tcorh | qcorh, for producers that write it in place (sml_phys_fordate) */
+double *sml_dyn_boundary_dev(sml_dyn *dyn);
 /* For a Fortran host that keeps the prognostic variables in mod_dynvar's arrays (src/mod_dynvar.f90:14-27): the handle owns a
  * device state; *_host copy complex vor/div/t(mx,nx,kx,2), ps(mx,nx,2) and the first tracer tr(mx,nx,kx,2) in and out, and
  * phis/tcorh/qcorh(mx,nx).  Synchronous.  sml_dyn_state_dev returns the device state to pass to step/window. */
@@ -484,6 +495,21 @@ int sml_phys_set_sst_dev(sml_phys *phys, const double *tsea_dev, void *stream);
 /* ... or read in place: later launches take the sea temperature straight from tsea_dev ([48][96] doubles on the device, e.g. the
  * SST segment of the hybrid state), no copy per step.  NULL returns to the handle's own copy. */
 int sml_phys_bind_sst_dev(sml_phys *phys, const double *tsea_dev);
+/* fordate(0)'s per-window work (src/ini_fordate.f90), which the hybrid repeats at the start of every 6-hour window through
+ * agcm_init (src/ini_agcm_init.f90:86) with sst_am = the ML-predicted SST:
+ *   :54-61   snowc, alb_l, alb_s, albsfc from alb0 (mod_surfcon), snowd_am, sice_am -- when those three are given (all or none;
+ *            otherwise the albedos of sml_phys_set_surface stay);
+ *   :72-86   tcorh = spec(gamlat phis0), gamlat = gamma / (1000 g) (setgam :116-136);
+ *   :88-113  qcorh = spec(refrh1 (q_sat(tref, 1) - q_sat(tsfc, psfc))), tsfc = fmask_l stl_am + fmask_s sst_am, tref = tsfc + gamlat phis0,
+ *            psfc = (tsfc / tref)^(1 / (rd gamlat)); psfc_dummy = 1.0 and the absence of trunct as in the reference.
+ * fmask_l, phis0, stl_am, sst_am are the handle's fmask, phis0, tland and (bound) tsea.  set_fordate_fields: host arrays (96,48),
+ * fmask_s = mod_cli_sea's sea fraction (src/ini_inbcon.f90:148-157).  sml_phys_fordate: one grid-point launch + one two-field
+ * spec; corh_spec_dev [2][32][62] receives tcorh | qcorh (e.g. sml_dyn_boundary_dev(dyn) + 32*62). */
+int sml_phys_set_fordate_fields(sml_phys *phys, const double *fmask_s, const double *alb0, const double *snowd_am, const double *sice_am);
+int sml_phys_fordate(sml_phys *phys, sml_spectral *sp, double *corh_spec_dev, void *stream);
+/* host copy of one surface field [48][96]: 0 fmask 1 phis0 2 tland 3 tsea (the handle's own copy) 4 swav 5 alb_l 6 alb_s 7 albsfc
+ * 8 snowc 9 forog; 10, 11 = fordate's grid fields corh (temperature, humidity).  Synchronises. */
+int sml_phys_get_surface(sml_phys *phys, int which, double *out_host);
 /* sol_oz(tyear) (src/phy_radiat.f90:1-83): zonal solar / ozone fields for the day, tyear = fraction of the year */
 int sml_phys_sol_oz(sml_phys *phys, double tyear);
 /* host copies for tests: zonal [6][48] = fsol ozone ozupp zenit stratz sqrt(clat); fband [301][4]; levels [9][9] = sig sigl

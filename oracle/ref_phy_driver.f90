@@ -1,5 +1,5 @@
 ! TEST INFRASTRUCTURE ONLY -- C-callable harness over the reference's own column-physics routines (phy_convmf.f90, phy_lscond.f90,
-! phy_shtorh.f90, phy_radiat.f90, phy_suflux.f90, phy_vdifsc.f90, ini_inphys.f90), compiled IN PLACE from /root/reference/src by
+! phy_shtorh.f90, phy_radiat.f90, phy_suflux.f90, phy_vdifsc.f90, ini_inphys.f90, ini_fordate.f90), compiled IN PLACE from /root/reference/src by
 ! oracle/build_ref.sh into oracle/_ref/libref_phy.so.  Nothing here restates physics: every routine below forwards to the
 ! reference.  All reals are 8 bytes (-fdefault-real-8, as the reference builds).  ngp = 96*48 columns, nlev = 8.
 module ref_phy_driver
@@ -19,6 +19,38 @@ contains
     call inphys(hsg, ppl, rlat)
     call radset
     ablco2_ref = ablco2
+  end subroutine
+
+  ! the reference's own fordate(0) (src/ini_fordate.f90, compiled in place): the per-window forcing set-up the hybrid re-runs every
+  ! step through agcm_init -- surface albedos from snow depth / sea ice (:54-61), tcorh = spec(gamlat phis0) (:72-86) and
+  ! qcorh = spec(refrh1 (q_sat(tref, 1) - q_sat(tsfc, psfc))) from the land / sea surface temperatures (:88-113).  Inputs are the
+  ! module variables fordate reads; nothing is restated here.
+  subroutine refp_fordate(tyear_, phis0_, fmask_l_, fmask_s_, stl_am_, sst_am_, alb0_, snowd_am_, sice_am_, tcorh_, qcorh_, &
+                          snowc_, alb_l_, alb_s_, albsfc_) bind(C, name="refp_fordate")
+    use mod_date, only: tyear, iyear
+    use mod_surfcon, only: phis0, alb0
+    use mod_cli_land, only: fmask_l
+    use mod_cli_sea, only: fmask_s
+    use mod_var_land, only: stl_am, snowd_am
+    use mod_var_sea, only: sst_am, sice_am
+    use mod_hdifcon, only: tcorh, qcorh
+    real(c_double), value :: tyear_
+    real(c_double), intent(in) :: phis0_(ix,il), fmask_l_(ix,il), fmask_s_(ix,il), stl_am_(ngp), sst_am_(ngp), alb0_(ix,il)
+    real(c_double), intent(in) :: snowd_am_(ngp), sice_am_(ngp)
+    real(c_double), intent(out) :: tcorh_(2,mx,nx), qcorh_(2,mx,nx), snowc_(ngp), alb_l_(ngp), alb_s_(ngp), albsfc_(ngp)
+    logical, save :: spectral_ready = .false.
+    if (.not. spectral_ready) then
+      call inifft()
+      call parmtr(6.371d6)
+      spectral_ready = .true.
+    end if
+    tyear = tyear_; iyear = 1981
+    phis0 = phis0_; alb0 = alb0_; fmask_l = fmask_l_; fmask_s = fmask_s_
+    stl_am = stl_am_; snowd_am = snowd_am_; sst_am = sst_am_; sice_am = sice_am_
+    call fordate(0)
+    tcorh_(1,:,:) = real(tcorh); tcorh_(2,:,:) = aimag(tcorh)
+    qcorh_(1,:,:) = real(qcorh); qcorh_(2,:,:) = aimag(qcorh)
+    snowc_ = snowc; alb_l_ = alb_l; alb_s_ = alb_s; albsfc_ = albsfc
   end subroutine
 
   subroutine refp_set_surface(phi0, alb_l_, alb_s_, albsfc_, snowc_) bind(C, name="refp_set_surface")

@@ -13,6 +13,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "bank.h"
 
@@ -74,6 +77,7 @@ struct ShmHeader {
     std::atomic<int> magic, arrive, generation, id_ready;
     char id[128];
     unsigned long long doubles_per_rank;
+    unsigned long long nonce;                     // the launch this segment belongs to (see launch_nonce)
 };
 constexpr int SHM_MAGIC = 0x534d4c43;
 
@@ -86,10 +90,57 @@ struct sml_comm {
     ShmHeader *hdr = nullptr;
     double *shm_data = nullptr;
     size_t shm_bytes = 0;
-    std::string shm_name, id_file;
+    std::string shm_name;
 };
 
 namespace {
+
+// A rendezvous name is reused from run to run (the Fortran host's default is a constant), so what is found under it may be the
+// leftover of an earlier -- possibly crashed -- run.  Every published id file / segment therefore carries a per-launch token and a
+// peer ignores one whose token is not its own: SML_COMM_NONCE when the launcher exports one (a job id), else the parent process id,
+// which the ranks of one launch share (children of one mpirun / torchrun / shell) and two launches do not.
+unsigned long long launch_nonce()
+{
+    const char *e = getenv("SML_COMM_NONCE");
+    if (e && *e) return strtoull(e, nullptr, 0) ^ 0x9e3779b97f4a7c15ull;
+    return (unsigned long long)getppid();
+}
+
+int rendezvous_timeout_s()
+{
+    const char *e = getenv("SML_COMM_TIMEOUT_S");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 120;
+}
+
+// names this process has published and not yet withdrawn: removed at exit, so that a host which never reaches sml_comm_destroy (the
+// reference's program main ends with mpi_finalize, not killmpi) or dies between publishing and the collective init leaves nothing behind
+std::mutex g_pending_mu;
+std::vector<std::string> g_pending_files, g_pending_shm;
+void withdraw_all()
+{
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    for (const std::string &f : g_pending_files) (void)unlink(f.c_str());
+    for (const std::string &n : g_pending_shm) (void)shm_unlink(n.c_str());
+    g_pending_files.clear(); g_pending_shm.clear();
+}
+void publish(std::vector<std::string> &list, const std::string &name)
+{
+    static std::once_flag once;
+    std::call_once(once, [] { atexit(withdraw_all); });
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    list.push_back(name);
+}
+void withdraw(std::vector<std::string> &list, const std::string &name, bool is_shm)
+{
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    for (size_t i = 0; i < list.size(); ++i)
+        if (list[i] == name) {
+            if (is_shm) (void)shm_unlink(name.c_str()); else (void)unlink(name.c_str());
+            list.erase(list.begin() + i);
+            return;
+        }
+}
 
 int shm_barrier(sml_comm *c)
 {
@@ -103,8 +154,8 @@ int shm_barrier(sml_comm *c)
     const auto t0 = std::chrono::steady_clock::now();
     while (h->generation.load() == g) {
         sched_yield();
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-            return sml::fail(SML_ERR_STATE, "sml_comm (shm): rank %d waited 120 s for its peers at a barrier", c->rank);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(rendezvous_timeout_s()))
+            return sml::fail(SML_ERR_STATE, "sml_comm (shm): rank %d waited %d s for its peers at a barrier", c->rank, rendezvous_timeout_s());
     }
     return SML_OK;
 }
@@ -184,70 +235,91 @@ int sml_comm_bootstrap(int nranks, int rank, const char *name, uint64_t max_doub
     SML_REQUIRE(out && name && *name && nranks >= 1 && rank >= 0 && rank < nranks, "sml_comm_bootstrap: bad arguments");
     const char *tr = getenv("SML_COMM_TRANSPORT");
     const bool shm = tr && !strcmp(tr, "shm");
+    const unsigned long long nonce = launch_nonce();
+    const int limit = rendezvous_timeout_s();
     const auto t0 = std::chrono::steady_clock::now();
-    auto timed_out = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120); };
+    auto timed_out = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit); };
     if (!shm) {
+        // id file = [nonce (8 bytes) | RCCL unique id (128 bytes)], written under a temporary name and renamed into place
         const std::string path = std::string("/dev/shm/") + name + ".id";
-        char id[ID_BYTES];
+        char rec[8 + ID_BYTES];
         if (rank == 0) {
-            int rc = sml_comm_unique_id(id);
+            int rc = sml_comm_unique_id(rec + 8);
             if (rc) return rc;
+            memcpy(rec, &nonce, 8);
+            (void)unlink(path.c_str());                                  // a leftover of an earlier run goes first
             const std::string tmp = path + ".tmp";
             FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, ID_BYTES, f) != ID_BYTES) { if (f) fclose(f); return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot write %s", tmp.c_str()); }
+            if (!f || fwrite(rec, 1, sizeof rec, f) != sizeof rec) { if (f) fclose(f); return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot write %s", tmp.c_str()); }
             fclose(f);
+            publish(g_pending_files, path);
             if (rename(tmp.c_str(), path.c_str())) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot publish %s", path.c_str());
         } else {
             for (;;) {
                 FILE *f = fopen(path.c_str(), "rb");
                 if (f) {
-                    const size_t got = fread(id, 1, ID_BYTES, f);
+                    const size_t got = fread(rec, 1, sizeof rec, f);
                     fclose(f);
-                    if (got == ID_BYTES) break;
+                    unsigned long long theirs = 0;
+                    memcpy(&theirs, rec, 8);
+                    if (got == sizeof rec && theirs == nonce) break;         // (anything else: another launch's file, or one being replaced)
                 }
-                if (timed_out()) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d waited 120 s for %s", rank, path.c_str());
+                if (timed_out())
+                    return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d waited %d s for an id file %s of this launch (nonce %llu)", rank, limit,
+                                     path.c_str(), nonce);
                 usleep(2000);
             }
         }
-        int rc = sml_comm_create(nranks, rank, id, out);
-        if (!rc && rank == 0) (*out)->id_file = path;
+        int rc = sml_comm_create(nranks, rank, rec + 8, out);
+        // ncclCommInitRank is collective: once it has returned here every peer has read the file
+        if (rank == 0) withdraw(g_pending_files, path, false);
         return rc;
     }
     const std::string shm_name = std::string("/") + name;
     const size_t per = max_doubles_per_rank ? (size_t)max_doubles_per_rank : (size_t)1 << 19;
     const size_t bytes = sizeof(ShmHeader) + 64 + per * nranks * sizeof(double);
-    int fd = -1;
+    void *mem = MAP_FAILED;
     if (rank == 0) {
         (void)shm_unlink(shm_name.c_str());
-        fd = shm_open(shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, (off_t)bytes)) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot create shared memory %s", shm_name.c_str());
+        const int fd = shm_open(shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes)) { if (fd >= 0) close(fd); return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: cannot create shared memory %s", shm_name.c_str()); }
+        publish(g_pending_shm, shm_name);
+        mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (mem == MAP_FAILED) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: mmap of %s failed", shm_name.c_str());
+        ShmHeader *h = (ShmHeader *)mem;
+        h->arrive.store(0); h->generation.store(0); h->id_ready.store(0);
+        h->doubles_per_rank = per;
+        h->nonce = nonce;
+        h->magic.store(SHM_MAGIC);
     } else {
+        // attach to the segment of THIS launch: one that is too small, not initialised yet, or carries another launch's nonce (a
+        // leftover rank 0 is about to replace) is let go and looked up again
         for (;;) {
-            fd = shm_open(shm_name.c_str(), O_RDWR, 0600);
+            const int fd = shm_open(shm_name.c_str(), O_RDWR, 0600);
             struct stat sb;
-            if (fd >= 0 && !fstat(fd, &sb) && (size_t)sb.st_size >= bytes) break;
+            if (fd >= 0 && !fstat(fd, &sb) && (size_t)sb.st_size >= bytes) {
+                mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                if (mem != MAP_FAILED) {
+                    ShmHeader *h = (ShmHeader *)mem;
+                    if (h->magic.load() == SHM_MAGIC && h->nonce == nonce && h->doubles_per_rank == per) { close(fd); break; }
+                    munmap(mem, bytes);
+                    mem = MAP_FAILED;
+                }
+            }
             if (fd >= 0) close(fd);
-            if (timed_out()) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d waited 120 s for shared memory %s", rank, shm_name.c_str());
+            if (timed_out())
+                return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d waited %d s for a shared-memory segment %s of this launch (nonce %llu)", rank, limit,
+                                 shm_name.c_str(), nonce);
             usleep(2000);
         }
     }
-    void *mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (mem == MAP_FAILED) return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: mmap of %s failed", shm_name.c_str());
     sml_comm *c = new sml_comm;
     c->nranks = nranks; c->rank = rank; c->hdr = (ShmHeader *)mem; c->shm_bytes = bytes; c->shm_name = shm_name;
     c->shm_data = (double *)((char *)mem + ((sizeof(ShmHeader) + 63) & ~(size_t)63));
-    if (rank == 0) {
-        c->hdr->arrive.store(0); c->hdr->generation.store(0); c->hdr->id_ready.store(0);
-        c->hdr->doubles_per_rank = per;
-        c->hdr->magic.store(SHM_MAGIC);
-    } else {
-        while (c->hdr->magic.load() != SHM_MAGIC) {
-            if (timed_out()) { munmap(mem, bytes); delete c; return sml::fail(SML_ERR_STATE, "sml_comm_bootstrap: rank %d: segment %s never initialised", rank, shm_name.c_str()); }
-            usleep(1000);
-        }
-    }
     int rc = shm_barrier(c);
+    // everybody is attached: the name is not needed any more (the mappings stay), and a later run cannot find this segment
+    if (rank == 0) withdraw(g_pending_shm, shm_name, true);
     if (rc) { munmap(mem, bytes); delete c; return rc; }
     *out = c;
     return SML_OK;
@@ -257,12 +329,10 @@ int sml_comm_destroy(sml_comm *c)
 {
     if (!c) return SML_OK;
     if (c->hdr) {
-        (void)shm_barrier(c);                   // (a rank that is still reading keeps the segment mapped; the name can go)
-        if (c->rank == 0) (void)shm_unlink(c->shm_name.c_str());
+        (void)shm_barrier(c);                   // (nobody is still reading; the name went right after the bootstrap)
         munmap((void *)c->hdr, c->shm_bytes);
         c->hdr = nullptr;
     }
-    if (!c->id_file.empty()) (void)unlink(c->id_file.c_str());
     Rccl *r;
     if (c->comm && load(&r) == SML_OK) (void)r->destroy(c->comm);
     if (c->send) (void)hipFree(c->send);

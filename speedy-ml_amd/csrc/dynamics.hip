@@ -1577,6 +1577,8 @@ int sml_dyn_get_state_host(sml_dyn *d, double *vor, double *div, double *t, doub
     return copy_state(d, vor, div, t, ps, tr, false);
 }
 
+double *sml_dyn_boundary_dev(sml_dyn *d) { return d ? d->bc : nullptr; }
+
 int sml_dyn_set_boundary_host(sml_dyn *d, const double *phis, const double *tcorh, const double *qcorh)
 {
     SML_REQUIRE(d && phis && tcorh && qcorh, "sml_dyn_set_boundary_host: bad arguments");

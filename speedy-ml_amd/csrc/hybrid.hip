@@ -26,7 +26,8 @@ struct sml_hybrid {
     sml_phys *phys = nullptr;
     int nreg = 0, nslots = 0, max_n_out = 0;
     double *G = nullptr, *F = nullptr, *fields = nullptr, *fields_out = nullptr, *raw_spec = nullptr, *state = nullptr;
-    double *bc = nullptr;                      // phis | tcorh | qcorh
+    double *bc = nullptr;                      // phis | tcorh | qcorh as set_orography leaves them (qcorh = 0 until the physics is attached)
+    double *phis0_grid = nullptr;              // mod_surfcon's phis0 = grid(phis, 1) (src/ini_invars.f90:31-34)
     double *base_sst = nullptr, *tisr = nullptr, *all_out = nullptr;
     int32_t *sea_mask = nullptr, *in_scale = nullptr, *in_desc = nullptr, *out_desc = nullptr, *safe = nullptr;
     int32_t *region_index = nullptr;
@@ -166,22 +167,39 @@ int sml_hybrid_set_base_sst(sml_hybrid *h, const double *base_sst, const int32_t
     return SML_OK;
 }
 
-/* surface geopotential phi0(96,48) [m2/s2]: phis = trunct(spec(phi0)), tcorh = trunct(spec(gamlat * phi0)) (src/ini_fordate.f90:72-113);
- * the humidity correction needs the physics' saturation routine and stays zero */
+/* invars' orography (src/ini_invars.f90:31-34) and fordate's temperature correction (src/ini_fordate.f90:72-86) from the surface
+ * geopotential phi0(96,48) [m2/s2]: phis = trunct(spec(phi0)), phis0 = grid(phis, 1) (the spectrally truncated orography, what
+ * mod_surfcon hands to fordate and to the physics: sml_hybrid_get_phis0), tcorh = spec(gamlat phis0) -- not truncated, as in the
+ * reference.  qcorh needs the surface temperatures: it is zero until sml_hybrid_attach_physics, from when on every window
+ * recomputes both correction terms (sml_phys_fordate). */
 int sml_hybrid_set_orography(sml_hybrid *h, const double *phi0_grid)
 {
     SML_REQUIRE(h && phi0_grid, "sml_hybrid_set_orography: bad arguments");
-    std::vector<double> two(2 * GR);
-    for (int i = 0; i < GR; ++i) { two[i] = phi0_grid[i]; two[GR + i] = phi0_grid[i] * GAMLAT; }
     double *tmp = nullptr;
-    int rc = sml::dev_upload(&tmp, two.data(), two.size());
+    int rc = sml::dev_upload(&tmp, phi0_grid, (size_t)GR);
     if (rc) return rc;
-    rc = sml_spectral_spec(h->sp, tmp, h->bc, 2, nullptr);
-    if (!rc) rc = sml_spectral_trunct(h->sp, h->bc, 2, nullptr);
+    if (!h->phis0_grid && (rc = dalloc(h, &h->phis0_grid, (size_t)GR))) { (void)hipFree(tmp); return rc; }
+    SML_HIP(hipMemset(h->bc, 0, sizeof(double) * 3 * SPF));
+    rc = sml_spectral_spec(h->sp, tmp, h->bc, 1, nullptr);
+    if (!rc) rc = sml_spectral_trunct(h->sp, h->bc, 1, nullptr);
+    if (!rc) rc = sml_spectral_grid(h->sp, h->bc, h->phis0_grid, 1, 1, nullptr);
+    std::vector<double> g(GR);
+    if (!rc && hipMemcpy(g.data(), h->phis0_grid, sizeof(double) * GR, hipMemcpyDeviceToHost) != hipSuccess) rc = sml::fail(SML_ERR_HIP, "sml_hybrid_set_orography: download failed");
+    for (int i = 0; i < GR; ++i) g[i] = GAMLAT * g[i];
+    if (!rc && hipMemcpy(tmp, g.data(), sizeof(double) * GR, hipMemcpyHostToDevice) != hipSuccess) rc = sml::fail(SML_ERR_HIP, "sml_hybrid_set_orography: upload failed");
+    if (!rc) rc = sml_spectral_spec(h->sp, tmp, h->bc + SPF, 1, nullptr);
     if (!rc) rc = sml_dyn_set_boundary(h->dyn, h->bc, h->bc + SPF, h->bc + 2 * SPF, nullptr);
     (void)hipDeviceSynchronize();
     (void)hipFree(tmp);
     return rc;
+}
+
+/* mod_surfcon's phis0(96,48): the truncated orography a host passes on as the physics' phis0 (after sml_hybrid_set_orography) */
+int sml_hybrid_get_phis0(sml_hybrid *h, double *phis0_host)
+{
+    SML_REQUIRE(h && phis0_host && h->phis0_grid, "sml_hybrid_get_phis0: sml_hybrid_set_orography has not been called");
+    SML_HIP(hipMemcpy(phis0_host, h->phis0_grid, sizeof(double) * GR, hipMemcpyDeviceToHost));
+    return SML_OK;
 }
 
 /* full_tisr: the pre-standardisation TISR table, one (96,48) slice per hour of a 365-day year (src/mod_reservoir.f90:890-909), and the
@@ -208,8 +226,21 @@ int sml_hybrid_attach_physics(sml_hybrid *h, const double *hsg9, const double *r
     SML_HIP(hipMemcpy(tsea.data(), h->base_sst, sizeof(double) * GR, hipMemcpyDeviceToHost));
     if ((rc = sml_phys_set_surface(h->phys, fmask, phis0, tland, tsea.data(), swav, alb_l, alb_s, albsfc, snowc))) return rc;
     if ((rc = sml_phys_bind_sst_dev(h->phys, h->G + SML_GS_OFF))) return rc;
+    // fordate's sea fraction: fmask_s = 1 - fmask_l, the relation src/ini_inbcon.f90:55-65,148-157 leaves between the two thresholded
+    // masks (sml_hybrid_set_fordate_fields overrides it and adds the albedo inputs)
+    std::vector<double> fs(GR);
+    for (int i = 0; i < GR; ++i) fs[i] = 1.0 - fmask[i];
+    if ((rc = sml_phys_set_fordate_fields(h->phys, fs.data(), nullptr, nullptr, nullptr))) return rc;
     h->phys_day = -1;
     return sml_dyn_attach_physics(h->dyn, h->phys, nstrad);
+}
+
+/* what fordate reads beyond the physics' surface fields (src/ini_fordate.f90:37-61,96-97): mod_cli_sea's fmask_s and -- all or none --
+ * alb0, snowd_am, sice_am, from which every window then recomputes snowc / alb_l / alb_s / albsfc as the reference does */
+int sml_hybrid_set_fordate_fields(sml_hybrid *h, const double *fmask_s, const double *alb0, const double *snowd_am, const double *sice_am)
+{
+    SML_REQUIRE(h && h->phys, "sml_hybrid_set_fordate_fields: sml_hybrid_attach_physics comes first");
+    return sml_phys_set_fordate_fields(h->phys, fmask_s, alb0, snowd_am, sice_am);
 }
 
 static int tisr_to_G(sml_hybrid *h, int timestep, hipStream_t st)
@@ -265,7 +296,11 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
     if ((rc = sml_handoff_to_fields(h->G, h->fields, stream))) return rc;
     if ((rc = sml_spectral_spec_mixed(h->sp, h->fields, h->raw_spec, NFIELD, h->in_scale, stream))) return rc;
     if ((rc = sml_spectral_spec_post(h->sp, h->raw_spec, h->in_desc, h->state, NSTATE, stream))) return rc;
-    if (h->phys) {          // fordate's daily sol_oz(tyear), tyear = (day of the 365-day year - 0.5) / 365 (src/ini_fordate.f90:47-50)
+    if (h->phys) {
+        // fordate(0) of this window's agcm_init (src/ini_agcm_init.f90:86): albedos, tcorh, and qcorh from sst_am = the SST just
+        // scattered into G, straight into the time steps' boundary fields; then its sol_oz(tyear), tyear = (day of the 365-day year
+        // - 0.5) / 365 (src/ini_fordate.f90:52), which changes once a day
+        if ((rc = sml_phys_fordate(h->phys, h->sp, sml_dyn_boundary_dev(h->dyn) + SPF, stream))) return rc;
         int32_t date[4];
         if ((rc = sml_calendar_date(1981, h->start_hours + h->t * h->timestep_hours, date)) < 0) return rc;
         static const int ndaycal[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};

@@ -48,6 +48,38 @@ __global__ __launch_bounds__(64) void k_physics(PhysLev L, PhysDev D, PhysIn in,
     physics_column(L, D, in, tend, lradsw, off_u, off_v, off_t, off_q, want_diag, p, park, u_dyn, v_dyn);
 }
 
+// fordate(0)'s grid-point work (src/ini_fordate.f90:54-61,72-109), which the hybrid repeats at the start of every window through
+// agcm_init: the surface albedos from snow depth and sea-ice fraction, and the two fields whose spectra correct the horizontal
+// diffusion of temperature and humidity over orography -- corh_t = gamlat phis0 and corh_q = refrh1 (q_sat(tref, p = 1) -
+// q_sat(tsfc, psfc)) with tsfc the land / sea mix of stl_am and sst_am (in the hybrid: the ML-predicted SST).  One thread per
+// grid point, statements in the reference's order; psfc_dummy = 1.0 is the reference's own stand-in for the reference pressure.
+__global__ __launch_bounds__(256) void k_fordate(const double *__restrict__ fmask_l, const double *__restrict__ fmask_s, const double *__restrict__ phis0,
+                                                  const double *__restrict__ stl_am, const double *__restrict__ sst_am, const double *__restrict__ alb0,
+                                                  const double *__restrict__ snowd_am, const double *__restrict__ sice_am, double *__restrict__ alb_l,
+                                                  double *__restrict__ alb_s, double *__restrict__ albsfc, double *__restrict__ snowc,
+                                                  double *__restrict__ corh /* [2][GR]: temperature, humidity */)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= GR) return;
+    if (alb0) {                                                        // :54-61
+        const double sc = fmin(1., snowd_am[p] / SD2SC);
+        const double al = alb0[p] + sc * (ALBSN - alb0[p]);
+        const double as = ALBSEA + sice_am[p] * (ALBICE - ALBSEA);
+        snowc[p] = sc; alb_l[p] = al; alb_s[p] = as;
+        albsfc[p] = as + fmask_l[p] * (al - as);
+    }
+    const double gamlat = GAMMA / (1000. * GG);                        // setgam :116-136
+    const double ct = gamlat * phis0[p];                               // :77
+    const double pexp = 1. / (RD * gamlat);                            // :91
+    const double tsfc = fmask_l[p] * stl_am[p] + fmask_s[p] * sst_am[p];
+    const double tref = tsfc + ct;
+    const double psfc = pow(tsfc / tref, pexp);
+    const double qref = qsat_of(tref, 1.0);                            // shtorh(0, ngp, tref, psfc_dummy = 1, -1., ...): P = ps(1)
+    const double qsfc = qsat_of(tsfc, 1. * psfc);                      // shtorh(0, ngp, tsfc, psfc, 1., ...): P = sig ps(j), sig = 1
+    corh[p] = ct;
+    corh[GR + p] = REFRH1 * (qref - qsfc);                             // :109
+}
+
 }  // namespace
 
 extern "C" {
@@ -114,6 +146,48 @@ int sml_phys_bind_sst_dev(sml_phys *ph, const double *tsea_dev)
 {   // sst_am read in place: the kernel takes the sea temperature from the caller's device array (NULL: back to the handle's copy)
     SML_REQUIRE(ph, "sml_phys_bind_sst_dev: null handle");
     ph->dev.tsea = tsea_dev ? tsea_dev : ph->surf + 3 * (size_t)smlphys::GR;
+    return SML_OK;
+}
+
+int sml_phys_set_fordate_fields(sml_phys *ph, const double *fmask_s, const double *alb0, const double *snowd_am, const double *sice_am)
+{   // host arrays [48][96]; alb0 / snowd_am / sice_am together or not at all
+    SML_REQUIRE(ph && fmask_s, "sml_phys_set_fordate_fields: bad arguments");
+    const bool alb = alb0 || snowd_am || sice_am;
+    SML_REQUIRE(!alb || (alb0 && snowd_am && sice_am), "sml_phys_set_fordate_fields: alb0, snowd_am and sice_am come together");
+    if (!ph->fordate) {
+        int rc = sml::dev_zeros(&ph->fordate, (size_t)6 * GR);          // fmask_s alb0 snowd_am sice_am | corh(2)
+        if (rc) return rc;
+        ph->allocs.push_back(ph->fordate);
+    }
+    SML_HIP(hipMemcpy(ph->fordate, fmask_s, GR * sizeof(double), hipMemcpyHostToDevice));
+    if (alb) {
+        SML_HIP(hipMemcpy(ph->fordate + GR, alb0, GR * sizeof(double), hipMemcpyHostToDevice));
+        SML_HIP(hipMemcpy(ph->fordate + 2 * GR, snowd_am, GR * sizeof(double), hipMemcpyHostToDevice));
+        SML_HIP(hipMemcpy(ph->fordate + 3 * GR, sice_am, GR * sizeof(double), hipMemcpyHostToDevice));
+    }
+    ph->fordate_albedo = alb;
+    return SML_OK;
+}
+
+int sml_phys_fordate(sml_phys *ph, sml_spectral *sp, double *corh_spec_dev, void *stream)
+{
+    SML_REQUIRE(ph && sp && corh_spec_dev, "sml_phys_fordate: bad arguments");
+    SML_REQUIRE(ph->fordate, "sml_phys_fordate: sml_phys_set_fordate_fields has not been called");
+    double *f = ph->fordate, *surf = ph->surf;
+    hipLaunchKernelGGL(k_fordate, dim3((GR + 255) / 256), dim3(256), 0, sml::as_stream(stream), ph->dev.fmask, (const double *)f, ph->dev.phis0,
+                       ph->dev.tland, ph->dev.tsea, ph->fordate_albedo ? (const double *)(f + GR) : (const double *)nullptr, (const double *)(f + 2 * GR),
+                       (const double *)(f + 3 * GR), surf + 5 * GR, surf + 6 * GR, surf + 7 * GR, surf + 8 * GR, f + 4 * GR);
+    SML_HIP(hipGetLastError());
+    return sml_spectral_spec(sp, f + 4 * GR, corh_spec_dev, 2, stream);      // spec(corh, tcorh), spec(corh, qcorh): no trunct (:86,113)
+}
+
+int sml_phys_get_surface(sml_phys *ph, int which, double *out_host)
+{   // 0 fmask 1 phis0 2 tland 3 tsea (the handle's copy) 4 swav 5 alb_l 6 alb_s 7 albsfc 8 snowc 9 forog | 10 corh_t 11 corh_q (fordate's grids)
+    SML_REQUIRE(ph && out_host && which >= 0 && which < 12, "sml_phys_get_surface: bad arguments");
+    SML_REQUIRE(which < 10 || ph->fordate, "sml_phys_get_surface: fordate has not been set up");
+    const double *src = which < 10 ? ph->surf + (size_t)which * GR : ph->fordate + (size_t)(which - 6) * GR;
+    SML_HIP(hipDeviceSynchronize());
+    SML_HIP(hipMemcpy(out_host, src, sizeof(double) * GR, hipMemcpyDeviceToHost));
     return SML_OK;
 }
 

@@ -15,6 +15,9 @@ constexpr int IX = 96, IL = 48, KX = 8, GR = IX * IL, NLP = KX + 1;
 
 // src/mod_physcon.f90:14-34
 constexpr double P0 = 1.e+5, GG = 9.81, RD = 287., CP = 1004., ALHC = 2501.0, SBC = 5.67e-8;
+// src/mod_dyncon0.f90:10,19 (reference lapse rate [K/km], reference relative humidity of the diffusion correction), src/mod_surfcon.f90:34,
+// src/mod_radcon.f90:59-61 -- fordate's constants
+constexpr double GAMMA = 6.0, REFRH1 = 0.7, SD2SC = 60.0, ALBSEA = 0.07, ALBICE = 0.60, ALBSN = 0.60;
 // src/mod_cnvcon.f90
 constexpr double PSMIN = 0.8, TRCNV = 6.0, RHBL = 0.9, RHIL = 0.7, ENTMAX = 0.5, SMF = 0.8;
 // src/mod_lsccon.f90
@@ -856,6 +859,8 @@ struct sml_phys {
     std::vector<void *> allocs;
     double *surf = nullptr;      // 10 x GR: fmask phis0 tland tsea swav alb_l alb_s albsfc snowc forog
     double *zonal = nullptr;     // 6 x 48: fsol ozone ozupp zenit stratz sqclat
+    double *fordate = nullptr;   // 6 x GR: fmask_s alb0 snowd_am sice_am (inputs of fordate) | corh_t corh_q (its two grid fields)
+    bool fordate_albedo = false; // fordate recomputes snowc / alb_l / alb_s / albsfc from alb0, snowd_am, sice_am
     double clat[48], slat[48];
 };
 

@@ -2032,6 +2032,7 @@ static int lu_trailing(LuSys &S, int nb, long ld, long np, int n_aug, int K0, in
 // L = U^T into the strictly lower triangle of W (free after the Cholesky factorisation: the trailing updates only ever touched
 // col >= row): W[c][r] = W[r][c] for r < c < n_aug.  The back substitution of a BATCH reads U(rows above, block) through it as the
 // row-contiguous operand of the LDS-DMA GEMM.  32 x 32 tiles through LDS.
+namespace {
 __global__ __launch_bounds__(256) void k_chol_mirror_u(double *__restrict__ w, long ld, int n_aug, LuStride ls)
 {
     if (blockIdx.y > blockIdx.x) return;                     // tile (row block by, column block bx) of the upper triangle
@@ -2051,6 +2052,7 @@ __global__ __launch_bounds__(256) void k_chol_mirror_u(double *__restrict__ w, l
         if (c < n_aug && r < c) w[(long)c * ld + r] = t[tx][ty + 8 * i];
     }
 }
+}  // namespace
 
 static int backsub_enqueue(LuSys &S, int nb, int n_aug, int n_out, long ld, bool chol = false)
 {

@@ -60,6 +60,17 @@ class Dynamics:
     def set_boundary(self, phis, tcorh, qcorh, stream=None):
         check(_lib.lib().sml_dyn_set_boundary(self._h, _chk(phis, (NX, MX2)), _chk(tcorh, (NX, MX2)), _chk(qcorh, (NX, MX2)), vp(stream)))
 
+    def boundary_ptr(self):
+        """device address of the handle's own [3][32][62] = phis | tcorh | qcorh (Physics.fordate writes the last two in place)"""
+        return int(_lib.lib().sml_dyn_boundary_dev(self._h))
+
+    def boundary(self):
+        """host copy (3, 32, 62) of phis | tcorh | qcorh as the time steps read them"""
+        import torch
+        from ._lib import device_view
+        torch.cuda.synchronize()
+        return device_view(self.boundary_ptr(), (3, NX, MX2)).cpu().numpy()
+
     def attach_physics(self, physics, nstrad=3):
         """grtend's physics call (src/dyn_grtend.f90:222-225): every later time step adds the column-physics tendencies of time
         level 1 to the grid-point tendencies.  nstrad: short-wave radiation every nstrad-th step (src/dyn_stloop.f90:39).

@@ -94,7 +94,7 @@ contains
     type(main_type), intent(inout) :: res
     logical, intent(in) :: ocean_model
     real(kind=dp), allocatable :: g(:), phi0(:,:), tisr(:,:,:), fmask(:,:), tland(:,:), swav(:,:), alb_l(:,:), alb_s(:,:), albsfc(:,:), snowc(:,:)
-    real(kind=dp), allocatable :: fill(:)
+    real(kind=dp), allocatable :: fill(:), phis0(:,:)
     integer(c_int), allocatable :: mask(:), sea_of_region(:)
     real(kind=dp) :: hsg(9), radang(48)
     integer :: start_hours, s
@@ -117,7 +117,11 @@ contains
     if (.not. first) return
     call sml_check(sml_hybrid_set_orography(hip_engine, phi0), 'sml_hybrid_set_orography')
     call sml_check(sml_hybrid_set_tisr_table(hip_engine, tisr, int(start_hours, c_int), int(res%model_parameters%timestep, c_int)), 'sml_hybrid_set_tisr_table')
-    call sml_check(sml_hybrid_attach_physics(hip_engine, hsg, radang, fmask, max(phi0, 0.0_dp), tland, swav, alb_l, alb_s, albsfc, snowc, 3_c_int), &
+    ! mod_surfcon's phis0 = grid(trunct(spec(phi0))) (src/ini_invars.f90:31-34): what fordate and the physics read.  With the physics
+    ! attached every window starts with fordate(0) on the device (tcorh, and qcorh from the hybrid SST; fmask_s = 1 - fmask1)
+    allocate(phis0(xgrid, ygrid))
+    call sml_check(sml_hybrid_get_phis0(hip_engine, phis0), 'sml_hybrid_get_phis0')
+    call sml_check(sml_hybrid_attach_physics(hip_engine, hsg, radang, fmask, phis0, tland, swav, alb_l, alb_s, albsfc, snowc, 3_c_int), &
                    'sml_hybrid_attach_physics')
     if (c_associated(hip_comm)) call sml_check(sml_hybrid_set_comm(hip_engine, hip_comm), 'sml_hybrid_set_comm')
     if (ocean_model) then

@@ -365,6 +365,18 @@ module speedyml_hip
       real(c_double), intent(in) :: phi0(*)
       integer(c_int) :: rc
     end function
+    function sml_hybrid_get_phis0(h, phis0) bind(C, name="sml_hybrid_get_phis0") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: phis0(*)
+      integer(c_int) :: rc
+    end function
+    function sml_hybrid_set_fordate_fields(h, fmask_s, alb0, snowd_am, sice_am) bind(C, name="sml_hybrid_set_fordate_fields") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: fmask_s(*), alb0(*), snowd_am(*), sice_am(*)
+      integer(c_int) :: rc
+    end function
     function sml_hybrid_set_tisr_table(h, tisr, start_hours, timestep_hours) bind(C, name="sml_hybrid_set_tisr_table") result(rc)
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h

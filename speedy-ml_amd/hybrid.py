@@ -17,6 +17,7 @@ steps of a window (DESIGN.md "What a bench step is").
 import numpy as np
 
 from . import domain
+from ._lib import device_view
 from .dynamics import DELT, F_DIV, F_PS, F_T, F_TR, F_VOR, NSTATE, Dynamics
 from .exchange import Exchange, handoff_check, handoff_from_fields, handoff_to_fields
 from .reservoir import ReservoirBank
@@ -84,17 +85,6 @@ def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, 
         keep[slot] = (b, mean, std, stat)
     bank.host_copies = keep
     return bank, sizes
-
-
-def device_view(ptr, shape):
-    """torch view (no copy) of device memory owned by the C-ABI library."""
-    import torch
-
-    class _Holder:
-        pass
-    h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (int(np.prod(shape)),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(h, device="cuda").view(*shape)
 
 
 def gather_outvec_slab(local_outvec, regions, all_out, even_split):
@@ -201,13 +191,18 @@ class HybridRank:
             self.raw_spec = torch.zeros((33, NX, MX2), dtype=f64, device=dev)
             self.safe = torch.ones(1, dtype=torch.int32, device=dev)
             self.dyn = Dynamics(self.sp)
-            # boundary fields: surface geopotential and the diffusion correction terms (ini_fordate.f90:72-113); the
-            # humidity correction needs the physics' saturation routine (shtorh) and is left at zero
-            phis0 = torch.from_numpy(np.ascontiguousarray(synthetic_orography())).to(dev)
-            bc = self.sp.spec(torch.stack([phis0, phis0 * GAMLAT]))
-            self.sp.trunct(bc)
-            self.phis, self.tcorh, self.qcorh = bc[0].contiguous(), bc[1].contiguous(), torch.zeros((NX, MX2), dtype=f64, device=dev)
-            self.dyn.set_boundary(self.phis, self.tcorh, self.qcorh)
+            # boundary fields as invars / fordate leave them (src/ini_invars.f90:31-34, src/ini_fordate.f90:72-86): phis = trunct(spec(phi0)),
+            # phis0 = grid(phis) -- the truncated orography, also the physics' phis0 -- and tcorh = spec(gamlat phis0), not truncated.
+            # The humidity correction qcorh needs the surface temperatures: zero for the adiabatic core; with the physics attached every
+            # window recomputes tcorh and qcorh from the hybrid SST (Physics.fordate in speedy_leg)
+            phi0 = torch.from_numpy(np.ascontiguousarray(synthetic_orography())).to(dev)
+            self.phis = self.sp.spec(phi0[None])
+            self.sp.trunct(self.phis)
+            phis0 = self.sp.grid(self.phis, 1)
+            self.phis0_grid = phis0[0].cpu().numpy()
+            self.tcorh = self.sp.spec(torch.from_numpy(GAMLAT * self.phis0_grid).to(dev)[None])[0].contiguous()
+            self.phis = self.phis[0].contiguous()
+            self.dyn.set_boundary(self.phis, self.tcorh, torch.zeros((NX, MX2), dtype=f64, device=dev))
             self.dyn.set_range_guard(self.safe)
             self.phys = None
             if physics:
@@ -255,21 +250,27 @@ class HybridRank:
     # ------------------------------------------------------------------ SPEEDY column physics inside every time step
     def init_physics(self, sea_mask, g4):
         """phypar in grtend (src/dyn_grtend.f90:222-225) with synthetic surface boundary fields: land fraction from the land-sea
-        mask, the orography of the dynamics, a land temperature from the lowest model level of the start state, mid-range soil
-        wetness, snow-free albedos.  The sea temperature is the hybrid state's SST grid, refreshed every step (sst_am)."""
+        mask, the truncated orography of the dynamics (mod_surfcon's phis0), a land temperature from the lowest model level of the start
+        state, mid-range soil wetness, snow-free albedos.  The sea temperature is the hybrid state's SST grid, refreshed every step
+        (sst_am).  fordate's sea fraction is 1 - fmask_l (src/ini_inbcon.f90:55-65,148-157)."""
         from .physics import NSTRAD, Physics
         from .synth import land_mask
         sea = (land_mask() if sea_mask is None else np.asarray(sea_mask)).reshape(IL, IX).astype(np.float64)
         fmask = 1.0 - sea
-        phis0 = np.maximum(0.0, synthetic_orography())
+        phis0 = self.phis0_grid
         tland = np.ascontiguousarray(g4[7, :, :, 0])
         sia = np.asarray(self.sp.table(1)).ravel()                       # sines of the 24 northern Gauss latitudes
         self.phys = Physics(np.concatenate([-np.arcsin(sia), np.arcsin(sia)[::-1]]))     # radang, src/ini_indyns.f90:72-80
-        alb_l, alb_s = np.full((IL, IX), 0.2), np.full((IL, IX), 0.07)
+        # albedos as fordate derives them (src/ini_fordate.f90:54-61) from a bare-land albedo of 0.2, no snow and no sea ice; every
+        # window's fordate recomputes them on the device from the same three inputs
+        alb0, snowd_am, sice_am = np.full((IL, IX), 0.2), np.zeros((IL, IX)), np.zeros((IL, IX))
+        alb_l, alb_s = alb0 + 0.0 * (0.60 - alb0), 0.07 + sice_am * (0.60 - 0.07)
         self.surface = dict(fmask=fmask, phis0=phis0, tland=tland, tsea=self.base_sst.cpu().numpy().reshape(IL, IX), swav=np.full((IL, IX), 0.5),
-                            alb_l=alb_l, alb_s=alb_s, albsfc=alb_s + fmask * (alb_l - alb_s), snowc=np.zeros((IL, IX)))
+                            alb_l=alb_l, alb_s=alb_s, albsfc=alb_s + fmask * (alb_l - alb_s), snowc=np.zeros((IL, IX)),
+                            alb0=alb0, snowd_am=snowd_am, sice_am=sice_am)
         self.phys.set_surface(*[self.surface[k] for k in ("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc")])
         self.phys.bind_sst(self.G[domain.GS_OFF:domain.GT_OFF])      # sst_am = the hybrid state's SST grid, read in place
+        self.phys.set_fordate_fields(1.0 - fmask, alb0, snowd_am, sice_am)
         self.phys_day = None
         self.update_forcing()
         self.dyn.attach_physics(self.phys, NSTRAD)       # diagnostics stay on: skipping their stores changes nothing measurable
@@ -399,6 +400,9 @@ class HybridRank:
     def speedy_leg(self, stream):
         self.handoff_in(stream)
         if self.phys is not None:
+            # fordate(0) of this window's agcm_init (src/ini_agcm_init.f90:86): tcorh, and qcorh from the SST just scattered into G,
+            # written straight into the time steps' boundary fields; then its daily sol_oz
+            self.phys.fordate(self.sp, self.dyn.boundary_ptr() + NX * MX2 * 8, stream)
             self.update_forcing()
         if self.leapfrog_steps is not None:
             # agcm_init -> stepone, then stloop's first 6-hour window (src/dyn_stloop.f90:24-95 with onehr_hybrid)

@@ -48,6 +48,29 @@ class Physics:
             self._sst_keep = tsea_dev
         check(_lib.lib().sml_phys_bind_sst_dev(self._h, dp(tsea_dev.data_ptr()) if tsea_dev is not None else None))
 
+    def set_fordate_fields(self, fmask_s, alb0=None, snowd_am=None, sice_am=None):
+        """what fordate reads besides the surface fields (src/ini_fordate.f90): the sea fraction fmask_s and -- optionally, all or
+        none -- the bare-land albedo, snow depth and sea-ice fraction from which it recomputes snowc / alb_l / alb_s / albsfc"""
+        a = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (fmask_s, alb0, snowd_am, sice_am)]
+        assert all(x is None or x.shape == (48, 96) for x in a)
+        self._fordate_keep = a
+        check(_lib.lib().sml_phys_set_fordate_fields(self._h, *[dp(x) for x in a]))
+
+    def fordate(self, spectral, corh_spec, stream=None):
+        """fordate(0) on the device: albedos (when their inputs were given), then tcorh | qcorh into corh_spec: a [2, 32, 62] CUDA
+        tensor or a raw device address (Dynamics.boundary_ptr() + 32 * 62 * 8)"""
+        if hasattr(corh_spec, "data_ptr"):
+            assert corh_spec.is_cuda and corh_spec.is_contiguous() and tuple(corh_spec.shape) == (2, 32, 62) and corh_spec.element_size() == 8
+            corh_spec = corh_spec.data_ptr()
+        check(_lib.lib().sml_phys_fordate(self._h, spectral._h, dp(int(corh_spec)), vp(stream)))
+
+    SURFACE = {n: i for i, n in enumerate(("fmask", "phis0", "tland", "tsea", "swav", "alb_l", "alb_s", "albsfc", "snowc", "forog", "corh_t", "corh_q"))}
+
+    def surface(self, name):
+        out = np.zeros((48, 96))
+        check(_lib.lib().sml_phys_get_surface(self._h, self.SURFACE[name], dp(out)))
+        return out
+
     def sol_oz(self, tyear):
         check(_lib.lib().sml_phys_sol_oz(self._h, C.c_double(tyear)))
 

@@ -668,6 +668,18 @@ class RefPhys:
     def sol_oz(self, tyear):
         self.lib.refp_sol_oz(tyear)
 
+    def fordate(self, tyear, phis0, fmask_l, fmask_s, stl_am, sst_am, alb0, snowd_am, sice_am):
+        """The reference's own fordate(0) (src/ini_fordate.f90, compiled in place) on the given module-variable values, each (48,96)
+        or (4608,).  Returns dict(tcorh, qcorh: oracle-layout (62,32); snowc, alb_l, alb_s, albsfc: (4608,)).  Leaves the physics'
+        albedo / sol_oz / sflset module state as fordate sets it."""
+        a = [np.ascontiguousarray(x, dtype=np.float64).ravel().copy() for x in (phis0, fmask_l, fmask_s, stl_am, sst_am, alb0, snowd_am, sice_am)]
+        tc, qc = np.zeros(2 * 31 * 32), np.zeros(2 * 31 * 32)
+        alb = [np.zeros(NGP) for _ in range(4)]
+        self.lib.refp_fordate.argtypes = [C.c_double] + [_dp] * 14
+        self.lib.refp_fordate(float(tyear), *[_p(x) for x in a], _p(tc), _p(qc), *[_p(x) for x in alb])
+        return dict(tcorh=tc.reshape((62, 32), order="F"), qcorh=qc.reshape((62, 32), order="F"), snowc=alb[0], alb_l=alb[1], alb_s=alb[2],
+                    albsfc=alb[3])
+
     def radstate(self):
         tau2, stratc, qcloud = np.zeros((NGP, KX, 4), order="F"), np.zeros((NGP, 2), order="F"), np.zeros(NGP)
         self.lib.refp_get_radstate(_p(tau2), _p(stratc), _p(qcloud))

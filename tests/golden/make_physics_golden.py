@@ -105,14 +105,16 @@ def coupled_inputs(seed=5):
     return o, st, phis, {k: surf[k] for k in ("fmask", "phis0", "tland", "tsea", "swav", "snowc", "alb_l", "alb_s", "albsfc")}
 
 
-def run_coupled_reference(o, st, phis, surf, ref, nsteps=WINDOW_STEPS, delt=900.0, tyear=TYEAR):
+def run_coupled_reference(o, st, phis, surf, ref, nsteps=WINDOW_STEPS, delt=900.0, tyear=TYEAR, tcorh=None, qcorh=None):
     """stepone + nsteps leapfrog steps (src/ini_stepone.f90, src/dyn_stloop.f90:28-43) with the oracle's dynamics and, in grtend's
-    physics slot (src/dyn_grtend.f90:222-225), the compiled reference parametrisations."""
+    physics slot (src/dyn_grtend.f90:222-225), the compiled reference parametrisations.  tcorh / qcorh: fordate's diffusion
+    corrections (62,32), zero when not given (the committed window fixture was generated without them)."""
     from _oracle import DynOracle
     ref.set_surface(surf["phis0"], surf["alb_l"], surf["alb_s"], surf["albsfc"], surf["snowc"])
     ref.sol_oz(tyear)
     do = DynOracle(o)
     zero = np.zeros((62, 32))
+    tcorh, qcorh = zero if tcorh is None else tcorh, zero if qcorh is None else qcorh
     flag = {"lradsw": True}
 
     def hook(ug, vg, tg, qg, phig, pslg, ut, vt, tt, qt):
@@ -124,7 +126,7 @@ def run_coupled_reference(o, st, phis, surf, ref, nsteps=WINDOW_STEPS, delt=900.
     for j1, j2, dt_imp, dt, sw in sched:
         do.impint(dt_imp, 0.5)
         flag["lradsw"] = sw
-        st = do.step(j1, j2, dt, 0.5, 0.05, 0.53, st, phis, zero, zero, phys=hook)
+        st = do.step(j1, j2, dt, 0.5, 0.05, 0.53, st, phis, tcorh, qcorh, phys=hook)
     return st
 
 

@@ -28,6 +28,22 @@ def test_every_declared_symbol_is_exported():
     assert sorted(_lib.EXPORTS) == names
 
 
+F77_EXTERNALS = {"parmtr_", "inifft_", "grid_", "spec_", "vdspec_", "uvspec_", "vds_", "grad_", "lap_", "invlap_", "trunct_"}
+
+
+def test_nothing_but_the_abi_is_exported():
+    """nm -D: the dynamic symbol table holds the sml_* entry points and the eleven F77 externals of the reference's spectral files,
+    nothing else (csrc/exports.map) -- no C++ helper, template instantiation or kernel stub leaks into the ABI"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    stray = sorted(n for n in names if not n.startswith("sml_") and n not in F77_EXTERNALS)
+    assert not stray, stray
+    assert F77_EXTERNALS <= names
+    # (a handful of sml_*_debug_stamps profiling aids are exported without a declaration in include/; everything declared is there)
+    assert set(declared_symbols()) <= names
+
+
 def test_host_only_entry_points():
     L = _lib.lib()
     assert L.sml_version() >= 100

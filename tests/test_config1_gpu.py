@@ -1,7 +1,8 @@
 """GPU: BASELINE config 1 -- SPEEDY-only T30L8 free run from rest, reservoir off (src/at_gcm.f90:84-90 agcm_1day -> src/dyn_stloop.f90:26-43,
 started by invars with istart = 0, src/ini_invars.f90:27-111, and stepone, src/ini_stepone.f90) -- on the device: stepone + 960 leapfrog
 steps of 900 s (10 days = 40 six-hour windows) with the column physics attached, short-wave radiation every third step
-(mod(istep, nstrad) == 1 with istep running through the days, 96 % 3 == 0) and the daily solar / ozone fields (fordate -> sol_oz).
+(mod(istep, nstrad) == 1 with istep running through the days, 96 % 3 == 0) and fordate's daily work on the device: the solar / ozone
+fields (sol_oz) and the diffusion corrections tcorh, qcorh from the surface temperatures (src/ini_fordate.f90:72-113, sml_phys_fordate).
 
 Parity: the first two windows (stepone + 48 steps) against the oracle's dynamics with the compiled reference parametrisations in
 grtend's physics slot, 1e-10 of each field's max-abs (the discrete switches of the parametrisations make longer trajectories
@@ -53,20 +54,33 @@ def surface():
     return {k: surf[k] for k in SURF}
 
 
-def free_run(lvl, phis, surf, windows, keep_after=None):
-    sp = Spectral()
-    dyn = Dynamics(sp)
+def attach(dyn, sp, phis, surf):
+    """boundary fields + physics; fordate's corrections are written into the boundary fields by Physics.fordate"""
     spec2 = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
     zero = np.zeros((62, 32))
     dyn.set_boundary(spec2(phis), spec2(zero), spec2(zero))
     ph = Physics(gaussian_latitudes())
     ph.set_surface(*[np.asarray(surf[k]).reshape(48, 96) for k in SURF])
+    ph.set_fordate_fields(1.0 - np.asarray(surf["fmask"]).reshape(48, 96))
     dyn.attach_physics(ph)
+    return ph
+
+
+def fordate(ph, dyn, sp, day):
+    """fordate(0) at the start and fordate(1) once a day (src/ini_agcm_init.f90:86, src/at_gcm.f90:75)"""
+    ph.sol_oz(TYEAR0 + day / 365.0)
+    ph.fordate(sp, dyn.boundary_ptr() + 32 * 62 * 8)
+
+
+def free_run(lvl, phis, surf, windows, keep_after=None):
+    sp = Spectral()
+    dyn = Dynamics(sp)
+    ph = attach(dyn, sp, phis, surf)
     state = to_state(lvl)
     kept = None
     for w in range(windows):
         if w % WINDOWS_PER_DAY == 0:
-            ph.sol_oz(TYEAR0 + (w // WINDOWS_PER_DAY) / 365.0)          # fordate(1) once a day (src/at_gcm.f90:75)
+            fordate(ph, dyn, sp, w // WINDOWS_PER_DAY)
         dyn.window(state, STEPS_PER_WINDOW, start=(w == 0))
         if keep_after is not None and w + 1 == keep_after:
             torch.cuda.synchronize()
@@ -91,7 +105,13 @@ def test_first_two_windows_match_oracle_with_reference_physics(oracle):
     state, _, _ = free_run(lvl, phis, surf, 2)
     got = from_state(state)
     st = {k: np.stack([lvl[k], np.full_like(lvl[k], 1e30)], axis=-1) for k in KEYS}
-    want = run_coupled_reference(oracle, st, phis, surf, RefPhys(HSG, gaussian_latitudes()), nsteps=2 * STEPS_PER_WINDOW, tyear=TYEAR0)
+    ref = RefPhys(HSG, gaussian_latitudes())
+    # the reference's own fordate(0) (compiled in place) gives the oracle its tcorh / qcorh; the albedo inputs are arbitrary here:
+    # run_coupled_reference puts the test's albedos back (the device run does not recompute them either)
+    one = np.ones(4608)
+    fd = ref.fordate(TYEAR0, surf["phis0"], surf["fmask"], 1.0 - np.asarray(surf["fmask"]), surf["tland"], surf["tsea"], 0.2 * one, 0 * one, 0 * one)
+    assert np.max(np.abs(fd["qcorh"])) > 1e-3 and np.max(np.abs(fd["tcorh"])) > 1e-3
+    want = run_coupled_reference(oracle, st, phis, surf, ref, nsteps=2 * STEPS_PER_WINDOW, tyear=TYEAR0, tcorh=fd["tcorh"], qcorh=fd["qcorh"])
     for k in KEYS:
         assert rel(got[k], want[k]) < 1e-10, (k, rel(got[k], want[k]))
     assert np.max(np.abs(want["vor"])) > 0                     # the physics set the atmosphere in motion
@@ -129,16 +149,10 @@ def test_hybrid_style_windows_restart_with_stepone(oracle):
     cont, _, sp = free_run(lvl, phis, surf, 8)
     sp2 = Spectral()
     dyn = Dynamics(sp2)
-    spec2 = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
-    zero = np.zeros((62, 32))
-    dyn.set_boundary(spec2(phis), spec2(zero), spec2(zero))
-    ph = Physics(gaussian_latitudes())
-    ph.set_surface(*[np.asarray(surf[k]).reshape(48, 96) for k in SURF])
-    dyn.attach_physics(ph)
+    ph = attach(dyn, sp2, phis, surf)
     state = to_state(lvl)
     for w in range(WINDOWS):
-        if w % WINDOWS_PER_DAY == 0:
-            ph.sol_oz(TYEAR0 + (w // WINDOWS_PER_DAY) / 365.0)
+        fordate(ph, dyn, sp2, w // WINDOWS_PER_DAY)                 # every window re-runs agcm_init, hence fordate(0)
         dyn.window(state, STEPS_PER_WINDOW, start=True)
         if w == 7:
             torch.cuda.synchronize()

@@ -120,3 +120,61 @@ def test_bench_gpus_n_relays_a_failing_rank():
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
     assert "no HIP device visible" in p.stderr
+
+
+# ---------------------------------------------------------------- sml_comm_bootstrap: leftovers of an earlier run under the same name
+_BOOT = r"""
+import ctypes as C, os, sys
+L = C.CDLL(sys.argv[1])
+L.sml_last_error.restype = C.c_char_p
+h = C.c_void_p()
+rc = L.sml_comm_bootstrap(int(sys.argv[3]), int(sys.argv[2]), sys.argv[4].encode(), C.c_uint64(1024), C.byref(h))
+print("rc", rc, L.sml_last_error().decode() if rc else "", flush=True)
+if rc == 0:
+    print("segment_name_left", os.path.exists("/dev/shm/" + sys.argv[4]), flush=True)
+    L.sml_comm_destroy(h)
+sys.exit(0 if rc == 0 else 3)
+"""
+
+
+def _stale_leftovers(name):
+    """what a crashed earlier run leaves under /dev/shm: an id file and an initialised segment, both with another launch's token"""
+    import struct
+    with open(f"/dev/shm/{name}.id", "wb") as f:
+        f.write(struct.pack("<Q", 0xdeadbeef) + bytes(128))
+    hdr = struct.pack("<4i128sQQ", 0x534d4c43, 0, 0, 0, bytes(128), 1024, 0xdeadbeef)        # ShmHeader of csrc/comm.hip
+    with open(f"/dev/shm/{name}", "wb") as f:
+        f.write(hdr + bytes(64 + 1024 * 2 * 8 + 64))
+
+
+def test_bootstrap_ignores_the_leftovers_of_an_earlier_run():
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "speedy-ml_amd", "csrc", "libspeedyml_hip.so")
+    name = f"sml_stale_test_{os.getpid()}"
+    run = lambda rank, env: subprocess.Popen([sys.executable, "-c", _BOOT, so, str(rank), "2", name], env=dict(os.environ, **env),
+                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        # RCCL transport: a peer that finds only the stale id file must keep waiting for this launch's (and say so), not join a dead id
+        _stale_leftovers(name)
+        p = run(1, {"SML_COMM_TIMEOUT_S": "2", "SML_COMM_NONCE": "41"})
+        out = p.communicate(timeout=60)[0]
+        assert p.returncode == 3 and "of this launch" in out, out
+        # shm transport: rank 1 starts first and sees the stale segment; rank 0 replaces it; both meet in the new one
+        env = {"SML_COMM_TRANSPORT": "shm", "SML_COMM_TIMEOUT_S": "30", "SML_COMM_NONCE": "42"}
+        p1 = run(1, env)
+        time.sleep(1.0)
+        assert p1.poll() is None, p1.communicate()[0]           # still waiting: the leftover did not fool it
+        p0 = run(0, env)
+        o0, o1 = p0.communicate(timeout=60)[0], p1.communicate(timeout=60)[0]
+        assert p0.returncode == 0 and p1.returncode == 0, (o0, o1)
+        # rank 0 withdraws the name as soon as everybody is attached (before its bootstrap call returns): nothing for the next run to
+        # trip over, even if the host never reaches sml_comm_destroy
+        assert "segment_name_left False" in o0, o0
+        assert not os.path.exists(f"/dev/shm/{name}")
+    finally:
+        for f in (f"/dev/shm/{name}", f"/dev/shm/{name}.id", f"/dev/shm/{name}.id.tmp"):
+            if os.path.exists(f):
+                os.unlink(f)

@@ -36,6 +36,10 @@ def test_native_engine_equals_python_step():
     f = lambda k: _lib.dp(np.ascontiguousarray(s[k], dtype=np.float64))
     check(L.sml_hybrid_attach_physics(h, _lib.dp(HSG), _lib.dp(radang), f("fmask"), f("phis0"), f("tland"), f("swav"), f("alb_l"), f("alb_s"),
                                       f("albsfc"), f("snowc"), NSTRAD))
+    phis0 = np.zeros((48, 96))
+    check(L.sml_hybrid_get_phis0(h, _lib.dp(phis0)))
+    assert np.array_equal(phis0, s["phis0"])                   # mod_surfcon's truncated orography, the same on both hosts
+    # (fordate's albedo inputs are left out here: the engine then keeps the albedos it was given, which are what fordate derives)
     check(L.sml_hybrid_initial_inputs(h, None))
     torch.cuda.synchronize()
     assert torch.equal(eng.feedback, ref.feedback) and torch.equal(eng.local_model, ref.local_model)
@@ -73,6 +77,8 @@ def make_engine(model, regions, classes, comm=None):
     f = lambda k: _lib.dp(np.ascontiguousarray(s[k], dtype=np.float64))
     check(L.sml_hybrid_attach_physics(h, _lib.dp(HSG), _lib.dp(radang), f("fmask"), f("phis0"), f("tland"), f("swav"), f("alb_l"), f("alb_s"),
                                       f("albsfc"), f("snowc"), NSTRAD))
+    fs = np.ascontiguousarray(1.0 - s["fmask"])
+    check(L.sml_hybrid_set_fordate_fields(h, _lib.dp(fs), f("alb0"), f("snowd_am"), f("sice_am")))
     if model.slab is not None:
         base = np.ascontiguousarray(model.base_sst.cpu().numpy())
         mask = np.ascontiguousarray(model.sst_mask.cpu().numpy(), dtype=np.int32)

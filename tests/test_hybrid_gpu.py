@@ -27,7 +27,9 @@ def oracle_speedy_leg(o, m, G, phys=None):
     """iogrid(30), stepone + 24 leapfrog steps, iogrid(31) with the oracle, from the device's hybrid state G.  With the column
     physics attached, grtend's physics slot is filled with the compiled reference parametrisations (oracle/_ref/libref_phy.so);
     `phys` continues a previous window's hook (short-wave flag and the short-wave scheme's leftovers carry over, as the reference's
-    module variables do).  Returns (F4, F2, phys)."""
+    module variables do).  The diffusion corrections tcorh / qcorh come from the reference's own fordate(0) (src/ini_fordate.f90,
+    compiled in place into the same library) run on the surface fields and the SST of G, as every window's agcm_init does; the
+    adiabatic core has no surface temperatures: tcorh from the orography, qcorh zero.  Returns (F4, F2, phys)."""
     from _oracle import DynOracle, PhysHook, RefPhys, oracle_iogrid30, oracle_iogrid31, oracle_window
     if m.phys is not None:
         if not RefPhys.available():
@@ -40,12 +42,22 @@ def oracle_speedy_leg(o, m, G, phys=None):
             phys = PhysHook(RefPhys(HSG, np.concatenate([-np.arcsin(sia), np.arcsin(sia)[::-1]])), surf, tyear)
         else:
             phys.s["tsea"] = np.ascontiguousarray(G[domain.GS_OFF:domain.GT_OFF], dtype=np.float64)
-            phys.ref.sol_oz(tyear)                     # fordate's daily call (same value when the day has not changed)
+        s = m.surface
+        fd = phys.ref.fordate(tyear, s["phis0"], s["fmask"], 1.0 - s["fmask"], s["tland"], G[domain.GS_OFF:domain.GT_OFF], s["alb0"], s["snowd_am"],
+                              s["sice_am"])      # (includes fordate's sol_oz(tyear) and sflset; leaves the albedos it computes in the physics' modules)
+        for k in ("alb_l", "alb_s", "albsfc", "snowc"):
+            assert np.array_equal(fd[k], np.asarray(s[k]).ravel()) and np.array_equal(m.phys.surface(k).ravel(), fd[k]), k
+        tcorh, qcorh = fd["tcorh"], fd["qcorh"]
+        assert np.max(np.abs(qcorh)) > 1e-3
+    else:
+        tcorh, qcorh = m.tcorh.cpu().numpy().T, np.zeros((62, 32))
     g4 = G[:domain.G2_OFF].reshape(8, 48, 96, 4)
     logp = G[domain.G2_OFF:domain.GP_OFF].reshape(48, 96)
     lvl = oracle_iogrid30(o, g4, logp)
     sp2 = lambda t: t.cpu().numpy().T
-    cur = oracle_window(DynOracle(o), lvl, sp2(m.phis), sp2(m.tcorh), sp2(m.qcorh), m.leapfrog_steps, phys=phys)
+    bc = m.dyn.boundary()
+    assert np.max(np.abs(bc[1].T - tcorh)) <= 1e-12 * np.max(np.abs(tcorh)) and np.max(np.abs(bc[2].T - qcorh)) <= 1e-12 * max(np.max(np.abs(qcorh)), 1e-3)
+    cur = oracle_window(DynOracle(o), lvl, sp2(m.phis), tcorh, qcorh, m.leapfrog_steps, phys=phys)
     F4, F2 = oracle_iogrid31(o, {k: cur[k][..., 0] for k in cur})
     qv = F4[..., 3]
     qv[qv < 0.000001] = 0.000001
