@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libspeedyml_hip.so")
+# (SML_LIB_PATH: a diagnostic build of the same library, e.g. csrc/libspeedyml_hip_span.so for profiles/micro/window_span.py)
+LIB_PATH = os.environ.get("SML_LIB_PATH") or os.path.join(_HERE, "csrc", "libspeedyml_hip.so")
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)

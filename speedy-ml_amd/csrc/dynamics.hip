@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "common.h"
+#include "span.h"
 #include "physics_dev.h"
 
 namespace {
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(64) void k_gridtend(DevHoriz H, LevelTables L, cons
 __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTables L, const double *__restrict__ G, double *__restrict__ O,
                                                            smlphys::PhysLev PL, smlphys::PhysDev PD, smlphys::PhysIn PG, int lradsw, int want_diag)
 {
+    SML_SPAN(2);
     __shared__ double park[smlphys::PARK_DOUBLES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // uniform: the two chains are scalar branches
@@ -610,8 +612,10 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
                                                   const double *tend_in, double *tend_out, int stop_after_grtend,
                                                   double *__restrict__ state, const double *__restrict__ imp_h,
                                                   const double *__restrict__ imp_x, const double *__restrict__ phis,
-                                                  const double *__restrict__ tcorh, const double *__restrict__ qcorh)
+                                                  const double *__restrict__ tcorh, const double *__restrict__ qcorh,
+                                                  double *__restrict__ phi_out)
 {
+    SML_SPAN(4);
     __shared__ double lv[LV_ROWS][KX];          // level tables, indexed by a lane-varying level
     __shared__ double xdc[2][KX * KX];          // xd, xc
     __shared__ double d4[KX][8], t4[KX][8];     // div and t of time level j4, [level][coefficient]
@@ -751,13 +755,29 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
         const double fj_after = two ? fj : n1;                // field(.,1) is overwritten before field(.,2) is formed
         s1[o] = n1;
         s2[o] = fnew - (1 - a.wil) * a.eps * (n1 - 2 * fj_after + fnew);
+        return n1;
     };
     // a column's ps is only touched by its k == 0 thread
     timint(ov, v1, v2, vordt);
     timint(od, d1, d2, divdt);
-    timint(ot, t1, t2, tdt);
+    const double t1_new = timint(ot, t1, t2, tdt);
     timint(oq, q1, q2, trdt);
     if (k == 0) timint(op, p1, p2, psdt);
+    if (phi_out) {
+        // geop(1) of the time level 1 this step leaves behind (src/dyn_geop.f90:19-35): what the NEXT step's phypar reads as phig1
+        // (src/dyn_grtend.f90:222-224).  The 8 levels of a coefficient are in this workgroup anyway; the next k_grid launch then stages
+        // eight plain fields instead of rebuilding the hydrostatic chain from eight temperature levels in each of its 48 workgroups of
+        // those rows (its slowest: 14 against 9-10 us, the launch's tail).  Same expression, same order, same bits as derived_coeff 7.
+        __syncthreads();
+        t4[k][ci] = t1_new;
+        __syncthreads();
+        double phi = phis[e] + lv[LV_XG1][KX - 1] * t4[KX - 1][ci];
+#pragma unroll
+        for (int j = KX - 2; j >= 0; --j)
+            if (j >= k) phi = phi + lv[LV_XG2][j + 1] * t4[j + 1][ci] + lv[LV_XG1][j] * t4[j][ci];
+        if (c < 2 && k >= 1 && k <= KX - 2) phi = phi + lv[LV_CORF][k] * (t4[k + 1][ci] - t4[k - 1][ci]);
+        phi_out[(size_t)k * SP + e] = phi;
+    }
 }
 
 
@@ -1251,7 +1271,9 @@ struct sml_dyn {
     int32_t *guard = nullptr;          // sml_dyn_set_range_guard: flag cleared when the first step's grids leave the physical range
     int nstrad = 3, lradsw = 1;        // short-wave radiation every nstrad-th step; flag of the next sml_dyn_step (mod_lflags.f90:22)
     int32_t *desc_phys = nullptr;      // inverse-batch descriptors with physics: [2 (j2)][91][4], fields relative to the whole state
-    double *aux = nullptr;             // xgeop1 | xgeop2 | corf | phis: geopotential operands of the type-7 rows
+    int32_t *desc_phys_phi = nullptr;  // the same with the eight geopotential rows taken from aux (type 8) instead of rebuilt (type 7)
+    double *aux = nullptr;             // xgeop1 | xgeop2 | corf | phis | phi(8 levels): geopotential operands of the type-7 rows, and the
+                                       // geop(1) fields k_spectral leaves for the type-8 rows of the next step
     double *tend_grid = nullptr;       // [73][GR]
     double *tend_spec = nullptr;       // [73][SP]
     int32_t *desc = nullptr, *scale = nullptr;     // inverse-batch descriptors [50][4], forward-batch scaling flags [73]
@@ -1281,13 +1303,17 @@ int fetch_table(sml_dyn *d, int which, const double **dst, std::vector<double> &
 
 int g_physics_fused = 1;     // sml_dyn_select_physics_form
 
-int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend, double *tend_out, hipStream_t st, int lradsw = 1)
+// phi_ready: the previous launch of this window's k_spectral left geop(1) of the current time level 1 in d->aux (its phi_out), so
+// the inverse set takes the physics' eight geopotential levels from there (descriptor type 8) instead of rebuilding them (type 7)
+int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend, double *tend_out, hipStream_t st, int lradsw = 1, bool phi_ready = false,
+             bool leave_phi = false)
 {
     const double *sj2 = state + (size_t)(a.j2 - 1) * NSTATE * SP;
     // the 50 inverse transforms of grtend (:61-99) straight from the state: uvspec and grad are formed while the fields are staged.
     // With physics attached the same launch also produces the 27 grids of time level 1 that phypar's parametrisations read
     // (phy_phypar.f90:54-66 minus the unused wind levels), geop(1) included.
-    int rc = d->phys ? sml_spectral_grid_derived_aux(d->sp, state, d->desc_phys + (size_t)(a.j2 - 1) * NB_ALL * 4, d->aux, d->batch_grid, NB_ALL, st)
+    int rc = d->phys ? sml_spectral_grid_derived_aux(d->sp, state, (phi_ready ? d->desc_phys_phi : d->desc_phys) + (size_t)(a.j2 - 1) * NB_ALL * 4, d->aux,
+                                                     d->batch_grid, NB_ALL, st)
                      : sml_spectral_grid_derived(d->sp, sj2, d->desc, d->batch_grid, NB_SPEC, st);
     if (rc) return rc;
     if (d->phys && g_physics_fused) {      // dyn_grtend.f90:80-225 in one launch: grid-point tendencies + phypar
@@ -1310,7 +1336,8 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
     rc = sml_spectral_spec_mixed(d->sp, d->tend_grid, d->tend_spec, NB_GRID, d->scale, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_spectral<true>, dim3(SP / 8), dim3(64), 0, st, d->d, d->cur->lv, a, d->tend_spec, (const double *)nullptr,
-                       tend_out, stop_after_grtend, state, d->cur->d_h, d->cur->d_x, d->bc, d->bc + SP, d->bc + 2 * SP);
+                       tend_out, stop_after_grtend, state, d->cur->d_h, d->cur->d_x, d->bc, d->bc + SP, d->bc + 2 * SP,
+                       (d->phys && leave_phi) ? d->aux + 24 + SP : (double *)nullptr);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
@@ -1398,7 +1425,7 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
     if (!rc) rc = zeros(&d->bc, (size_t)3 * SP);
     if (!rc) rc = zeros(&d->own_state, (size_t)2 * NSTATE * SP);
     if (!rc) rc = zeros(&d->batch_grid, (size_t)NB_ALL * GR);
-    if (!rc) rc = zeros(&d->aux, (size_t)24 + SP);
+    if (!rc) rc = zeros(&d->aux, (size_t)24 + SP + (size_t)KX * SP);
     if (!rc) {
         double lv[24];
         for (int k = 0; k < KX; ++k) {
@@ -1440,6 +1467,10 @@ int sml_dyn_create(sml_spectral *sp, sml_dyn **out)
         }
         if (!rc) rc = sml::dev_upload(&d->desc_phys, &kp[0][0][0], 2 * NB_ALL * 4);
         if (!rc) d->allocs.push_back(d->desc_phys);
+        for (int j2 = 0; j2 < 2; ++j2)
+            for (int f = 18; f < 26; ++f) kp[j2][NB_SPEC + f][0] = 8;          // phi level (f - 18) as k_spectral left it in aux
+        if (!rc) rc = sml::dev_upload(&d->desc_phys_phi, &kp[0][0][0], 2 * NB_ALL * 4);
+        if (!rc) d->allocs.push_back(d->desc_phys_phi);
     }
     if (rc) { sml_dyn_destroy(d); return rc; }
     *out = d;
@@ -1531,6 +1562,8 @@ int sml_dyn_set_boundary(sml_dyn *d, const double *phis_dev, const double *tcorh
     return SML_OK;
 }
 
+SML_SPAN_ATTACH(sml_span_attach_dyn)
+
 int sml_dyn_debug_stamps(unsigned long long *out)        // not part of the C-ABI (no declaration in include/): phase profiling aid
 {
     SML_HIP(hipDeviceSynchronize());
@@ -1604,7 +1637,7 @@ int sml_dyn_spectral_step(sml_dyn *d, double *state_dev, double *tend_dev, int j
     SML_REQUIRE(d->cur, "sml_dyn_spectral_step: call sml_dyn_impint first");
     StepArgs a = make_args(j1, j2, dt, alph, rob, wil);
     hipLaunchKernelGGL(k_spectral<false>, dim3(SP / 8), dim3(64), 0, sml::as_stream(stream), d->d, d->cur->lv, a, (const double *)nullptr,
-                       (const double *)tend_dev, tend_dev, 0, state_dev, d->cur->d_h, d->cur->d_x, d->bc, d->bc + SP, d->bc + 2 * SP);
+                       (const double *)tend_dev, tend_dev, 0, state_dev, d->cur->d_h, d->cur->d_x, d->bc, d->bc + SP, d->bc + 2 * SP, (double *)nullptr);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }
@@ -1682,7 +1715,9 @@ int sml_dyn_window(sml_dyn *d, double *state_dev, int start, int nsteps, double 
     if (four_launch) {
         for (size_t i = 0; i < sched.size() && !rc; ++i) {
             rc = sml_dyn_impint(d, sched[i].dt_imp, alph);
-            if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st, sched[i].lradsw);
+            // (within one window every step integrates, so step i > 0 finds the geopotential of its time level 1 where step i - 1's
+            // spectral kernel left it; the first step -- after a hand-off, or a host that touched the state -- rebuilds it)
+            if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st, sched[i].lradsw, i > 0, i + 1 < sched.size());
             if (!rc && i == 0 && start && d->guard) {       // the first step's inverse set is still in batch_grid
                 hipLaunchKernelGGL(k_range_guard, dim3((32 * GR + 255) / 256), dim3(256), 0, st, (const double *)d->batch_grid, d->guard);
                 SML_HIP(hipGetLastError());

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "common.h"
+#include "span.h"
 
 namespace {
 
@@ -150,13 +151,18 @@ void build_tables(HostTables &t, double a)
 // synthesis are both independent per latitude), zonal wavenumbers for the forward transform (the DFT is independent
 // per wavenumber and the Legendre analysis only sums over latitude within one wavenumber).  Every workgroup re-reads
 // its field from L2 (16-37 KB); nothing is exchanged between workgroups.
+// How far to split was re-decided in round 4 from per-wavefront records (profiles/micro/window_span.py): a time step's sets are 77
+// inverse and 73 forward fields, and what decides a launch is whether its workgroups exceed the 256 CUs -- a CU that holds two
+// workgroups runs both slower (they share its LDS pipe), and the launch ends with those.  3 workgroups per field keep both sets at
+// ONE workgroup per CU (231 and 219): k_grid 15.1 -> 10.8 us per launch against 6 x 512 threads (462 workgroups, 206 CUs doubly
+// occupied, together with the geopotential rows moved to the spectral step), k_spec 12.1 -> 10.4 us against 4 x 512 (292, 36 doubly).
 #ifndef SML_LATG
-#define SML_LATG 4
+#define SML_LATG 8
 #endif
 constexpr int LATG = SML_LATG;          // latitude pairs per workgroup (inverse)
-constexpr int NLG = IY / LATG;          // 6 workgroups per field
+constexpr int NLG = IY / LATG;          // 3 workgroups per field
 #ifndef SML_MG
-#define SML_MG 8
+#define SML_MG 11
 #endif
 constexpr int MG = SML_MG;              // zonal wavenumbers per workgroup (forward)
 constexpr int NMG = (MX + MG - 1) / MG; // workgroups per field
@@ -213,7 +219,10 @@ __device__ unsigned long long g_grid_dbg[16];
 #define GSTAMP(slot) do { } while (0)
 #endif
 __device__ __host__ constexpr int nsh2_of(int n) { return 2 * (NX - n) < MX2 ? 2 * (NX - n) : MX2; }
-constexpr int TG = 512;     // phase ablation: staging+launch floor 6.7 us, Legendre 2.6 us, Fourier 6.5 us at 256 threads (two
+#ifndef SML_TG
+#define SML_TG 1024
+#endif
+constexpr int TG = SML_TG;  // phase ablation: staging+launch floor 6.7 us, Legendre 2.6 us, Fourier 6.5 us at 256 threads (two
                             // rounds of the 392 Fourier items); 512 threads do them in one round
 #ifndef SML_FPW
 #define SML_FPW 1
@@ -221,7 +230,8 @@ constexpr int TG = 512;     // phase ablation: staging+launch floor 6.7 us, Lege
 constexpr int FPW = SML_FPW;            // fields per workgroup: each gets TG threads of its own, the Legendre slab is staged once
 constexpr size_t GRID_LDS = sizeof(double) * ((size_t)FPW * SPEC_N + (size_t)LATG * NX * MX + (size_t)FPW * 2 * LATG * MX2 + 2 * IX) + sizeof(int) * NX;
 // desc (optional): int32 [nf][4] = (type, src0, src1, kcos) per output field; type 0 = field src0 of vorm as it is,
-// 1..4 = derived_coeff of fields src0 (P) and src1 (Q); 7 = geopotential of level src1 from the temperature levels at src0 (needs aux)
+// 1..4 = derived_coeff of fields src0 (P) and src1 (Q); 7 = geopotential of level src1 from the temperature levels at src0 (needs aux);
+// 8 = geopotential of level src1 as the previous spectral step left it behind aux's tables (aux + 24 + SPEC_N + src1 * SPEC_N), a plain copy
 // A workgroup can serve FPW fields of one latitude group (the Legendre slab is then staged once for both).  Measured on the 77-field
 // set of a time step with physics (462 one-field workgroups, two on most CUs): FPW = 2 (231 workgroups of 1024 threads) is 1 us
 // SLOWER per launch, and the launch costs 14.2 us even when every field is a plain copy (the geopotential rows add 1.3 us) against
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
                                                     const int *__restrict__ kcos_of_field, const int *__restrict__ desc,
                                                     const double *__restrict__ aux, int nf)
 {
+    SML_SPAN(1);
     GSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) double grid_lds[];
     double *sv_all = grid_lds;                                            // [FPW][SPEC_N] spectral coefficients
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
         if (kcos_of_field) kcos = kcos_of_field[f];
         if (desc) { type = desc[4 * f]; src0 = desc[4 * f + 1]; src1 = desc[4 * f + 2]; kcos = desc[4 * f + 3]; }
     }
-    const double *v = vorm + (size_t)src0 * SPEC_N;
+    const double *v = type == 8 ? aux + 24 + SPEC_N + (size_t)src1 * SPEC_N : vorm + (size_t)src0 * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
     // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
     // Only the coefficients inside the triangular truncation are ever read below (c < nsh2(n), i.e. m < nsh2(n) / 2): staging
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     // (a wavefront stages whole rows: lane = coefficient within total wavenumber n, no index division per element)
     const int wv = tid >> 6, ln = tid & 63;
     if (active) {
-        if (type == 0) {
+        if (type == 0 || type == 8) {
             for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = v[n * MX2 + ln]; }
         } else if (type == 7) {
             for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = derived_coeff(T, 7, v, v, n, ln, src1, aux); }
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
 __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restrict__ vorg, double *__restrict__ vorm, int scale_all,
                                               const int *__restrict__ scale_of_field)
 {
+    SML_SPAN(3);
     // The field is folded about longitude index 48 while it is staged: ss = x_i + x_{96-i}, sd = x_i - x_{96-i}
     // (i = 1..47; ss[0] = x_0, ss[48] = x_48), which halves the DFT: Re_k = sum ss cos, Im_k = - sum sd sin.
     __shared__ double ss[IL][IX / 2 + 2];      // padded rows: lanes that differ in latitude hit different banks
@@ -628,6 +640,8 @@ int sml_spectral_get_table(sml_spectral *sp, int which, double *out, int capacit
     memcpy(out, src, sizeof(double) * n);
     return n;
 }
+
+SML_SPAN_ATTACH(sml_span_attach_spectral)
 
 int sml_spectral_debug_stamps(unsigned long long *out)      // not part of the C-ABI (no declaration in include/): phase profiling aid
 {
