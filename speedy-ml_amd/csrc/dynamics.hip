@@ -661,7 +661,13 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
     const double v2 = two ? s2[ov] : 0., d2 = two ? s2[od] : 0., t2 = two ? s2[ot] : 0., q2 = two ? s2[oq] : 0., p2 = two ? s2[op] : 0.;
     const double dmp = H.dmp[hm], dmpd = H.dmpd[hm], dmps = H.dmps[hm];
     const double dmp1 = imp_h[hm], dmp1d = imp_h[NX * MX + hm], dmp1s = imp_h[2 * NX * MX + hm];
-    const double tch = tcorh[e], qch = qcorh[e], tf = H.trfilt[hm];
+    const double tch = tcorh[e], qch = qcorh[e], tf = H.trfilt[hm], phis_e = phis[e];
+    // the semi-implicit operands too (a load behind the first barrier is a round trip of its own: barriers fence memory operations)
+    const int ll = m + n;
+    const double elz = imp_h[3 * NX * MX + hm];
+    double xl[KX];
+#pragma unroll
+    for (int k1 = 0; k1 < KX; ++k1) xl[k1] = (a.implicit && ll != 0) ? imp_x[128 + (size_t)(ll - 1) * 64 + k1 * KX + k] : 0.0;
     if (!stop_after_grtend) {
         // ---- sptend (src/dyn_sptend.f90) on time level j4
         const double *s4 = a.j4 == 1 ? s1 : s2;
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
         const double dumk_k1 = k < KX - 1 ? sig_k1 * (lv[LV_TREF][k < KX - 1 ? k + 1 : k] - lv[LV_TREF][k]) : 0.0;
         tdt = tdt - (dumk_k1 + dumk_k) * lv[LV_DHSR][k] + lv[LV_TREF3][k] * (sig_k1 + sig_k) - lv[LV_TREF2][k] * dmeanc;
         // geop (src/dyn_geop.f90): hydrostatic integration from the surface up to this level
-        double phi = phis[e] + lv[LV_XG1][KX - 1] * t4[KX - 1][ci];
+        double phi = phis_e + lv[LV_XG1][KX - 1] * t4[KX - 1][ci];
 #pragma unroll
         for (int j = KX - 2; j >= 0; --j)
             if (j >= k) phi = phi + lv[LV_XG2][j + 1] * t4[j + 1][ci] + lv[LV_XG1][j] * t4[j][ci];
@@ -699,11 +705,6 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
         }
         // ---- implic (src/dyn_implic.f90)
         if (a.implicit) {
-            const double elz = imp_h[3 * NX * MX + hm];
-            const int ll = m + n;
-            double xl[KX];
-#pragma unroll
-            for (int k1 = 0; k1 < KX; ++k1) xl[k1] = ll != 0 ? imp_x[128 + (size_t)(ll - 1) * 64 + k1 * KX + k] : 0.0;
             tds[k][ci] = tdt;
             __syncthreads();
             double ye = 0.;
@@ -747,35 +748,45 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
     }
     if (stop_after_grtend || !a.integrate) return;
     // ---- timint (src/dyn_step.f90:152-190): truncation, leapfrog, Robert-Asselin-Williams filter, both levels in place
-    auto timint = [&](size_t o, double f1, double f2, double fdt) {
+    auto timint = [&](double f1, double f2, double fdt, double &o1, double &o2) {
         fdt = fdt * tf;
         const double fj = two ? f2 : f1;
         const double fnew = f1 + a.dt * fdt;
         const double n1 = fj + a.wil * a.eps * (f1 - 2 * fj + fnew);
         const double fj_after = two ? fj : n1;                // field(.,1) is overwritten before field(.,2) is formed
-        s1[o] = n1;
-        s2[o] = fnew - (1 - a.wil) * a.eps * (n1 - 2 * fj_after + fnew);
-        return n1;
+        o1 = n1;
+        o2 = fnew - (1 - a.wil) * a.eps * (n1 - 2 * fj_after + fnew);
     };
-    // a column's ps is only touched by its k == 0 thread
-    timint(ov, v1, v2, vordt);
-    timint(od, d1, d2, divdt);
-    const double t1_new = timint(ot, t1, t2, tdt);
-    timint(oq, q1, q2, trdt);
-    if (k == 0) timint(op, p1, p2, psdt);
+    double nv1, nv2, nd1, nd2, nt1, nt2, nq1, nq2, np1 = 0., np2 = 0.;
+    timint(v1, v2, vordt, nv1, nv2);
+    timint(d1, d2, divdt, nd1, nd2);
+    timint(t1, t2, tdt, nt1, nt2);
+    timint(q1, q2, trdt, nq1, nq2);
+    if (k == 0) timint(p1, p2, psdt, np1, np2);       // a column's ps is only touched by its k == 0 thread
+    s1[ov] = nv1; s2[ov] = nv2;
+    s1[od] = nd1; s2[od] = nd2;
+    s1[ot] = nt1; s2[ot] = nt2;
+    s1[oq] = nq1; s2[oq] = nq2;
+    if (k == 0) { s1[op] = np1; s2[op] = np2; }
     if (phi_out) {
         // geop(1) of the time level 1 this step leaves behind (src/dyn_geop.f90:19-35): what the NEXT step's phypar reads as phig1
-        // (src/dyn_grtend.f90:222-224).  The 8 levels of a coefficient are in this workgroup anyway; the next k_grid launch then stages
-        // eight plain fields instead of rebuilding the hydrostatic chain from eight temperature levels in each of its 48 workgroups of
-        // those rows (its slowest: 14 against 9-10 us, the launch's tail).  Same expression, same order, same bits as derived_coeff 7.
-        __syncthreads();
-        t4[k][ci] = t1_new;
-        __syncthreads();
-        double phi = phis[e] + lv[LV_XG1][KX - 1] * t4[KX - 1][ci];
+        // (src/dyn_grtend.f90:222-224).  The 8 levels of a coefficient are in this wavefront anyway (lane 8 j + ci holds level j); the
+        // next k_grid launch then stages eight plain fields instead of rebuilding the hydrostatic chain from eight temperature levels in
+        // each of its workgroups of those rows (its slowest: 14 against 9-10 us, the launch's tail).  Same expression, same order, same
+        // bits as derived_coeff 7.  Lane exchange, no barrier: the chain runs while the stores above drain.
+        double tl[KX];
+#pragma unroll
+        for (int j = 0; j < KX; ++j) tl[j] = __shfl(nt1, j * 8 + ci, 64);
+        double phi = phis_e + lv[LV_XG1][KX - 1] * tl[KX - 1];
 #pragma unroll
         for (int j = KX - 2; j >= 0; --j)
-            if (j >= k) phi = phi + lv[LV_XG2][j + 1] * t4[j + 1][ci] + lv[LV_XG1][j] * t4[j][ci];
-        if (c < 2 && k >= 1 && k <= KX - 2) phi = phi + lv[LV_CORF][k] * (t4[k + 1][ci] - t4[k - 1][ci]);
+            if (j >= k) phi = phi + lv[LV_XG2][j + 1] * tl[j + 1] + lv[LV_XG1][j] * tl[j];
+        if (c < 2 && k >= 1 && k <= KX - 2) {
+            double up = 0., dn = 0.;                            // t(k+1), t(k-1) of this thread's own level (predicated picks)
+#pragma unroll
+            for (int j = 0; j < KX; ++j) { if (j == k + 1) up = tl[j]; if (j == k - 1) dn = tl[j]; }
+            phi = phi + lv[LV_CORF][k] * (up - dn);
+        }
         phi_out[(size_t)k * SP + e] = phi;
     }
 }
