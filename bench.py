@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over the 1152 local reservoirs of the T30L8 hybrid model (BASELINE.json
-config 3): batched predict of every resident reservoir, the region exchange (pack / all-gather over RCCL when
+config 3), driven by the native engine -- one sml_hybrid_step call per step, the path the Fortran drop-in ships (--host python: the same
+kernels issued call by call from Python): batched predict of every resident reservoir, the region exchange (pack / all-gather over RCCL when
 N>1 / scatter + clamps), the SPEEDY hand-off and the 6-hour SPEEDY window on the device (26 time steps: spectral
 transforms, grid-point tendencies with the column physics, semi-implicit spectral step), and the gather + standardisation
 of the next inputs.  Regions are sharded over ranks exactly as processor_decomposition does
@@ -33,6 +34,10 @@ def parse():
     ap.add_argument("--mode", default="hybrid", choices=["hybrid", "sweep", "ml_only"],
                     help="sweep = reservoir predict sweep only; ml_only = the reference's ML-only forecast loop (predict_ml + exchange, no "
                          "SPEEDY); development aids, the driver uses the default")
+    ap.add_argument("--host", default="native", choices=["native", "python"],
+                    help="who drives a hybrid step: native = ONE sml_hybrid_step call per step (csrc/hybrid.hip, the engine the Fortran drop-in's "
+                         "sendrecievegrid drives; default), python = HybridRank.step issuing the same kernels call by call (development aid; "
+                         "the only host of --mode sweep / ml_only and of SML_PIPELINE=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-training", action="store_true", help="skip the BASELINE config 4 training-kernel block (N = 1 only) of the JSON line")
     ap.add_argument("--slab", action="store_true", help="BASELINE config 5: add the 1152-region slab-ocean reservoirs and their coupling")
@@ -46,14 +51,13 @@ def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the ranks ourselves, as a CHILD
     `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU over RCCL), relay its output and
     exit code.  Nothing here touches the GPU, and the launcher is a child process, never an exec of this one."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
+    if os.environ.get("SML_BENCH_CHILD") == "1":
+        raise SystemExit("bench.py: a child of a self-launched run came up without WORLD_SIZE: refusing to launch again")
+    # --standalone: torchrun picks AND HOLDS a free port for its own c10d rendezvous (no bind-close-reuse race on a port of ours)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, SML_BENCH_CHILD="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
     print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
@@ -388,6 +392,16 @@ def main():
     model.stop_on_unsafe = not (world == 1 and args.regions != 1152)       # (--regions emulates one rank's load: its grid is not physical)
     if rank == 0:
         print(f"[bench] rank0 loaded {len(regions)} reservoirs in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
+    # The timed host: the native engine (what a Fortran host ships with) unless --host python or a schedule only the Python host has
+    python_only = args.mode != "hybrid" or model.pipeline
+    if args.host == "native" and python_only and rank == 0:
+        print("[bench] --mode sweep / ml_only and SML_PIPELINE=1 exist in the Python host only: timing HybridRank.step", file=sys.stderr, flush=True)
+    comm = None
+    host = model
+    if args.host == "native" and not python_only:
+        if world > 1:
+            comm = hybrid.make_comm(world, rank)
+        host = hybrid.NativeEngine(model, comm=comm)
 
     stream = torch.cuda.current_stream()
 
@@ -398,18 +412,18 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        model.step(stream)
+        host.step(stream)
     barrier()
-    model.timing(True)
+    host.timing(True)
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        model.step(stream)
+        host.step(stream)
     barrier()
     elapsed = time.perf_counter() - t_start
-    kern = model.timing_collect()
-    model.timing(False)
+    kern = host.timing_collect()
+    host.timing(False)
     emulated_rank = world == 1 and args.regions != 1152          # (--regions: one rank's load without its peers' outvecs -- the grid is not physical)
-    if model.aborted(wait=True) and not emulated_rank:
+    if host.aborted(wait=True) and not emulated_rank:
         raise SystemExit("bench.py: the range guard of iogrid(30) tripped -- the forecast loop stopped (src/mpires.f90:744); no number")
     # every rank's view of the step: kernel and phase times (an N-GPU line is read through these: the SPEEDY leg is replicated)
     per_rank = {"rank": rank, "regions": len(regions),
@@ -430,15 +444,16 @@ def main():
         # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md): collected by
         # profiles/collect.sh with the same bank at N=1, so it is only quoted when this run is N=1 with all 1152 regions.
-        traffic = None
+        traffic, traffic_from = None, None
         try:
             import glob
             latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[-1]
             traffic = json.load(open(latest))["kernels"]["k_readout"].get("hbm_traffic_bytes_per_launch")
+            traffic_from = os.path.relpath(latest, ROOT)
             if world != 1 or len(regions) != hybrid.NREG:
-                traffic = None
+                traffic = traffic_from = None
         except Exception:
-            traffic = None
+            traffic = traffic_from = None
         ms = elapsed / args.steps * 1e3
         upd_b, ro_b = model.bank.algorithmic_bytes()
         ro_ms = kern["readout_ms"] / max(kern["readout_launches"], 1)
@@ -455,11 +470,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": model.describe(),
+            "config": host.describe(),
             "per_rank": ranks,
             "roofline": {"bound": "hbm", "kernel": "k_readout<4,512> (W_out [local_model;x~] GEMV, all resident reservoirs)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
+                         "traffic_source": (f"{traffic_from}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect.sh), "
+                                            "a committed measurement, not taken in this run") if traffic_from else None,
                          "algorithmic_bytes_per_launch": ro_b, "avg_launch_ms": ro_ms,
                          "secondary": {"kernel": "k_update (SELL-64 [A|Win]x + tanh)", "achieved":
                                        (upd_b / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0), "unit": "GB/s",
@@ -468,10 +485,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is measured at N = 1 only (the other ranks would idle)
             line["cpu_baseline"] = cpu_baseline(model)
         if not args.no_training and world == 1 and args.mode == "hybrid":
-            del model
+            if host is not model:
+                host.close()
+            del host, model
             torch.cuda.empty_cache()
             line["training"] = training_block(not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        _lib.check(_lib.lib().sml_comm_destroy(comm))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -37,6 +37,8 @@ int sml_device_count(void);
 /* selects the GPU of this process.  One process drives one GPU (one rank per GPU): a later call with another ordinal returns
  * SML_ERR_STATE -- the library's cached streams, launch attributes and solver workspaces belong to the first device. */
 int sml_set_device(int ordinal);
+/* hipDeviceSynchronize for hosts without a HIP binding of their own (a Fortran host timing its loop) */
+int sml_device_synchronize(void);
 /* device memory for hosts without a HIP binding of their own (the Fortran drop-ins of speedy-ml_amd/fortran/): hipMalloc,
  * hipFree, hipMemset(0), synchronous hipMemcpy in either direction */
 int sml_dev_alloc(uint64_t bytes, void **out_dev);
@@ -297,6 +299,11 @@ int sml_hybrid_set_fordate_fields(sml_hybrid *h, const double *fmask_s, const do
 int sml_hybrid_initial_inputs(sml_hybrid *h, void *stream);
 int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream);
 int sml_hybrid_safe(sml_hybrid *h, int *safe_out);
+/* Device time of each phase of the steps taken through sml_hybrid_step while timing is on (HIP events on the step's stream), summed
+ * over *steps: ms5 = predict (+ predict_slab_ml when due) | rank exchange | scatter + clamps (+ SST assembly) | SPEEDY leg (iogrid(30),
+ * fordate, the window, iogrid(31)) | TISR slice + gather + standardise (+ slab inputs).  collect synchronises and resets the sums. */
+int sml_hybrid_timing(sml_hybrid *h, int on);
+int sml_hybrid_timing_collect(sml_hybrid *h, double *ms5, int *steps);
 /* ---- the `ocean_model` branches and the rank exchange inside the engine (src/mpires.f90:286-330,347-454,470-484,756-790) ----
  *   attach_slab : the rank's slab-ocean bank beside its atmosphere bank (slot i of both = region_of_slot[i]; slab slots are loaded
  *                 for SST-predicting regions only).  sea_of_slot[nslots] / sea_of_region[number_of_regions] = sst_bool_prediction;
@@ -591,7 +598,12 @@ int sml_train_symmetrize(double *c_dev, int n_aug, void *stream);
  * the LU the only solver.  c_dev is symmetrised in place either way (sml_train_accumulate fills the lower-triangle tiles only).
  * No size limits: the LU's register-resident panel kernel holds 7168 rows and taller panels go through a slower in-memory leaf; any
  * n_out (the back substitution runs in groups of 136 right-hand sides).
- * Returns SML_ERR_NUMERIC when a pivot of the LU is exactly zero (dgesv info > 0). */
+ * Returns SML_ERR_NUMERIC when a pivot of the LU is exactly zero (dgesv info > 0).
+ * Reproducibility: under the Cholesky this one-system entry (latency form: the back substitution's far rows by vector FMAs in the
+ * solving launch) and sml_train_fit_batched (far rows by an MFMA product through the mirrored factor) are DIFFERENT arithmetics for
+ * n_aug > 256 -- both at a backward error of 3-4e-17, last bits apart.  Only the batched entry gives the same bits whatever the number
+ * of systems per call; a host that needs W_out reproducible across group sizes or rank counts (the Fortran training queue, training.py)
+ * uses the batched entry for every system, also for a single one, and leaves SML_CHOL_BACKSUB_GEMM / SML_CHOL_GROUP / SML_CHOL_FUSED unset. */
 int sml_train_fit(double *c_dev, const double *b_dev, int n, int n_model, int n_out, double beta_res, double beta_model,
                   double prior_val, int using_prior, double *wout_dev, void *stream);
 

@@ -47,7 +47,7 @@ class ResSizes(C.Structure):
 
 # every symbol include/speedyml_hip.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
-    "sml_last_error", "sml_version", "sml_device_count", "sml_set_device",
+    "sml_last_error", "sml_version", "sml_device_count", "sml_set_device", "sml_device_synchronize",
     "sml_stream_create_cu_mask", "sml_stream_destroy", "sml_dev_alloc", "sml_dev_free", "sml_dev_zero", "sml_dev_upload", "sml_dev_download",
     "sml_domain_decompose", "sml_domain_region_owner", "sml_domain_region", "sml_domain_sizes", "sml_domain_out_map", "sml_domain_in_map", "sml_domain_message_sizes", "sml_domain_target_map", "sml_find_closest_divisor", "sml_calendar_date", "sml_hours_into_year", "sml_tisr_index",
     "sml_bank_create", "sml_bank_destroy", "sml_bank_load", "sml_bank_load_sparse_win", "sml_bank_set_wout",
@@ -58,7 +58,7 @@ EXPORTS = [
     "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
     "sml_comm_unique_id", "sml_comm_create", "sml_comm_bootstrap", "sml_comm_destroy", "sml_comm_allgather_outvec", "sml_comm_unpack_regions",
     "sml_hybrid_create", "sml_hybrid_destroy", "sml_hybrid_set_state", "sml_hybrid_get_state", "sml_hybrid_set_base_sst", "sml_hybrid_set_orography",
-    "sml_hybrid_set_tisr_table", "sml_hybrid_get_phis0", "sml_hybrid_set_fordate_fields", "sml_hybrid_attach_physics", "sml_hybrid_initial_inputs", "sml_hybrid_exchange_and_speedy", "sml_hybrid_safe",
+    "sml_hybrid_set_tisr_table", "sml_hybrid_get_phis0", "sml_hybrid_set_fordate_fields", "sml_hybrid_attach_physics", "sml_hybrid_initial_inputs", "sml_hybrid_exchange_and_speedy", "sml_hybrid_safe", "sml_hybrid_timing", "sml_hybrid_timing_collect",
     "sml_hybrid_g_dev", "sml_hybrid_f_dev", "sml_hybrid_attach_slab", "sml_hybrid_set_comm", "sml_hybrid_restart", "sml_hybrid_slab_due", "sml_hybrid_step",
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_predict_hybrid", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",

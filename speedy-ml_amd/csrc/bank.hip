@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
+#include <mutex>
 #include <vector>
 
 #include "bank.h"
@@ -689,12 +690,17 @@ std::vector<hipStream_t> &masked_streams()
     static std::vector<hipStream_t> *v = new std::vector<hipStream_t>;      // (never destroyed: the exit handler may run late)
     return *v;
 }
+std::mutex &registry_mutex()        // the C-ABI may be called from several host threads: the registry and sml_set_device's choice are shared
+{
+    static std::mutex *m = new std::mutex;
+    return *m;
+}
 
 void exit_cleanup()
 {
     (void)sml_train_release_workspace();
     std::vector<hipStream_t> left;
-    left.swap(masked_streams());
+    { std::lock_guard<std::mutex> lk(registry_mutex()); left.swap(masked_streams()); }
     for (hipStream_t st : left) {
         (void)hipStreamSynchronize(st);
         (void)hipStreamDestroy(st);
@@ -704,22 +710,22 @@ void exit_cleanup()
 
 int masked_stream_create(hipStream_t *out, const uint32_t *mask, int nwords)
 {
-    static bool registered = false;
+    static std::once_flag registered;
     SML_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)nwords, mask));
-    masked_streams().push_back(*out);
-    if (!registered) {
-        registered = true;
-        atexit(exit_cleanup);
-    }
+    { std::lock_guard<std::mutex> lk(registry_mutex()); masked_streams().push_back(*out); }
+    std::call_once(registered, [] { atexit(exit_cleanup); });
     return SML_OK;
 }
 
 int masked_stream_destroy(hipStream_t st)
 {
     if (!st) return SML_OK;
-    auto &v = masked_streams();
-    for (size_t i = 0; i < v.size(); ++i)
-        if (v[i] == st) { v.erase(v.begin() + i); break; }
+    {
+        std::lock_guard<std::mutex> lk(registry_mutex());
+        auto &v = masked_streams();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == st) { v.erase(v.begin() + i); break; }
+    }
     SML_HIP(hipStreamDestroy(st));
     return SML_OK;
 }
@@ -742,10 +748,17 @@ int sml_set_device(int ordinal)
     // One process drives ONE GPU (one rank per GPU): the library's cached streams, launch attributes and solver workspaces belong to
     // the device that was current when they were made.  A second device in the same process is refused rather than served wrongly.
     static int chosen = -1;
+    std::lock_guard<std::mutex> lk(sml::registry_mutex());
     if (chosen >= 0 && chosen != ordinal)
         return sml::fail(SML_ERR_STATE, "sml_set_device(%d): this process already drives device %d (one process per GPU)", ordinal, chosen);
     SML_HIP(hipSetDevice(ordinal));
     chosen = ordinal;
+    return SML_OK;
+}
+
+int sml_device_synchronize(void)
+{
+    SML_HIP(hipDeviceSynchronize());
     return SML_OK;
 }
 

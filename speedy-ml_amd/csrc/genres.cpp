@@ -96,7 +96,11 @@ long sml_makesparse_draws(int n, int k) { return (n > 0 && k >= 0) ? makesparse_
 int sml_makesparse_from_draws(int n, int k, const double *draws, long ndraws, int32_t *rows, int32_t *cols, double *vals)
 {
     SML_REQUIRE(n > 0 && k >= 0 && draws && rows && cols && vals, "sml_makesparse_from_draws: bad arguments");
-    SML_REQUIRE(ndraws >= makesparse_draw_count(n, k), "sml_makesparse_from_draws: %ld deviates supplied, %ld needed", ndraws, makesparse_draw_count(n, k));
+    const long need = makesparse_draw_count(n, k);
+    SML_REQUIRE(ndraws >= need, "sml_makesparse_from_draws: %ld deviates supplied, %ld needed", ndraws, need);
+    // the deviates index the shuffle's choice list (pick = int(a * remaining)): one outside [0, 1) -- or a NaN -- would read past it
+    for (long i = 0; i < need; ++i)
+        SML_REQUIRE(draws[i] >= 0.0 && draws[i] < 1.0, "sml_makesparse_from_draws: deviate %ld = %g is not in [0, 1)", i, draws[i]);
     Draws rng{nullptr, draws, 0};
     return makesparse_impl(n, k, rng, rows, cols, vals);
 }

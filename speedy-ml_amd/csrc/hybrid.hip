@@ -41,6 +41,9 @@ struct sml_hybrid {
     int slab_every = 0;                      // timestep_slab / timestep
     std::vector<int32_t> regions, sst_input;
     std::vector<void *> owned;
+    // phase timing (sml_hybrid_timing): six events per step on the step's stream -- start | predict | all-gather | scatter | SPEEDY leg | gather
+    bool timing = false, in_step = false;
+    std::vector<hipEvent_t> marks, spare;
 };
 
 namespace {
@@ -60,6 +63,16 @@ __global__ void k_place_rows(const double *__restrict__ outvec, const int32_t *_
     if (t >= (long)nslots * width) return;
     const int s = (int)(t / width), o = (int)(t % width);
     all_out[(long)region_of_slot[s] * width + o] = outvec[t];
+}
+
+void mark(sml_hybrid *h, hipStream_t st)
+{
+    if (!h->timing || !h->in_step) return;
+    hipEvent_t e = nullptr;
+    if (!h->spare.empty()) { e = h->spare.back(); h->spare.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    h->marks.push_back(e);
 }
 
 int upload_i32(sml_hybrid *h, int32_t **dst, const std::vector<int32_t> &v)
@@ -83,7 +96,38 @@ int sml_hybrid_destroy(sml_hybrid *h)
     if (h->phys) (void)sml_phys_destroy(h->phys);
     if (h->sp) (void)sml_spectral_destroy(h->sp);
     for (void *p : h->owned) (void)hipFree(p);
+    for (hipEvent_t e : h->marks) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->spare) (void)hipEventDestroy(e);
     delete h;
+    return SML_OK;
+}
+
+/* Per-phase device time of the steps taken through sml_hybrid_step while timing is on (HIP events on the step's stream):
+ * ms[0..4] = predict (+ predict_slab_ml when due) | rank exchange (all-gather, or placing the rank's own rows) | scatter + clamps (+ SST
+ * assembly) | SPEEDY leg (iogrid(30), fordate, the window, iogrid(31)) | TISR slice + gather + standardise (+ slab inputs), summed over
+ * *steps.  collect synchronises the device and resets the sums. */
+int sml_hybrid_timing(sml_hybrid *h, int on)
+{
+    SML_REQUIRE(h, "sml_hybrid_timing: null handle");
+    h->timing = on != 0;
+    return SML_OK;
+}
+
+int sml_hybrid_timing_collect(sml_hybrid *h, double *ms5, int *steps)
+{
+    SML_REQUIRE(h && ms5 && steps, "sml_hybrid_timing_collect: bad arguments");
+    SML_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 5; ++i) ms5[i] = 0.0;
+    const size_t n = h->marks.size() / 6;
+    for (size_t s = 0; s < n; ++s)
+        for (int i = 0; i < 5; ++i) {
+            float t = 0.f;
+            SML_HIP(hipEventElapsedTime(&t, h->marks[6 * s + i], h->marks[6 * s + i + 1]));
+            ms5[i] += t;
+        }
+    *steps = (int)n;
+    h->spare.insert(h->spare.end(), h->marks.begin(), h->marks.end());
+    h->marks.clear();
     return SML_OK;
 }
 
@@ -285,6 +329,7 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
         else { place(h->bank, h->all_out); SML_HIP(hipGetLastError()); }
         slab = h->all_out;
     }
+    mark(h, st);
     if (h->slab) {
         // the slab reservoirs' last outputs keep being gathered between their steps (src/mpires.f90:367-395); SST assembly (:309-330)
         if (h->comm) { if ((rc = sml_comm_allgather_outvec(h->comm, h->slab_bank, h->nreg, h->all_slab_out, stream))) return rc; }
@@ -292,6 +337,7 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
         if ((rc = sml_slab_scatter_sst(h->slab, h->all_slab_out, h->slab_bank->max_n_out, h->sea_of_region, h->G, stream))) return rc;
     }
     if ((rc = sml_exchange_scatter(h->ex, slab, h->G, h->base_sst, h->sea_mask, stream))) return rc;
+    mark(h, st);
     // iogrid(30)
     if ((rc = sml_handoff_to_fields(h->G, h->fields, stream))) return rc;
     if ((rc = sml_spectral_spec_mixed(h->sp, h->fields, h->raw_spec, NFIELD, h->in_scale, stream))) return rc;
@@ -319,12 +365,14 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
     // iogrid(31)
     if ((rc = sml_spectral_grid_derived(h->sp, h->state, h->out_desc, h->fields_out, NFIELD, stream))) return rc;
     if ((rc = sml_handoff_from_fields(h->fields_out, h->F, stream))) return rc;
+    mark(h, st);
     // next inputs: get_tisr_by_date(timestep - 1) (src/mpires.f90:750), then tile + standardise
     h->t += 1;
     if ((rc = tisr_to_G(h, h->t - 1, st))) return rc;
     if ((rc = sml_exchange_gather(h->ex, h->G, h->F, stream))) return rc;
     // the slab reservoirs' inputs: ring column mod(timestep - 1, R) + 1 and the running mean (src/mpires.f90:776-781)
-    if (h->slab) return sml_slab_update_inputs(h->slab, h->t, stream);
+    if (h->slab && (rc = sml_slab_update_inputs(h->slab, h->t, stream))) return rc;
+    mark(h, st);
     return SML_OK;
 }
 
@@ -340,13 +388,25 @@ int sml_hybrid_attach_slab(sml_hybrid *h, sml_bank *slab_bank, const int32_t *se
     SML_REQUIRE(timestep_slab_hours % h->timestep_hours == 0 && timestep_slab_hours / h->timestep_hours >= 2,
                 "sml_hybrid_attach_slab: timestep_slab = %d h is not a multiple (>= 2) of the %d-hour step", timestep_slab_hours, h->timestep_hours);
     SML_REQUIRE(!h->slab, "sml_hybrid_attach_slab: a slab bank is already attached");
-    h->slab_every = timestep_slab_hours / h->timestep_hours;
-    int rc = sml_slab_create(h->bank, slab_bank, h->nreg, h->regions.data(), h->nslots, sea_of_slot, h->sst_input.data(), h->slab_every - 1, &h->slab);
+    const int every = timestep_slab_hours / h->timestep_hours;
+    sml_slab *slab = nullptr;
+    int rc = sml_slab_create(h->bank, slab_bank, h->nreg, h->regions.data(), h->nslots, sea_of_slot, h->sst_input.data(), every - 1, &slab);
     if (rc) return rc;
-    h->slab_bank = slab_bank;
-    if ((rc = dalloc(h, &h->all_slab_out, (size_t)h->nreg * slab_bank->max_n_out))) return rc;
-    if ((rc = dalloc(h, &h->sea_of_region, (size_t)h->nreg))) return rc;
-    SML_HIP(hipMemcpy(h->sea_of_region, sea_of_region, sizeof(int32_t) * h->nreg, hipMemcpyHostToDevice));
+    // (the engine changes only when everything is in place: a failure below leaves it exactly as it was, free to try again)
+    double *all_slab_out = nullptr;
+    int32_t *sea_dev = nullptr;
+    if (!(rc = sml::dev_zeros(&all_slab_out, (size_t)h->nreg * slab_bank->max_n_out)) && !(rc = sml::dev_zeros(&sea_dev, (size_t)h->nreg)) &&
+        hipMemcpy(sea_dev, sea_of_region, sizeof(int32_t) * h->nreg, hipMemcpyHostToDevice) != hipSuccess)
+        rc = sml::fail(SML_ERR_HIP, "sml_hybrid_attach_slab: upload failed");
+    if (rc) {
+        if (all_slab_out) (void)hipFree(all_slab_out);
+        if (sea_dev) (void)hipFree(sea_dev);
+        (void)sml_slab_destroy(slab);
+        return rc;
+    }
+    h->owned.push_back(all_slab_out); h->owned.push_back(sea_dev);
+    h->slab = slab; h->slab_bank = slab_bank; h->slab_every = every;
+    h->all_slab_out = all_slab_out; h->sea_of_region = sea_dev;
     return SML_OK;
 }
 
@@ -385,10 +445,18 @@ int sml_hybrid_slab_due(sml_hybrid *h)
 int sml_hybrid_step(sml_hybrid *h, int leapfrog_steps, void *stream)
 {
     SML_REQUIRE(h, "sml_hybrid_step: null handle");
+    const size_t before = h->marks.size();
+    h->in_step = true;
+    mark(h, sml::as_stream(stream));
     int rc = sml_bank_predict_all(h->bank, 0, stream);
-    if (rc) return rc;
-    if (sml_hybrid_slab_due(h) && (rc = sml_bank_predict_all(h->slab_bank, 0, stream))) return rc;
-    return sml_hybrid_exchange_and_speedy(h, nullptr, leapfrog_steps, stream);
+    if (!rc && sml_hybrid_slab_due(h)) rc = sml_bank_predict_all(h->slab_bank, 0, stream);
+    mark(h, sml::as_stream(stream));
+    if (!rc) rc = sml_hybrid_exchange_and_speedy(h, nullptr, leapfrog_steps, stream);
+    h->in_step = false;
+    if (h->timing && h->marks.size() != before + 6) {          // (a failed step leaves no partial record)
+        while (h->marks.size() > before) { h->spare.push_back(h->marks.back()); h->marks.pop_back(); }
+    }
+    return rc;
 }
 
 /* run_speedy of the reference (src/mpires.f90:744): 1 while every state handed to SPEEDY passed iogrid(30)'s range guard.

@@ -36,6 +36,10 @@ module speedyml_hip
       integer(c_int), value :: ordinal
       integer(c_int) :: rc
     end function
+    function sml_device_synchronize() bind(C, name="sml_device_synchronize") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
 
     ! ---- resdomain ----
     function sml_domain_decompose(rank, nranks, number_of_regions, region_indices, capacity) bind(C, name="sml_domain_decompose") result(n)

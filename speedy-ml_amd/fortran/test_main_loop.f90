@@ -203,6 +203,9 @@ program test_main_loop
       deallocate(g, f)
     end do
   end do
+  ! ---- the same loop body, bare and timed: what a step costs through the Fortran host (SML_TEST_TIMED_STEPS iterations of
+  ! src/parallelmain.f90:207-272 -- predict for every region of the rank, then sendrecievegrid -- between two system_clock readings) ----
+  call timed_main_loop(env_default('SML_TEST_TIMED_STEPS', 0), nsteps)
   if (res%model_parameters%slab_ocean_model_bool .and. nsteps >= 28 .and. slab_loaded > 0 .and. slab_fired == 0) then
     print *, 'FAIL (4): 28 steps taken and no slab reservoir was stepped'; nfail = nfail + 1
   end if
@@ -215,6 +218,34 @@ program test_main_loop
   call killmpi()
 
 contains
+
+  subroutine timed_main_loop(ntimed, t_done)
+    integer, intent(in) :: ntimed, t_done
+    integer(kind=8) :: c0, c1, rate
+    integer :: tt, ii, jj
+    logical :: ocean
+    if (ntimed <= 0) return
+    ocean = res%model_parameters%slab_ocean_model_bool
+    call sml_check(sml_device_synchronize(), 'sml_device_synchronize')
+    call system_clock(c0, rate)
+    do tt = t_done + 1, t_done + ntimed
+      do ii = 1, res%model_parameters%num_of_regions_on_proc
+        do jj = 1, res%model_parameters%num_vert_levels
+          call predict(res%reservoir(ii,jj), res%model_parameters, res%grid(ii,jj), res%reservoir(ii,jj)%current_state, res%reservoir(ii,jj)%local_model)
+        end do
+        if (ocean) then
+          if (mod(tt * res%model_parameters%timestep, res%model_parameters%timestep_slab) == 0 .and. res%reservoir_special(ii,1)%sst_bool_prediction) &
+            call predict_slab_ml(res%reservoir_special(ii,1), res%model_parameters, res%grid_special(ii,1), res%reservoir_special(ii,1)%current_state)
+        end if
+      end do
+      call sendrecievegrid(res, tt, ocean)
+      if (.not. res%model_parameters%run_speedy) exit
+    end do
+    call sml_check(sml_device_synchronize(), 'sml_device_synchronize')
+    call system_clock(c1)
+    print '(a,i0,a,f9.4,a,i0,a)', ' timed main loop: ', ntimed, ' steps through the Fortran host, ', 1.0d3 * dble(c1 - c0) / dble(rate) / dble(ntimed), &
+          ' ms per step (', res%model_parameters%num_of_regions_on_proc, ' regions on this rank; predict x regions + sendrecievegrid, system_clock)'
+  end subroutine
 
   integer function env_default(name, default)
     character(len=*), intent(in) :: name

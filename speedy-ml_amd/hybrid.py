@@ -602,3 +602,125 @@ class HybridRank:
                                         * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
                 "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s); "
                                + ("one all-gather of the outvec slab per step" if self.world > 1 else "no collective")}
+
+
+def make_comm(world, rank):
+    """sml_comm for the native engine's rank exchange inside a torch.distributed job: RCCL (`nccl` backend) with rank 0's unique id
+    handed round through torch.distributed -- what MPI_Bcast does in an MPI host; under any other backend (several ranks sharing one
+    GPU: rehearsal, never numbers) the host-staged shared-memory transport of sml_comm_bootstrap.  Returns a c_void_p (destroy with
+    sml_comm_destroy)."""
+    import ctypes as C
+    import os
+
+    import torch.distributed as dist
+
+    from ._lib import check, lib
+    L = lib()
+    comm = C.c_void_p()
+    if dist.get_backend() == "nccl":
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            check(L.sml_comm_unique_id(ident))
+        box = [ident.raw]
+        dist.broadcast_object_list(box, src=0)
+        check(L.sml_comm_create(world, rank, box[0], C.byref(comm)))
+    else:
+        os.environ["SML_COMM_TRANSPORT"] = "shm"
+        os.environ.setdefault("SML_COMM_NONCE", os.environ.get("MASTER_PORT", "0"))
+        name = ("speedyml_bench_%s" % os.environ.get("MASTER_PORT", "0")).encode()
+        check(L.sml_comm_bootstrap(world, rank, name, C.c_uint64(0), C.byref(comm)))
+    return comm
+
+
+class NativeEngine:
+    """The native hybrid engine of the C-ABI (sml_hybrid_*, csrc/hybrid.hip) -- the device-resident body of mpires::sendrecievegrid that
+    the Fortran drop-in drives (speedy-ml_amd/fortran/mpires.f90) -- over the banks, boundary fields, tables and start state of a
+    HybridRank built for the same regions.  The Python object supplies the synthetic inputs; every step from here on is ONE C call,
+    sml_hybrid_step: predict of the resident reservoirs (+ predict_slab_ml when due), the rank exchange (sml_comm all-gather when a
+    communicator is given), scatter + clamps, iogrid(30), fordate, the 6-hour window, iogrid(31), TISR, gather + standardise."""
+
+    def __init__(self, model, comm=None):
+        import ctypes as C
+
+        from ._lib import check, dp, ip, lib
+        assert model.mode == "hybrid" and not model.pipeline
+        self.model, self.L, self.C = model, lib(), C
+        L, regions, classes = self.L, model.regions, model.classes
+        self._h = h = C.c_void_p()
+        ros = np.ascontiguousarray(regions, dtype=np.int32)
+        sst = np.array([int(classes[r][1]) for r in regions], dtype=np.int32)
+        check(L.sml_hybrid_create(model.bank._h, NREG, ip(ros), len(ros), 1, 1, ip(sst), C.byref(h)))
+        check(L.sml_hybrid_set_state(h, dp(model.G.cpu().numpy().copy())))
+        check(L.sml_hybrid_set_orography(h, dp(np.ascontiguousarray(synthetic_orography()))))
+        check(L.sml_hybrid_set_tisr_table(h, dp(np.ascontiguousarray(model.tisr.cpu().numpy())), model.start_hours, model.timestep_hours))
+        if model.phys is not None:
+            from .physics import HSG, NSTRAD
+            sia = np.asarray(model.sp.table(1)).ravel()
+            radang = np.concatenate([-np.arcsin(sia), np.arcsin(sia)[::-1]])
+            s = model.surface
+            f = lambda k: dp(np.ascontiguousarray(s[k], dtype=np.float64))
+            check(L.sml_hybrid_attach_physics(h, dp(HSG), dp(radang), f("fmask"), f("phis0"), f("tland"), f("swav"), f("alb_l"), f("alb_s"),
+                                              f("albsfc"), f("snowc"), NSTRAD))
+            check(L.sml_hybrid_set_fordate_fields(h, dp(np.ascontiguousarray(1.0 - s["fmask"])), f("alb0"), f("snowd_am"), f("sice_am")))
+        if model.slab is not None:
+            base = np.ascontiguousarray(model.base_sst.cpu().numpy())
+            mask = np.ascontiguousarray(model.sst_mask.cpu().numpy(), dtype=np.int32)
+            check(L.sml_hybrid_set_base_sst(h, dp(base), ip(mask)))
+            sea_slot = np.array([int(classes[r][1]) for r in regions], dtype=np.int32)
+            sea_reg = np.array([int(c[1]) for c in classes], dtype=np.int32)
+            check(L.sml_hybrid_attach_slab(h, model.slab_bank._h, ip(sea_slot), ip(sea_reg), 168))
+        if comm is not None:
+            check(L.sml_hybrid_set_comm(h, comm))
+        check(L.sml_hybrid_initial_inputs(h, None))
+        self.leapfrog_steps = -1 if model.leapfrog_steps is None else model.leapfrog_steps
+        self.stop_on_unsafe = True
+
+    def close(self):
+        if self._h:
+            self.L.sml_hybrid_destroy(self._h)
+            self._h = None
+
+    def step(self, stream):
+        from ._lib import check, vp
+        check(self.L.sml_hybrid_step(self._h, self.leapfrog_steps, vp(stream)))
+        return True
+
+    def safe(self):
+        """run_speedy (src/mpires.f90:744); synchronises the device"""
+        from ._lib import check
+        v = self.C.c_int()
+        check(self.L.sml_hybrid_safe(self._h, self.C.byref(v)))
+        return v.value == 1
+
+    def aborted(self, wait=False):
+        return not self.safe()
+
+    def state(self):
+        from ._lib import check, dp
+        g, f = np.zeros(domain.G_SIZE), np.zeros(domain.G_SIZE)
+        check(self.L.sml_hybrid_get_state(self._h, dp(g), dp(f)))
+        return g, f
+
+    def timing(self, on):
+        from ._lib import check
+        check(self.L.sml_bank_timing(self.model.bank._h, 1 if on else 0))
+        check(self.L.sml_hybrid_timing(self._h, 1 if on else 0))
+
+    def timing_collect(self):
+        from ._lib import check, dp
+        C = self.C
+        um, rm, uc, rc = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        check(self.L.sml_bank_timing_collect(self.model.bank._h, C.byref(um), C.byref(uc), C.byref(rm), C.byref(rc)))
+        out = {"update_ms": um.value, "update_launches": uc.value, "readout_ms": rm.value, "readout_launches": rc.value}
+        ms, n = np.zeros(5), C.c_int()
+        check(self.L.sml_hybrid_timing_collect(self._h, dp(ms), C.byref(n)))
+        if n.value:
+            out["phases_ms_per_step"] = dict(zip(("predict", "allgather", "scatter", "speedy", "gather"), (ms / n.value).tolist()))
+        return out
+
+    def describe(self):
+        d = self.model.describe()
+        d["host"] = "native engine: one sml_hybrid_step call per step (csrc/hybrid.hip), what the Fortran drop-in's sendrecievegrid drives"
+        if self.model.world > 1:
+            d["parallelism"] = d["parallelism"].replace("one all-gather", "one sml_comm (RCCL) all-gather")
+        return d

@@ -101,6 +101,12 @@ def test_makesparse_index_construction_bit_exact_for_supplied_draws(oracle, n, k
     # too few deviates: refused, not read past the end
     with pytest.raises(_lib.SmlError):
         _lib.check(L.sml_makesparse_from_draws(n, k, _lib.dp(draws), C.c_long(nd - 1), _lib.ip(rows), _lib.ip(cols), _lib.dp(vals)))
+    # a deviate outside [0, 1) would index past the shuffle's choice list: refused (1.0, a negative value, NaN), wherever it sits
+    for pos, bad in ((k + 3, 1.0), (nd - 1, -0.25), (0, float("nan"))):
+        spoiled = draws.copy()
+        spoiled[pos] = bad
+        with pytest.raises(_lib.SmlError, match="not in"):
+            _lib.check(L.sml_makesparse_from_draws(n, k, _lib.dp(spoiled), C.c_long(nd), _lib.ip(rows), _lib.ip(cols), _lib.dp(vals)))
 
 
 def test_spectral_radius_of_the_config2_matrix_against_arpack():
