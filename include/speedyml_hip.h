@@ -193,6 +193,12 @@ int sml_bank_advance_all(sml_bank *bank, void *stream);
  * the SPEEDY window; bit4 (16) launches a full-occupancy kernel that drains the SAME work queue (call it, on any stream,
  * once the overlapped work is done; part 1 is complete when both launches have finished). */
 int sml_bank_readout_part(sml_bank *bank, int part, int flags, void *stream);
+/* predict's split readout, `outvec_component_contribs` (src/mod_reservoir.f90:1458-1461): after a predict of every slot (state
+ * advanced, local_model still the step's), v_ml = W_out[:, n_model:] x~ and v_p = W_out[:, :n_model] local_model of every slot, both
+ * left standardised as the reference leaves them; v_p + v_ml = the readout before unstandardize_state_vec_res (<= 1e-13: the column
+ * sum is associated differently).  get_contribs: host copies of one slot's two vectors (either may be NULL). */
+int sml_bank_outvec_contribs(sml_bank *bank, void *stream);
+int sml_bank_get_contribs(sml_bank *bank, int slot, double *v_p, double *v_ml);
 
 /* byte accounting for the roofline (algorithmic bytes as defined in DESIGN.md) */
 int sml_bank_algorithmic_bytes(sml_bank *bank, uint64_t *update_bytes, uint64_t *readout_bytes);

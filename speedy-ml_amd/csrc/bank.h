@@ -39,6 +39,7 @@ struct sml_bank {
     std::vector<sml::HostRes> res;
     sml::ResDesc *d_descs = nullptr;
     double *d_feedback = nullptr, *d_local_model = nullptr, *d_outvec = nullptr, *d_partial = nullptr;
+    double *d_vp = nullptr;            // [capacity][max_n_out] physics-model block of the readout (sml_bank_outvec_contribs), made on first use
     unsigned *d_counter = nullptr;     // work counter of the persistent readout
     bool descs_dirty = true;
     bool timing = false;

@@ -585,6 +585,21 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     return SML_OK;
 }
 
+// v_p = matmul(wout(:, 1:chunk_size_speedy), local_model) (src/mod_reservoir.f90:1459): the physics-model columns of the readout alone,
+// standardised like v_ml.  132 columns x 136 rows per reservoir: one wavefront per output row, diagnostics only.
+__global__ __launch_bounds__(64) void k_vp(const ResDesc *__restrict__ descs, const double *__restrict__ lm_all, int lm_stride, double *__restrict__ vp, int out_stride)
+{
+    const ResDesc &D = descs[blockIdx.y];
+    const int o = blockIdx.x;
+    if (!D.loaded || o >= D.n_out) return;
+    const double *w = D.wout + (size_t)o * D.n_aug_pad, *lm = lm_all + (size_t)blockIdx.y * lm_stride;
+    double acc = 0.0;
+    for (int c = threadIdx.x; c < D.n_model; c += 64) acc += w[c] * lm[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (threadIdx.x == 0) vp[(size_t)blockIdx.y * out_stride + o] = acc;
+}
+
 int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream_t st)
 {
     // <rows per workgroup, threads>, non-temporal 16-byte loads.  Round 3 (profiles/micro/sweep_readout_variants.sh, event-timed, ms at
@@ -835,7 +850,7 @@ int sml_bank_destroy(sml_bank *b)
 {
     if (!b) return SML_OK;
     for (auto &r : b->res) free_slot(r);
-    (void)hipFree(b->d_descs); (void)hipFree(b->d_feedback); (void)hipFree(b->d_local_model); (void)hipFree(b->d_outvec); (void)hipFree(b->d_partial);
+    (void)hipFree(b->d_descs); (void)hipFree(b->d_feedback); (void)hipFree(b->d_local_model); (void)hipFree(b->d_outvec); (void)hipFree(b->d_partial); if (b->d_vp) (void)hipFree(b->d_vp);
     if (b->d_counter) (void)hipFree(b->d_counter);
     for (auto &t : b->train_states)
         if (t.first) (void)hipFree(t.first);
@@ -929,6 +944,35 @@ int sml_bank_get_outvec(sml_bank *bank, int slot, double *out)
 {
     BANK_SLOT(bank, slot);
     SML_HIP(hipMemcpy(out, bank->d_outvec + (size_t)slot * bank->max_n_out, sizeof(double) * D.n_out, hipMemcpyDeviceToHost));
+    return SML_OK;
+}
+
+/* predict's split readout (src/mod_reservoir.f90:1458-1461, outvec_component_contribs): after a predict of every slot, v_ml =
+ * W_out[:, n_model:] x~ (the state block of the readout, its own launch over the state columns) and v_p = W_out[:, :n_model]
+ * local_model, both standardised as in the reference (which un-standardises outvec only); v_p + v_ml = the readout before
+ * unstandardize_state_vec_res up to the association of the column sum.  Call while local_model still holds the step's values. */
+int sml_bank_outvec_contribs(sml_bank *b, void *stream)
+{
+    SML_REQUIRE(b, "sml_bank_outvec_contribs: null bank");
+    int rc = sync_descs(b);
+    if (rc) return rc;
+    hipStream_t st = sml::as_stream(stream);
+    for (auto &h : b->res)       // (the state block of the readout starts at an even column: 132 and 0 as shipped)
+        SML_REQUIRE(!h.desc.loaded || h.desc.n_model % 2 == 0, "sml_bank_outvec_contribs: a slot has an odd number of model columns (%d)", h.desc.n_model);
+    if (!b->d_vp && (rc = sml::dev_zeros(&b->d_vp, (size_t)b->capacity * b->max_n_out))) return rc;
+    if ((rc = launch_readout(b, 0, b->capacity, 2, st))) return rc;                   // part 1: the state block -> d_partial
+    hipLaunchKernelGGL(k_vp, dim3(b->max_n_out_loaded, b->capacity), dim3(64), 0, st, (const ResDesc *)b->d_descs, (const double *)b->d_local_model,
+                       b->max_n_model, b->d_vp, b->max_n_out);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_bank_get_contribs(sml_bank *bank, int slot, double *v_p, double *v_ml)
+{
+    BANK_SLOT(bank, slot);
+    SML_REQUIRE(bank->d_vp, "sml_bank_get_contribs: sml_bank_outvec_contribs has not run");
+    if (v_p) SML_HIP(hipMemcpy(v_p, bank->d_vp + (size_t)slot * bank->max_n_out, sizeof(double) * D.n_out, hipMemcpyDeviceToHost));
+    if (v_ml) SML_HIP(hipMemcpy(v_ml, bank->d_partial + (size_t)slot * bank->max_n_out, sizeof(double) * D.n_out, hipMemcpyDeviceToHost));
     return SML_OK;
 }
 

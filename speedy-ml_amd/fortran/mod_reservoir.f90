@@ -543,20 +543,27 @@ contains
   end subroutine
 
   ! predict / predict_ml: the first call of a time step advances and reads out EVERY resident reservoir
-  subroutine batched_predict(reservoir, x)
+  subroutine batched_predict(reservoir, x, contribs)
     type(reservoir_type), intent(inout) :: reservoir
     real(kind=dp), intent(inout) :: x(:)
+    logical, intent(in) :: contribs
     integer :: s
     s = reservoir%hip_slot + 1
     if (slot_predicted(s) .or. hip_predicted == 0) then                  ! a slot seen twice, or nobody yet: a new time step begins
       slot_predicted = .false.
       hip_predicted = 0
       call sml_check(sml_bank_predict_all(hip_bank, 0_c_int, c_null_ptr), 'sml_bank_predict_all')
+      ! outvec_component_contribs (src/mod_reservoir.f90:1458-1461): the two column blocks of the readout apart, for every slot at once
+      if (contribs) call sml_check(sml_bank_outvec_contribs(hip_bank, c_null_ptr), 'sml_bank_outvec_contribs')
     end if
     slot_predicted(s) = .true.
     hip_predicted = hip_predicted + 1
     if (hip_predicted == hip_loaded) hip_predicted = 0
     if (host_mirror) call hip_fetch(reservoir, x)
+    if (contribs) then          ! reservoir%v_p, reservoir%v_ml (standardised, as the reference leaves them)
+      if (.not. allocated(reservoir%v_p)) allocate(reservoir%v_p(reservoir%chunk_size_prediction), reservoir%v_ml(reservoir%chunk_size_prediction))
+      call sml_check(sml_bank_get_contribs(hip_bank, reservoir%hip_slot, reservoir%v_p, reservoir%v_ml), 'sml_bank_get_contribs')
+    end if
   end subroutine
 
   ! reservoir%outvec (un-standardised) and the state x of this reservoir from the device
@@ -573,7 +580,7 @@ contains
     type(grid_type), intent(inout) :: grid
     real(kind=dp), intent(inout) :: x(:)
     real(kind=dp), intent(inout) :: local_model_in(:)
-    call batched_predict(reservoir, x)
+    call batched_predict(reservoir, x, model_parameters%outvec_component_contribs)
   end subroutine
 
   subroutine predict_ml(reservoir, model_parameters, grid, x)
@@ -581,7 +588,7 @@ contains
     type(model_parameters_type), intent(in) :: model_parameters
     type(grid_type), intent(inout) :: grid
     real(kind=dp), intent(inout) :: x(:)
-    call batched_predict(reservoir, x)
+    call batched_predict(reservoir, x, .false.)          ! (predict_ml has no model block: src/mod_reservoir.f90:1491-1535)
   end subroutine
 
 end module mod_reservoir

@@ -181,19 +181,20 @@ contains
     internal_state_vector%is_safe_to_run_speedy = safe /= 0
   end subroutine
 
-  ! send_outvec_ml_contrib / send_outvec_speedy_contrib (src/mpires.f90:1076-1330): NetCDF diagnostics of the split readout
-  ! (W_out's reservoir columns and physics-model columns apart), only reached with outvec_component_contribs = .true. (off as
-  ! shipped, src/mod_reservoir.f90:71).  Diagnostics and output are outside the hot path (SURVEY section 2.1 #4): asking for them stops.
+  ! send_outvec_ml_contrib / send_outvec_speedy_contrib (src/mpires.f90:1076-1330): the root tiles every region's v_ml / v_p into global
+  ! grids and writes them with write_netcdf, only reached with outvec_component_contribs = .true. (off as shipped,
+  ! src/mod_reservoir.f90:71).  The two products themselves are part of predict and ARE computed (reservoir%v_p, reservoir%v_ml,
+  ! mod_reservoir::predict -> sml_bank_outvec_contribs); what stops here is the NetCDF writer (out of scope, SURVEY section 2.1 #4).
   subroutine send_outvec_ml_contrib(res, timestep)
     type(main_type), intent(inout) :: res
     integer, intent(in) :: timestep
-    stop 'mpires: outvec_component_contribs (NetCDF diagnostics of the split readout) is not part of the MI355X drop-in'
+    stop 'mpires: the NetCDF writer behind send_outvec_*_contrib is not part of the MI355X drop-in (reservoir%v_p / v_ml are filled by predict)'
   end subroutine
 
   subroutine send_outvec_speedy_contrib(res, timestep)
     type(main_type), intent(inout) :: res
     integer, intent(in) :: timestep
-    stop 'mpires: outvec_component_contribs (NetCDF diagnostics of the split readout) is not part of the MI355X drop-in'
+    stop 'mpires: the NetCDF writer behind send_outvec_*_contrib is not part of the MI355X drop-in (reservoir%v_p / v_ml are filled by predict)'
   end subroutine
 
 end module mpires

@@ -320,6 +320,18 @@ module speedyml_hip
       real(c_double), intent(out) :: out(*)
       integer(c_int) :: rc
     end function
+    function sml_bank_outvec_contribs(bank, stream) bind(C, name="sml_bank_outvec_contribs") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: bank, stream
+      integer(c_int) :: rc
+    end function
+    function sml_bank_get_contribs(bank, slot, v_p, v_ml) bind(C, name="sml_bank_get_contribs") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: bank
+      integer(c_int), value :: slot
+      real(c_double), intent(out) :: v_p(*), v_ml(*)
+      integer(c_int) :: rc
+    end function
     function sml_bank_predict_all(bank, flags, stream) bind(C, name="sml_bank_predict_all") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: bank, stream

@@ -45,6 +45,7 @@ program test_main_loop
   call startmpi()
   call initialize_model_parameters(res%model_parameters, mpi_res%proc_num, mpi_res%numprocs)
   res%model_parameters%slab_ocean_model_bool = env_default('SML_TEST_SLAB', 1) /= 0
+  res%model_parameters%outvec_component_contribs = env_default('SML_TEST_CONTRIBS', 0) /= 0        ! predict also fills v_p / v_ml
   nsteps = env_default('SML_TEST_STEPS', 2)
   npred = env_default('SML_TEST_PREDICTIONS', 1)
   if (npred /= res%model_parameters%num_predictions) then
@@ -157,6 +158,21 @@ program test_main_loop
         call one_slot_predict(res%reservoir(probe,1), res%grid(probe,1), x0, fb0, lm0, out_one)
         if (any(out_one /= res%reservoir(probe,1)%outvec) .or. any(x0 /= res%reservoir(probe,1)%current_state)) then
           print *, 'FAIL (1) step', t, maxval(abs(out_one - res%reservoir(probe,1)%outvec)); nfail = nfail + 1
+        end if
+        ! ---- check (6): outvec_component_contribs -- v_p is the physics-model block of the readout on the inputs of this step ----
+        if (res%model_parameters%outvec_component_contribs) then
+          if (.not. allocated(res%reservoir(probe,1)%v_p) .or. .not. allocated(res%reservoir(probe,1)%v_ml)) then
+            print *, 'FAIL (6): predict left v_p / v_ml unallocated'; nfail = nfail + 1
+          else
+            want = matmul(res%reservoir(probe,1)%wout(:, 1:res%reservoir(probe,1)%chunk_size_speedy), lm0(1:res%reservoir(probe,1)%chunk_size_speedy))
+            if (maxval(abs(want - res%reservoir(probe,1)%v_p)) > 1.0e-12_dp * max(1.0_dp, maxval(abs(want))) .or. &
+                .not. all(res%reservoir(probe,1)%v_ml == res%reservoir(probe,1)%v_ml) .or. maxval(abs(res%reservoir(probe,1)%v_ml)) == 0.0_dp) then
+              print *, 'FAIL (6) step', t, maxval(abs(want - res%reservoir(probe,1)%v_p)); nfail = nfail + 1
+            else if (t == 1) then
+              print *, 'split readout of region 954: |v_p| max', maxval(abs(res%reservoir(probe,1)%v_p)), ' |v_ml| max', maxval(abs(res%reservoir(probe,1)%v_ml))
+            end if
+            deallocate(want)
+          end if
         end if
       end if
 

@@ -121,6 +121,16 @@ class ReservoirBank:
         part 2 = physics-model columns + un-standardisation -> outvec.  advance(); readout_part(1); readout_part(2) == predict()."""
         check(_lib.lib().sml_bank_readout_part(self._h, int(part), (1 if raw else 0) | (8 if persistent else 0) | (16 if drain else 0), vp(stream)))
 
+    def outvec_contribs(self, stream=None):
+        """predict's split readout (outvec_component_contribs, src/mod_reservoir.f90:1458-1461) for every slot: call after predict()"""
+        check(_lib.lib().sml_bank_outvec_contribs(self._h, vp(stream)))
+
+    def get_contribs(self, slot):
+        """(v_p, v_ml) of one slot: the physics-model block and the reservoir-state block of the readout, standardised"""
+        v_p, v_ml = np.zeros(self.shapes[slot][3]), np.zeros(self.shapes[slot][3])
+        check(_lib.lib().sml_bank_get_contribs(self._h, slot, dp(v_p), dp(v_ml)))
+        return v_p, v_ml
+
     def synchronize(self, inputs_dev_ptr, length, stream=None):
         """synchronize (src/mod_reservoir.f90:1354-1381); inputs: device [length][capacity][max_d]."""
         check(_lib.lib().sml_bank_synchronize_all(self._h, dp(int(inputs_dev_ptr)), length, vp(stream)))

@@ -59,8 +59,9 @@ def test_fortran_module_api_runs_program_mains_loop(tmp_path):
     state, run_speedy, the batched predict_slab_ml against the slab step written out on the host and its SST in the hybrid state, and
     the TISR slice after the engine's restart for the second forecast."""
     out = _run("test_main_loop", dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="30", SML_TEST_PREDICTIONS="2", SML_TEST_ERA_HOURS="800",
-                                      SML_TEST_DUMP=str(tmp_path / "one.bin")))
+                                      SML_TEST_DUMP=str(tmp_path / "one.bin"), SML_TEST_CONTRIBS="1", SML_TEST_TIMED_STEPS="5"))
     assert "main loop parity OK" in out and "slab predict_slab_ml of region" in out
+    assert "split readout of region 954" in out and "timed main loop: 5 steps" in out        # outvec_component_contribs: predict filled v_p / v_ml
 
 
 def test_fortran_main_loop_two_ranks_equal_one_rank(tmp_path):

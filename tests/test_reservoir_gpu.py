@@ -87,6 +87,42 @@ def test_config2_single_reservoir_full_size(oracle):
     assert np.array_equal(bank.get_state(0), x1)
 
 
+def test_split_readout_contributions(oracle):
+    """outvec_component_contribs (src/mod_reservoir.f90:1458-1461): v_p = wout(:, 1:132) local_model and v_ml = wout(:, 133:) x~ of every
+    slot after a predict, left standardised as the reference leaves them; v_p + v_ml is the readout before un-standardisation.  Full-size
+    region 954 beside two small reservoirs."""
+    g = domain.initializedomain(1152, 954)
+    s = domain.allocate_res_sizes(g)
+    _, stat = domain.out_map(1152, 954)
+    rs = [make_reservoir(n=s.n, d=s.reservoir_numinputs, n_model=132, n_out=136, seed=20240954),
+          make_reservoir(n=1152, d=576, n_model=132, n_out=136, seed=2), make_reservoir(n=560, d=560, n_model=132, n_out=136, seed=3)]
+    bank = ReservoirBank(len(rs))
+    rng = np.random.default_rng(8)
+    x0 = [rng.standard_normal(r.n) * 0.2 for r in rs]
+    for i, r in enumerate(rs):
+        load(bank, i, r, stat)
+        bank.set_state(i, x0[i])
+        bank.set_feedback(i, r.feedback)
+        bank.set_local_model(i, r.local_model)
+    with pytest.raises(Exception):
+        bank.get_contribs(0)                        # nothing computed yet: an error, not stale memory
+    bank.predict()
+    bank.outvec_contribs()
+    torch.cuda.synchronize()
+    for i, r in enumerate(rs):
+        xw, raw = oracle.predict_raw(r.n, r.d, r.n_model, r.n_out, r.rows, r.cols, r.vals, r.win, r.wout, 1.0, r.feedback, r.local_model, x0[i])
+        xt = xw.copy()
+        xt[1::2] = xt[1::2] ** 2                     # x_temp(2:n:2) ** 2
+        v_p, v_ml = bank.get_contribs(i)
+        sc = np.max(np.abs(raw))
+        assert np.max(np.abs(v_p - r.wout[:, :132] @ r.local_model)) <= 1e-13 * sc
+        assert np.max(np.abs(v_ml - r.wout[:, 132:] @ xt)) <= 1e-13 * sc
+        assert np.max(np.abs(v_p + v_ml - raw)) <= 1e-13 * sc, i
+        # and the bank's own (un-standardised) outvec is what un-standardising their sum gives
+        want = oracle.unstandardize_res(oracle.initializedomain(1152, 954), r.mean, r.std, v_p + v_ml)
+        assert np.max(np.abs(bank.get_outvec(i) - want)) <= OUT_TOL * np.max(np.abs(want))
+
+
 def test_leakage_and_duplicates(oracle):
     r = make_reservoir(n=256, d=16, n_model=4, n_out=6, seed=9, deg=60)
     q = r.k // 4
