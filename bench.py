@@ -288,6 +288,14 @@ def training_block(with_cpu):
                          "reservoirs_per_s_shipped_config": 1.0 / per_res,
                          "note": "shipped config: 120 batches of m = 98 per reservoir (12000 h, 6 interleaved passes) + one ridge solve (16 systems in lockstep, Cholesky)"}
     bank.close()
+    del noisy, models, targs, cs8, bs8
+    torch.cuda.empty_cache()
+    # BASELINE config 4 END TO END at the size it is quoted on (40 years = 350 640 hourly columns, six passes of 20 batches of m = 2920
+    # per reservoir + the ridge solves): 16 resident full-size reservoirs through training.train_reservoirs_device, inputs generated on
+    # the device (profiles/train_40yr.py; 64 residents reach 0.28 s per reservoir, profiles/r4_train_40yr_64_residents.json)
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from train_40yr import run as train_40yr
+    out["train_pass_40yr"] = train_40yr(16, verbose=False, compare_m98=False)
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _oracle import Oracle

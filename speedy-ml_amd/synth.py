@@ -154,3 +154,26 @@ def land_mask(seed=1):
     for _ in range(6):
         f = (f + np.roll(f, 1, 0) + np.roll(f, -1, 0) + np.roll(f, 1, 1) + np.roll(f, -1, 1)) / 5.0
     return (f < np.quantile(f, 0.7)).astype(np.int32)
+
+
+def ar1_series_device(length, width, phi=0.98, seed=0, chunk=1024, device="cuda"):
+    """ERA5-shaped synthetic training inputs generated ON the device: `width` independent stationary AR(1)
+    series of `length` hourly samples, x_t = phi x_{t-1} + sqrt(1 - phi^2) eps_t, unit variance (standardised inputs), as one float64
+    tensor [length, width].  Time is the sequential dimension: a chunk of L steps is one lower-triangular Toeplitz product
+    X = phi^(1..L) x_prev + T eps on the matrix cores, so 350 640 hours x 9216 columns take a few hundred launches, not 350 640."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    out = torch.empty((length, width), dtype=torch.float64, device=device)
+    k = torch.arange(chunk, dtype=torch.float64, device=device)
+    lag = k[:, None] - k[None, :]
+    toep = torch.where(lag >= 0, phi ** lag.clamp(min=0), torch.zeros((), dtype=torch.float64, device=device)) * (1.0 - phi * phi) ** 0.5
+    carry = phi ** (k + 1.0)
+    prev = torch.randn((width,), dtype=torch.float64, device=device, generator=g)          # stationary start
+    for t0 in range(0, length, chunk):
+        n = min(chunk, length - t0)
+        eps = torch.randn((n, width), dtype=torch.float64, device=device, generator=g)
+        blk = toep[:n, :n] @ eps + carry[:n, None] * prev[None, :]
+        out[t0:t0 + n] = blk
+        prev = blk[n - 1].clone()
+    return out

@@ -109,6 +109,78 @@ def train_reservoirs(bank, specs, traininglength, discardlength, timestep, beta_
     return out
 
 
+def train_reservoirs_device(bank, specs, hourly, traininglength, discardlength, timestep, noisemag=0.2, model_sigma=0.3, seed=0,
+                            beta_res=0.001, beta_model=1.0, prior_val=0.0, using_prior=True, noisy_of_pass=None, model_of_pass=None,
+                            keep_gram=False, stream=None, progress=None):
+    """train_reservoirs with the training data RESIDENT on the device -- the form for BASELINE config 4 at its quoted size (40 years =
+    350 640 hourly columns: 1.6 GB per reservoir, which a host loop of numpy slices cannot feed).  hourly: float64 CUDA tensor
+    [traininglength, capacity, max_d], the clean standardised inputs of every slot (slot s uses its first d columns).  Per pass i of the
+    `timestep` interleaved passes (trainingdata(:, i:traininglength:timestep), src/mod_reservoir.f90:289-301) the strided slice is made
+    contiguous, the input noise is applied (gaussian_noise_1d_function: x + g noisemag x, src/mod_utilities.f90:1387-1409; deviates from
+    a seeded device generator), the imperfect model is truth + N(0, model_sigma^2) on the slot's target rows, and
+    ReservoirBank.train_pass runs the recurrence + Gram updates; then one ridge solve per slot, size classes in lockstep.
+    specs: per slot dict(n, n_model, n_out, target_rows) or None.  noisy_of_pass(i, clean_pass) / model_of_pass(i, slot, truth_pass)
+    override the two random draws (tests feed the host path the same numbers).  keep_gram: also return C and B (device, column-major).
+    Returns {slot: dict(wout, batch_size, batches[, c, b])}."""
+    import torch
+    assert traininglength % timestep == 0 and discardlength % timestep == 0
+    assert hourly.is_cuda and hourly.dtype == torch.float64 and tuple(hourly.shape) == (traininglength, bank.capacity, bank.max_d)
+    batch = chunk_batch_size(traininglength, discardlength, timestep)
+    discard = discardlength // timestep
+    cap = bank.capacity
+    dev = hourly.device
+    cs, bs = [None] * cap, [None] * cap
+    rows_dev = [None] * cap
+    for slot, sp in enumerate(specs):
+        if sp is None:
+            continue
+        n_aug = sp["n"] + sp["n_model"]
+        cs[slot] = train.fortran_zeros(n_aug, n_aug)
+        bs[slot] = train.fortran_zeros(sp["n_out"], n_aug)
+        rows_dev[slot] = torch.as_tensor(np.asarray(sp["target_rows"]), dtype=torch.long, device=dev)
+    gen = torch.Generator(device=dev)
+    nb_total = 0
+    for i in range(timestep):
+        clean = hourly[i::timestep].contiguous()                                    # [T_pass, cap, max_d]
+        gen.manual_seed(int(seed) * 1000 + i)
+        if noisy_of_pass is not None:
+            noisy = noisy_of_pass(i, clean)
+        else:
+            noisy = clean + torch.randn(clean.shape, dtype=torch.float64, device=dev, generator=gen) * noisemag * clean
+        models, targets = [None] * cap, [None] * cap
+        for slot, sp in enumerate(specs):
+            if sp is None:
+                continue
+            truth = clean[:, slot, :].index_select(1, rows_dev[slot]).contiguous()        # (n_out, T_pass) column-major = torch [T_pass, n_out]
+            targets[slot] = truth
+            if sp["n_model"]:
+                if model_of_pass is not None:
+                    models[slot] = model_of_pass(i, slot, truth)
+                else:
+                    models[slot] = (truth[:, :sp["n_model"]] + model_sigma * torch.randn((truth.shape[0], sp["n_model"]), dtype=torch.float64, device=dev,
+                                                                                         generator=gen)).contiguous()
+        nb = bank.train_pass(noisy, discard, batch, models, targets, cs, bs, stream=stream)
+        nb_total += nb
+        del noisy, clean, models, targets
+        if progress is not None:
+            progress(i, nb)
+    out, classes = {}, {}
+    for slot, sp in enumerate(specs):
+        if sp is not None:
+            classes.setdefault((sp["n"], sp["n_model"], sp["n_out"]), []).append(slot)
+    for (n, n_model, n_out), slots in classes.items():
+        wouts = train.fit_chunk_hybrid_batched([cs[s] for s in slots], [bs[s] for s in slots], n, n_model, n_out, beta_res, beta_model,
+                                               prior_val, using_prior, stream=stream)
+        torch.cuda.synchronize()
+        for slot, wout in zip(slots, wouts):
+            host = np.asfortranarray(wout.cpu().numpy().T)
+            bank.set_wout(slot, host)
+            out[slot] = dict(wout=host, batch_size=batch, batches=nb_total // timestep)
+            if keep_gram:
+                out[slot].update(c=cs[slot], b=bs[slot], wout_dev=wout)
+    return out
+
+
 def shard_plan(rank, world, number_of_regions, group=64):
     """The regions rank `rank` of `world` trains, in bank-sized groups: processor_decomposition (src/res_domain.f90:31-62) exactly as
     program main's training loop uses it (src/parallelmain.f90:82-128), cut into groups of `group` reservoirs that are resident

@@ -128,3 +128,62 @@ def test_train_reservoir_end_to_end(oracle, tmp_path):
     x1, out = oracle.predict_raw(n, d, n_model, n_out, w["rows"], w["cols"], w["vals"], w["win"], w["wout"], 1.0, u7, m8, x0)
     assert np.max(np.abs(bank.get_state(0) - x1)) <= 1e-13
     assert np.max(np.abs(bank.get_outvec(0) - out)) <= 1e-11 * np.max(np.abs(out))
+
+
+def test_device_resident_training_equals_the_host_fed_path():
+    """train_reservoirs_device (the data resident on the device: the form BASELINE config 4 needs at 350 640 hourly columns) against
+    train_reservoirs fed from host arrays with the SAME noise and imperfect-model numbers: same kernels, same order -> W_out bit for bit.
+    Two slots of different size classes, one empty slot between them; the series comes from the device AR(1) generator."""
+    from speedy_ml_amd import synth
+    L, disc, ts = 1236, 36, 6
+    d, n_model, n_out = 576, 132, 136
+    rows_t = domain.target_map(NREG, REGION)
+    sizes = {0: 576, 2: 1152}
+    bank_d = ReservoirBank(3, max_d=d, max_n_model=n_model, max_n_out=n_out)
+    bank_h = ReservoirBank(3, max_d=d, max_n_model=n_model, max_n_out=n_out)
+    stat = np.full(n_out, -1, dtype=np.int32)
+    specs = [None, None, None]
+    for slot, n in sizes.items():
+        r = make_reservoir(n=n, d=d, n_model=n_model, n_out=n_out, seed=40 + slot)
+        for b in (bank_d, bank_h):
+            b.load(slot, n, d, n_model, n_out, r.rows, r.cols, r.vals, r.win, np.zeros((n_out, n + n_model)), r.mean, r.std, stat)
+        specs[slot] = dict(n=n, n_model=n_model, n_out=n_out, target_rows=rows_t)
+    hourly = synth.ar1_series_device(L, 3 * d, phi=0.95, seed=3, chunk=256).reshape(L, 3, d).contiguous()
+    # stationary, unit variance, the right memory
+    h = hourly.reshape(L, -1)
+    assert abs(float(h.var()) - 1.0) < 0.1 and abs(float((h[1:] * h[:-1]).mean() / h.var()) - 0.95) < 0.02
+    drawn = {}
+
+    def noisy_of_pass(i, clean):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(100 + i)
+        drawn[("noisy", i)] = clean + torch.randn(clean.shape, dtype=torch.float64, device="cuda", generator=g) * 0.2 * clean
+        return drawn[("noisy", i)]
+
+    def model_of_pass(i, slot, truth):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1000 + 10 * i + slot)
+        drawn[("model", i, slot)] = (truth[:, :n_model] + 0.3 * torch.randn((truth.shape[0], n_model), dtype=torch.float64, device="cuda", generator=g)).contiguous()
+        return drawn[("model", i, slot)]
+
+    res_d = training.train_reservoirs_device(bank_d, specs, hourly, L, disc, ts, noisy_of_pass=noisy_of_pass, model_of_pass=model_of_pass, keep_gram=True)
+    host = hourly.cpu().numpy()
+    hspecs = [None, None, None]
+    for slot in sizes:
+        noisy = np.zeros((d, L))
+        model = np.zeros((n_model, L))
+        for i in range(ts):
+            noisy[:, i::ts] = drawn[("noisy", i)][:, slot, :].cpu().numpy().T
+            model[:, i::ts] = drawn[("model", i, slot)].cpu().numpy().T
+        hspecs[slot] = dict(specs[slot], trainingdata=noisy, clean=np.ascontiguousarray(host[:, slot, :].T), imperfect_model=model)
+    res_h = training.train_reservoirs(bank_h, hspecs, L, disc, ts)
+    for slot in sizes:
+        assert res_d[slot]["batch_size"] == res_h[slot]["batch_size"] == 10 and res_d[slot]["batches"] == 20
+        assert np.array_equal(res_d[slot]["wout"], res_h[slot]["wout"]), slot
+        # the ridge system it solves: normwise backward error of the device W_out on the device's own Gram matrix
+        c, b, w = res_d[slot]["c"], res_d[slot]["b"], res_d[slot]["wout_dev"]
+        n = sizes[slot]
+        reg = torch.diag(torch.cat([torch.full((n_model,), 1.0), torch.full((n,), 1e-6)])).to("cuda", torch.float64)
+        resid = (c + reg) @ w - b
+        berr = float(resid.norm() / (torch.linalg.matrix_norm(c + reg) * w.norm() + b.norm()))
+        assert berr < 1e-15, berr
