@@ -589,9 +589,9 @@ class HybridRank:
         else:
             nst = 0 if self.leapfrog_steps is None else self.leapfrog_steps + 2
             wl = ("BASELINE config 3: 1152-reservoir batched predict + region exchange (scatter, clamps, gather, standardise) "
-                  "+ SPEEDY hand-off iogrid(30)/(31) + one 6-hour SPEEDY window of %d time steps (stepone + leapfrog: "
+                  "+ SPEEDY hand-off iogrid(30)/(31) + %sone 6-hour SPEEDY window of %d time steps (stepone + leapfrog: "
                   "%d inverse + 73 forward transforms, grid-point tendencies, %ssemi-implicit spectral step each) on the device"
-                  % (nst, 77 if self.phys is not None else 50,
+                  % ("fordate(0) (albedos, tcorh, qcorh from the hybrid SST) + " if self.phys is not None else "", nst, 77 if self.phys is not None else 50,
                      "column physics (convection, condensation, clouds, SW every 3rd step, LW, surface fluxes, vertical diffusion), "
                      if self.phys is not None else "no column physics, "))
         if self.mode == "hybrid" and self.slab is not None:
@@ -599,7 +599,8 @@ class HybridRank:
                    "predict_slab_ml of the SST-predicting regions every 28th step")
         return {"workload": wl, "regions_total": NREG, "regions_this_rank": len(self.regions),
                 "transforms_per_step": ((99 if self.leapfrog_steps is None else 66) + (150 if self.phys is not None else 123)
-                                        * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)) if self.mode == "hybrid" else 0,
+                                        * (0 if self.leapfrog_steps is None else self.leapfrog_steps + 2)
+                                        + (2 if self.phys is not None else 0)) if self.mode == "hybrid" else 0,      # (+ fordate's two)
                 "parallelism": f"regions sharded by processor_decomposition over {self.world} rank(s); "
                                + ("one all-gather of the outvec slab per step" if self.world > 1 else "no collective")}
 
