@@ -479,9 +479,10 @@ int sml_dyn_set_range_guard(sml_dyn *dyn, int32_t *safe_dev);
 /* whether time steps keep the physics' 2-D diagnostics (sml_phys_diag: precipitation, fluxes, cloud cover ...) up to date: on by
  * default; a host that does not read them between windows can switch the 18 stores per column and step off */
 int sml_dyn_physics_diag(sml_dyn *dyn, int on);
-/* how a time step runs grtend's grid-point part with physics attached: 1 = one fused two-wavefront launch (default), 0 = the
- * grid-point dynamics and sml_phys_tendencies_sfcwind as two launches, 2 = one fused one-wavefront launch (same arithmetic and
- * bits in all three; kept so that tests can compare them) */
+/* how a time step runs grtend's grid-point part with physics attached: 3 = one fused launch of three wavefronts per 64 columns --
+ * grid-point dynamics | convection, condensation, vertical diffusion, final sums | radiation and surface fluxes (default since round 4),
+ * 1 = the two-wavefront launch of rounds 2-3, 0 = the grid-point dynamics and sml_phys_tendencies_sfcwind as two launches, 2 = one
+ * fused one-wavefront launch (same arithmetic and bits in all four; kept so that tests can compare them) */
 int sml_dyn_select_physics_form(int fused);
 /* how sml_dyn_window runs a time step: 0 = four launches over whole fields (default), 1 = two kernels (zonal-wavenumber
  * space <-> latitude space; bit-identical results, measured slower on MI355X, see csrc/dynamics.hip), -1 = default /

@@ -350,6 +350,87 @@ __global__ __launch_bounds__(64) void k_gridtend(DevHoriz H, LevelTables L, cons
     }
 }
 
+// grtend's grid-point part (src/dyn_grtend.f90:101-216) for column p: the dynamical tendencies of vorticity / divergence (as flux
+// components) and the flux products go straight to the forward batch O; ttend and qtend go to the workgroup's park (P_TT, P_QT), where
+// phypar's accumulators start from them; utend(kx), vtend(kx) are returned (the physics adds the surface stress to them).
+__device__ __forceinline__ void gridpoint_dynamics(const DevHoriz &H, const LevelTables &L, const double *__restrict__ G, double *__restrict__ O, int p,
+                                                   double *park, int lane, double &u_dyn_out, double &v_dyn_out)
+{
+        const int j = p / IX;
+        smlphys::LA tt = smlphys::park_array(park, smlphys::P_TT, lane), qt = smlphys::park_array(park, smlphys::P_QT, lane);   // 1-based levels
+        double ug[KX], vg[KX], tg[KX], vorg[KX], divg[KX], trg[KX], puv[KX], sigdt[KXP], sigm[KXP];
+        const double cor = H.coriol[j];
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            vorg[k] = G[(size_t)(F_VOR + k) * GR + p] + cor;
+            divg[k] = G[(size_t)(F_DIV + k) * GR + p];
+            tg[k] = G[(size_t)(F_T + k) * GR + p];
+            trg[k] = G[(size_t)(F_TR + k) * GR + p];
+            ug[k] = G[(size_t)(32 + k) * GR + p];
+            vg[k] = G[(size_t)(40 + k) * GR + p];
+        }
+        double px = G[(size_t)48 * GR + p], py = G[(size_t)49 * GR + p];
+        double umean = 0.0, vmean = 0.0, dmean = 0.0;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            umean = umean + ug[k] * L.dhs[k];
+            vmean = vmean + vg[k] * L.dhs[k];
+            dmean = dmean + divg[k] * L.dhs[k];
+        }
+        O[(size_t)72 * GR + p] = -umean * px - vmean * py;
+        sigdt[0] = 0.0; sigm[0] = 0.0;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {          // the reference's loop runs to kx and so overwrites the zero it put at kxp
+            sigdt[k + 1] = sigdt[k] - L.dhs[k] * (puv[k] + divg[k] - dmean);
+            sigm[k + 1] = sigm[k] - L.dhs[k] * puv[k];
+        }
+        double tgg[KX];
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - L.tref[k];
+        px = RGAS * px;
+        py = RGAS * py;
+        double tmp[KXP];
+        tmp[0] = 0.0; tmp[KX] = 0.0;
+        // zonal wind
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX - 1; ++k) O[(size_t)k * GR + p] = vg[k] * vorg[k] - tgg[k] * px - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        const double u_dyn = vg[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * px - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
+        // meridional wind
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX - 1; ++k) O[(size_t)(8 + k) * GR + p] = -ug[k] * vorg[k] - tgg[k] * py - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        const double v_dyn = -ug[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * py - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
+        // temperature
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (L.tref[k] - L.tref[k - 1]);
+    #pragma unroll
+        for (int k = 0; k < KX; ++k)
+            tt[k + 1] = tgg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k] + L.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k])
+                                           + L.tref3[k] * (sigm[k + 1] + sigm[k]) + L.akap * (tg[k] * puv[k] - tgg[k] * dmean);
+        // tracer (specific humidity): no vertical advection across the two uppermost interfaces (:196-203)
+    #pragma unroll
+        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
+        tmp[1] = 0.; tmp[2] = 0.;
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) qt[k + 1] = trg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
+        // flux products (:241-246, :262-267)
+    #pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            O[(size_t)(48 + k) * GR + p] = 0.5 * (ug[k] * ug[k] + vg[k] * vg[k]);
+            O[(size_t)(16 + k) * GR + p] = -ug[k] * tgg[k];
+            O[(size_t)(24 + k) * GR + p] = -vg[k] * tgg[k];
+            O[(size_t)(32 + k) * GR + p] = -ug[k] * trg[k];
+            O[(size_t)(40 + k) * GR + p] = -vg[k] * trg[k];
+        }
+    u_dyn_out = u_dyn;
+    v_dyn_out = v_dyn;
+}
+
 // k_gridtend_physics: grtend's grid-point part (dyn_grtend.f90:80-216) and phypar (:222-225, phy_phypar.f90:80-230) in ONE launch
 // of 72 workgroups x 2 wavefronts for 64 columns each:
 //   wave 0: the dynamical tendencies (k_gridtend's body; ttend, qtend, utend(kx), vtend(kx) go straight into the physics'
@@ -368,94 +449,33 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // uniform: the two chains are scalar branches
     const int p = blockIdx.x * 64 + lane;                                     // the grid is exactly GR / 64 workgroups
+    CSTAMP(0);
     if (wave == 0) {
         smlphys::Column c;
         smlphys::column_load(PG, p, c);                  // issued with the loads of the dynamics below: one exposed round trip
-        const int j = p / IX;
-        smlphys::LA tt = smlphys::park_array(park, smlphys::P_TT, lane), qt = smlphys::park_array(park, smlphys::P_QT, lane);   // 1-based levels
-        double ug[KX], vg[KX], tg[KX], vorg[KX], divg[KX], trg[KX], puv[KX], sigdt[KXP], sigm[KXP];
-        const double cor = H.coriol[j];
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            vorg[k] = G[(size_t)(F_VOR + k) * GR + p] + cor;
-            divg[k] = G[(size_t)(F_DIV + k) * GR + p];
-            tg[k] = G[(size_t)(F_T + k) * GR + p];
-            trg[k] = G[(size_t)(F_TR + k) * GR + p];
-            ug[k] = G[(size_t)(32 + k) * GR + p];
-            vg[k] = G[(size_t)(40 + k) * GR + p];
-        }
-        double px = G[(size_t)48 * GR + p], py = G[(size_t)49 * GR + p];
-        double umean = 0.0, vmean = 0.0, dmean = 0.0;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            umean = umean + ug[k] * L.dhs[k];
-            vmean = vmean + vg[k] * L.dhs[k];
-            dmean = dmean + divg[k] * L.dhs[k];
-        }
-        O[(size_t)72 * GR + p] = -umean * px - vmean * py;
-        sigdt[0] = 0.0; sigm[0] = 0.0;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {          // the reference's loop runs to kx and so overwrites the zero it put at kxp
-            sigdt[k + 1] = sigdt[k] - L.dhs[k] * (puv[k] + divg[k] - dmean);
-            sigm[k + 1] = sigm[k] - L.dhs[k] * puv[k];
-        }
-        double tgg[KX];
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - L.tref[k];
-        px = RGAS * px;
-        py = RGAS * py;
-        double tmp[KXP];
-        tmp[0] = 0.0; tmp[KX] = 0.0;
-        // zonal wind
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
-    #pragma unroll
-        for (int k = 0; k < KX - 1; ++k) O[(size_t)k * GR + p] = vg[k] * vorg[k] - tgg[k] * px - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-        const double u_dyn = vg[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * px - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
-        // meridional wind
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
-    #pragma unroll
-        for (int k = 0; k < KX - 1; ++k) O[(size_t)(8 + k) * GR + p] = -ug[k] * vorg[k] - tgg[k] * py - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-        const double v_dyn = -ug[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * py - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
-        // temperature
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (L.tref[k] - L.tref[k - 1]);
-    #pragma unroll
-        for (int k = 0; k < KX; ++k)
-            tt[k + 1] = tgg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k] + L.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k])
-                                           + L.tref3[k] * (sigm[k + 1] + sigm[k]) + L.akap * (tg[k] * puv[k] - tgg[k] * dmean);
-        // tracer (specific humidity): no vertical advection across the two uppermost interfaces (:196-203)
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
-        tmp[1] = 0.; tmp[2] = 0.;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) qt[k + 1] = trg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-        // flux products (:241-246, :262-267)
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            O[(size_t)(48 + k) * GR + p] = 0.5 * (ug[k] * ug[k] + vg[k] * vg[k]);
-            O[(size_t)(16 + k) * GR + p] = -ug[k] * tgg[k];
-            O[(size_t)(24 + k) * GR + p] = -vg[k] * tgg[k];
-            O[(size_t)(32 + k) * GR + p] = -ug[k] * trg[k];
-            O[(size_t)(40 + k) * GR + p] = -vg[k] * trg[k];
-        }
+        double u_dyn, v_dyn;
+        gridpoint_dynamics(H, L, G, O, p, park, lane, u_dyn, v_dyn);
+        CSTAMP(1);
             smlphys::column_thermo(PL, c);
+        CSTAMP(2);
         int iptop, icnv;
         double precnv, precls;
         smlphys::chain_moist(PL, PD, c, p, want_diag, park, lane, iptop, icnv, precnv, precls);
+        CSTAMP(3);
         double pt[smlphys::NLP], pq[smlphys::NLP];
         smlphys::vdifsc(PL, c, icnv, pt, pq);
+        CSTAMP(4);
         __syncthreads();                                                      // the radiation chain has left its results in the park
+        CSTAMP(5);
         smlphys::chain_pbl_and_store(PL, c, p, icnv, park, lane, O, 0, 8, 56, 64, u_dyn, v_dyn, pt, pq);
+        CSTAMP(6);
     } else {
         smlphys::Column c;
         smlphys::RadIn r;
         smlphys::column_load(PG, p, c);                  // everything this chain reads, in one batch
         smlphys::radiation_load(PD, p, lradsw, park, lane, r);
         smlphys::column_thermo(PL, c);
+        CSTAMP(1);
         double precnv = 0., precls = 0.;
         int iptop = 0;
         if (lradsw) {
@@ -465,8 +485,82 @@ __global__ __launch_bounds__(128) void k_gridtend_physics(DevHoriz H, LevelTable
             smlphys::convmf(PL, c, iptop, cbmf, precnv, s1, s2);
             smlphys::lscond(PL, c, iptop, precls, s1, s2);
         }
+        CSTAMP(2);
         smlphys::chain_radiation(PL, PD, c, r, p, lradsw, want_diag, park, lane, precnv, precls, iptop);
+        CSTAMP(7);
         __syncthreads();
+    }
+}
+
+// THREE wavefronts per 64 columns (round 4, the default since): phase stamps of the two-wavefront kernel (profiles/micro/
+// physics_wave_stamps.py) put 4.6-5.5 of wave 0's 10 us into the loads and arithmetic of the grid-point dynamics -- 77 fields per
+// column through one wavefront's miss queue -- before its moist chain (3.1 us) could even start, while the radiation wavefront of a step
+// without short-wave radiation was done after 4 us.  Here the dynamics have a wavefront of their own:
+//   wave 0  grid-point dynamics: 50 grids in, the flux fields out, ttend / qtend / utend(kx) / vtend(kx) into the park
+//   wave 1  column state (25 values), convection, condensation, vertical diffusion; after the barrier the column's sums and stores
+//   wave 2  radiation and surface fluxes as before
+// One workgroup barrier, raw (s_barrier behind an LDS-only wait): every wavefront reaches it when its park entries are written, none
+// waits for anybody's global stores.  Each sum keeps the reference's order (finish_and_store), so the result equals the other forms bit
+// for bit (tests/test_physics_gpu.py::test_fused_forms_agree_bit_for_bit).
+__device__ __forceinline__ void park_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wavefront's LDS writes have landed (vmcnt / expcnt left alone)
+    __builtin_amdgcn_s_barrier();
+}
+struct ParkBarrier { __device__ __forceinline__ void operator()() const { park_barrier(); } };
+
+__global__ __launch_bounds__(192) void k_gridtend_physics3(DevHoriz H, LevelTables L, const double *__restrict__ G, double *__restrict__ O,
+                                                            smlphys::PhysLev PL, smlphys::PhysDev PD, smlphys::PhysIn PG, int lradsw, int want_diag)
+{
+    SML_SPAN(2);
+    __shared__ double park[smlphys::PARK_DOUBLES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // uniform: the three chains are scalar branches
+    const int p = blockIdx.x * 64 + lane;                                     // the grid is exactly GR / 64 workgroups
+    CSTAMP(0);
+    if (wave == 0) {
+        double u_dyn, v_dyn;
+        gridpoint_dynamics(H, L, G, O, p, park, lane, u_dyn, v_dyn);
+        smlphys::LA uv = smlphys::park_array(park, smlphys::P_UV, lane);
+        uv[0] = u_dyn; uv[1] = v_dyn;
+        CSTAMP(1);
+        park_barrier();
+        CSTAMP(2);
+    } else if (wave == 1) {
+        smlphys::Column c;
+        smlphys::column_load(PG, p, c);
+        smlphys::column_thermo(PL, c);
+        CSTAMP(1);
+        int iptop, icnv;
+        double precnv, precls, a1[smlphys::NLP], a2[smlphys::NLP], b1[smlphys::NLP], b2[smlphys::NLP];
+        smlphys::moist_tendencies(PL, PD, c, p, want_diag, iptop, icnv, precnv, precls, a1, a2, b1, b2);
+        CSTAMP(2);
+        double pt[smlphys::NLP], pq[smlphys::NLP];
+        smlphys::vdifsc(PL, c, icnv, pt, pq);
+        CSTAMP(3);
+        park_barrier();                                                       // the dynamics and the radiation have left their results
+        CSTAMP(4);
+        smlphys::finish_and_store(PL, c, p, park, lane, O, 0, 8, 56, 64, a1, a2, b1, b2, pt, pq);
+        CSTAMP(5);
+    } else {
+        smlphys::Column c;
+        smlphys::RadIn r;
+        smlphys::column_load(PG, p, c);                  // everything this chain reads, in one batch
+        smlphys::radiation_load(PD, p, lradsw, park, lane, r);
+        smlphys::column_thermo(PL, c);
+        CSTAMP(1);
+        double precnv = 0., precls = 0.;
+        int iptop = 0;
+        if (lradsw) {
+            // cloud() needs the precipitation and the convection top: this wavefront evaluates convmf / lscond for itself (same inputs, same
+            // code, same bits) rather than wait for wave 1 to hand them over through the park (they would arrive 1 us later)
+            double cbmf, s1[smlphys::NLP], s2[smlphys::NLP];
+            smlphys::convmf(PL, c, iptop, cbmf, precnv, s1, s2);
+            smlphys::lscond(PL, c, iptop, precls, s1, s2);
+        }
+        CSTAMP(2);
+        smlphys::chain_radiation(PL, PD, c, r, p, lradsw, want_diag, park, lane, precnv, precls, iptop, ParkBarrier());
+        CSTAMP(7);
     }
 }
 
@@ -485,77 +579,8 @@ __global__ __launch_bounds__(64) void k_gridtend_physics_onewave(DevHoriz H, Lev
     const int p = blockIdx.x * 64 + lane;
         smlphys::Column c;
         smlphys::column_load(PG, p, c);                  // issued with the loads of the dynamics below: one exposed round trip
-        const int j = p / IX;
-        smlphys::LA tt = smlphys::park_array(park, smlphys::P_TT, lane), qt = smlphys::park_array(park, smlphys::P_QT, lane);   // 1-based levels
-        double ug[KX], vg[KX], tg[KX], vorg[KX], divg[KX], trg[KX], puv[KX], sigdt[KXP], sigm[KXP];
-        const double cor = H.coriol[j];
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            vorg[k] = G[(size_t)(F_VOR + k) * GR + p] + cor;
-            divg[k] = G[(size_t)(F_DIV + k) * GR + p];
-            tg[k] = G[(size_t)(F_T + k) * GR + p];
-            trg[k] = G[(size_t)(F_TR + k) * GR + p];
-            ug[k] = G[(size_t)(32 + k) * GR + p];
-            vg[k] = G[(size_t)(40 + k) * GR + p];
-        }
-        double px = G[(size_t)48 * GR + p], py = G[(size_t)49 * GR + p];
-        double umean = 0.0, vmean = 0.0, dmean = 0.0;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            umean = umean + ug[k] * L.dhs[k];
-            vmean = vmean + vg[k] * L.dhs[k];
-            dmean = dmean + divg[k] * L.dhs[k];
-        }
-        O[(size_t)72 * GR + p] = -umean * px - vmean * py;
-        sigdt[0] = 0.0; sigm[0] = 0.0;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {          // the reference's loop runs to kx and so overwrites the zero it put at kxp
-            sigdt[k + 1] = sigdt[k] - L.dhs[k] * (puv[k] + divg[k] - dmean);
-            sigm[k + 1] = sigm[k] - L.dhs[k] * puv[k];
-        }
-        double tgg[KX];
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - L.tref[k];
-        px = RGAS * px;
-        py = RGAS * py;
-        double tmp[KXP];
-        tmp[0] = 0.0; tmp[KX] = 0.0;
-        // zonal wind
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
-    #pragma unroll
-        for (int k = 0; k < KX - 1; ++k) O[(size_t)k * GR + p] = vg[k] * vorg[k] - tgg[k] * px - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-        const double u_dyn = vg[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * px - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
-        // meridional wind
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
-    #pragma unroll
-        for (int k = 0; k < KX - 1; ++k) O[(size_t)(8 + k) * GR + p] = -ug[k] * vorg[k] - tgg[k] * py - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-        const double v_dyn = -ug[KX - 1] * vorg[KX - 1] - tgg[KX - 1] * py - (tmp[KX] + tmp[KX - 1]) * L.dhsr[KX - 1];
-        // temperature
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (L.tref[k] - L.tref[k - 1]);
-    #pragma unroll
-        for (int k = 0; k < KX; ++k)
-            tt[k + 1] = tgg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k] + L.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k])
-                                           + L.tref3[k] * (sigm[k + 1] + sigm[k]) + L.akap * (tg[k] * puv[k] - tgg[k] * dmean);
-        // tracer (specific humidity): no vertical advection across the two uppermost interfaces (:196-203)
-    #pragma unroll
-        for (int k = 1; k < KX; ++k) tmp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
-        tmp[1] = 0.; tmp[2] = 0.;
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) qt[k + 1] = trg[k] * divg[k] - (tmp[k + 1] + tmp[k]) * L.dhsr[k];
-        // flux products (:241-246, :262-267)
-    #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            O[(size_t)(48 + k) * GR + p] = 0.5 * (ug[k] * ug[k] + vg[k] * vg[k]);
-            O[(size_t)(16 + k) * GR + p] = -ug[k] * tgg[k];
-            O[(size_t)(24 + k) * GR + p] = -vg[k] * tgg[k];
-            O[(size_t)(32 + k) * GR + p] = -ug[k] * trg[k];
-            O[(size_t)(40 + k) * GR + p] = -vg[k] * trg[k];
-        }
+        double u_dyn, v_dyn;
+        gridpoint_dynamics(H, L, G, O, p, park, lane, u_dyn, v_dyn);
             smlphys::column_thermo(PL, c);
         int iptop, icnv;
         double precnv, precls;
@@ -1312,7 +1337,7 @@ int fetch_table(sml_dyn *d, int which, const double **dst, std::vector<double> &
     return dst ? upload(d, dst, tmp.data(), n) : SML_OK;
 }
 
-int g_physics_fused = 1;     // sml_dyn_select_physics_form
+int g_physics_fused = 3;     // sml_dyn_select_physics_form
 
 // phi_ready: the previous launch of this window's k_spectral left geop(1) of the current time level 1 in d->aux (its phi_out), so
 // the inverse set takes the physics' eight geopotential levels from there (descriptor type 8) instead of rebuilding them (type 7)
@@ -1330,7 +1355,10 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
     if (d->phys && g_physics_fused) {      // dyn_grtend.f90:80-225 in one launch: grid-point tendencies + phypar
         const double *pg = d->batch_grid + (size_t)NB_SPEC * GR;
         smlphys::PhysIn in{pg, pg + (size_t)GR, pg + (size_t)2 * GR, pg + (size_t)10 * GR, pg + (size_t)18 * GR, pg + (size_t)26 * GR};
-        if (g_physics_fused == 2)
+        if (g_physics_fused == 3)
+            hipLaunchKernelGGL(k_gridtend_physics3, dim3(GR / 64), dim3(192), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
+                               d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag);
+        else if (g_physics_fused == 2)
             hipLaunchKernelGGL(k_gridtend_physics_onewave, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
                                d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag);
         else
@@ -1575,6 +1603,13 @@ int sml_dyn_set_boundary(sml_dyn *d, const double *phis_dev, const double *tcorh
 
 SML_SPAN_ATTACH(sml_span_attach_dyn)
 
+int sml_dyn_phys_stamps(unsigned long long *out48)        // not part of the C-ABI: CSTAMP records of k_gridtend_physics (-DSML_PHYS_STAMPS builds)
+{
+    SML_HIP(hipDeviceSynchronize());
+    SML_HIP(hipMemcpyFromSymbol(out48, HIP_SYMBOL(smlphys::g_phys_dbg), sizeof(unsigned long long) * 48));
+    return SML_OK;
+}
+
 int sml_dyn_debug_stamps(unsigned long long *out)        // not part of the C-ABI (no declaration in include/): phase profiling aid
 {
     SML_HIP(hipDeviceSynchronize());
@@ -1692,7 +1727,7 @@ int sml_dyn_set_lradsw(sml_dyn *d, int lradsw)
 
 int sml_dyn_select_physics_form(int fused)
 {
-    g_physics_fused = fused == 2 ? 2 : fused ? 1 : 0;      // 2: the one-wavefront fused form (experiment / regression subject)
+    g_physics_fused = (fused == 2 || fused == 3) ? fused : fused ? 1 : 0;      // 3: three wavefronts (default); 1: two; 2: one (regression subjects)
     return SML_OK;
 }
 

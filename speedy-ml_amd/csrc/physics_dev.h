@@ -640,12 +640,16 @@ __device__ void vdifsc(const PhysLev &L, const Column &c, int icnv, double *tt, 
 }
 
 // phase time stamps of one tropical workgroup (profiles/micro/physics_phase_stamps.py); compiled in with -DSML_PHYS_STAMPS only
-__device__ unsigned long long g_phys_dbg[16];
+__device__ unsigned long long g_phys_dbg[48];
 #ifdef SML_PHYS_STAMPS
 #define PSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); \
         if (blockIdx.x == 36 && threadIdx.x == 0) g_phys_dbg[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// the two-wavefront kernel of dynamics.hip: lane 0 of either wavefront stamps into its own half, [wave][16]
+#define CSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); \
+        if (blockIdx.x == 36 && (threadIdx.x & 63) == 0) smlphys::g_phys_dbg[(threadIdx.x >> 6) * 16 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PSTAMP(slot) do { } while (0)
+#define CSTAMP(slot) do { } while (0)
 #endif
 
 // where phypar's grid-point inputs of time level 1 are: 8 consecutive level fields each for t, q, phi; ONE field each for the
@@ -668,8 +672,9 @@ struct PhysIn { const double *usfc, *vsfc, *t, *q, *phi, *ps; };
 //   P_RSW       short-wave heating (tendency) of this or the last short-wave step        P_RLW  long-wave heating (tendency)
 //   P_FB        long-wave band fractions of the level temperatures [level][band]
 //   P_XB        radiation chain -> finish: ustr, vstr, shf, evap of the surface (fmask-weighted)
+//   P_UV        (three-wavefront form) dynamics wave -> finish: utend(kx), vtend(kx)
 // The sums keep the reference's order whatever runs where: ttend = ((dyn + cnv) + lsc), then (+ rsw) + rlw, then + pbl.
-constexpr int P_TT = 0, P_QT = NLP, P_RSW = 2 * NLP, P_FB = 3 * NLP, P_RLW = 8 * NLP, P_XB = 9 * NLP, P_SLOTS = 9 * NLP + 4;
+constexpr int P_TT = 0, P_QT = NLP, P_RSW = 2 * NLP, P_FB = 3 * NLP, P_RLW = 8 * NLP, P_XB = 9 * NLP, P_UV = 9 * NLP + 4, P_SLOTS = 9 * NLP + 6;
 constexpr int PARK_DOUBLES = P_SLOTS * 64;
 
 __device__ __forceinline__ LA park_array(double *park, int slot, int lane) { return LA{park + slot * 64 + lane}; }
@@ -737,27 +742,40 @@ __device__ __forceinline__ void radiation_load(const PhysDev &D, int p, int lrad
     r.ssrd = D.ssrd[p];
 }
 
-// phypar 2 (:102-118): convection and large-scale condensation; ttend = ttend + tt_cnv + tt_lsc (same for q)
-__device__ __forceinline__ void chain_moist(const PhysLev &L, const PhysDev &D, const Column &c, int p, int want_diag, double *park, int lane,
-                                            int &iptop, int &icnv, double &precnv, double &precls)
+// phypar 2 (:102-118): convection and large-scale condensation as tendencies (tt_cnv, qt_cnv already scaled by rps grdscp / grdsig)
+__device__ __forceinline__ void moist_tendencies(const PhysLev &L, const PhysDev &D, const Column &c, int p, int want_diag, int &iptop, int &icnv,
+                                                 double &precnv, double &precls, double (&a1)[NLP], double (&a2)[NLP], double (&b1)[NLP], double (&b2)[NLP])
 {
-    LA tt = park_array(park, P_TT, lane), qt = park_array(park, P_QT, lane);
-    double cbmf, a1[NLP], a2[NLP], b1[NLP], b2[NLP];
+    double cbmf;
     convmf(L, c, iptop, cbmf, precnv, a1, a2);
     for (int k = 2; k <= KX; ++k) { a1[k] = a1[k] * c.rps * L.grdscp[k]; a2[k] = a2[k] * c.rps * L.grdsig[k]; }
     icnv = KX - iptop;
     lscond(L, c, iptop, precls, b1, b2);
-    for (int k = 1; k <= KX; ++k) { tt[k] = tt[k] + a1[k] + b1[k]; qt[k] = qt[k] + a2[k] + b2[k]; }
     if (want_diag) {
         D.diag[(size_t)D_PRECNV * GR + p] = precnv; D.diag[(size_t)D_PRECLS * GR + p] = precls; D.diag[(size_t)D_CBMF * GR + p] = cbmf;
         D.diag[(size_t)D_IPTOP * GR + p] = iptop;
     }
 }
 
+// ... and ttend = ttend + tt_cnv + tt_lsc (same for q) on the park's accumulators
+__device__ __forceinline__ void chain_moist(const PhysLev &L, const PhysDev &D, const Column &c, int p, int want_diag, double *park, int lane,
+                                            int &iptop, int &icnv, double &precnv, double &precls)
+{
+    LA tt = park_array(park, P_TT, lane), qt = park_array(park, P_QT, lane);
+    double a1[NLP], a2[NLP], b1[NLP], b2[NLP];
+    moist_tendencies(L, D, c, p, want_diag, iptop, icnv, precnv, precls, a1, a2, b1, b2);
+    for (int k = 1; k <= KX; ++k) { tt[k] = tt[k] + a1[k] + b1[k]; qt[k] = qt[k] + a2[k] + b2[k]; }
+}
+
 // phypar 3 (:120-176): clouds and short-wave radiation on short-wave steps (else what the last one left), long-wave radiation
 // down, surface fluxes, long-wave radiation up.  Leaves the two heating tendencies and the surface fluxes in the park.
+// PARK_READY: called once the park holds everything this chain hands on (the heating tendencies and the surface fluxes), before the 2-D
+// diagnostics are stored -- the multi-wavefront kernels put their workgroup barrier there, so that the wavefront that finishes the column
+// does not wait for this one's stores to drain
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <class PARK_READY = NoHook>
 __device__ __forceinline__ void chain_radiation(const PhysLev &L, const PhysDev &D, const Column &c, RadIn &r, int p, int lradsw, int want_diag,
-                                                double *park, int lane, double precnv, double precls, int iptop)
+                                                double *park, int lane, double precnv, double precls, int iptop, PARK_READY park_ready = PARK_READY())
 {
     LA tt_rsw = park_array(park, P_RSW, lane), tt_rlw = park_array(park, P_RLW, lane), xb = park_array(park, P_XB, lane);
     double (&tau2)[NLP][5] = r.tau2;
@@ -783,15 +801,20 @@ __device__ __forceinline__ void chain_radiation(const PhysLev &L, const PhysDev 
             D.diag[(size_t)D_TSR * GR + p] = tsr; D.diag[(size_t)D_SSR * GR + p] = ssr; D.diag[(size_t)D_ICLTOP * GR + p] = icltop;
         }
     }
+    CSTAMP(3);
     LwState lw;
     lw.fb = LA2<5>{park + P_FB * 64 + lane};
     double slrd, slr, olr, dfabs[NLP];
     radlw_down(L, c, D.fband, tau2, lw, slrd, dfabs);
+    CSTAMP(4);
     Surface sf;
     suflux(L, c, r.phis0, r.fmask, r.tland, r.tsea, r.swav, ssrd, slrd, r.alb_l, r.alb_s, r.snowc, r.forog, r.sqclat, sf);
+    CSTAMP(5);
     radlw_up(L, c, D.fband, tau2, stratc, lw, sf.tsfc, slrd, sf.slru[3], slr, olr, dfabs);
+    CSTAMP(6);
     for (int k = 1; k <= KX; ++k) tt_rlw[k] = dfabs[k] * c.rps * L.grdscp[k];
     xb[0] = sf.ustr[3]; xb[1] = sf.vstr[3]; xb[2] = sf.shf[3]; xb[3] = sf.evap[3];
+    park_ready();
     if (want_diag) {
         double *dg = D.diag;
         dg[(size_t)D_TS * GR + p] = sf.tsfc; dg[(size_t)D_TSKIN * GR + p] = sf.tskin; dg[(size_t)D_SSRD * GR + p] = ssrd;
@@ -820,6 +843,29 @@ __device__ __forceinline__ void chain_pbl_and_store(const PhysLev &L, const Colu
         const double t_rad = tt[k] + tt_rsw[k] + tt_rlw[k];
         tend[(size_t)(off_t + k - 1) * GR + p] = t_rad + t_pbl;
         tend[(size_t)(off_q + k - 1) * GR + p] = qt[k] + q_pbl;
+    }
+}
+
+// The same finish for the three-wavefront kernel, whose moist wavefront did NOT add its tendencies into the park (the dynamics wavefront
+// was still filling it): ttend = ((dyn + cnv) + lsc), then + rsw + rlw, then + pbl -- the order of chain_moist followed by
+// chain_pbl_and_store, hence the same bits.
+__device__ __forceinline__ void finish_and_store(const PhysLev &L, const Column &c, int p, double *park, int lane, double *__restrict__ tend,
+                                                 int off_u, int off_v, int off_t, int off_q, const double (&a1)[NLP], const double (&a2)[NLP],
+                                                 const double (&b1)[NLP], const double (&b2)[NLP], const double (&pt)[NLP], const double (&pq)[NLP])
+{
+    LA tt = park_array(park, P_TT, lane), qt = park_array(park, P_QT, lane), tt_rsw = park_array(park, P_RSW, lane);
+    LA tt_rlw = park_array(park, P_RLW, lane), xb = park_array(park, P_XB, lane), uv = park_array(park, P_UV, lane);
+    const double ut = 0.0 + xb[0] * c.rps * L.grdsig[KX];
+    const double vt = 0.0 + xb[1] * c.rps * L.grdsig[KX];
+    tend[(size_t)(off_u + KX - 1) * GR + p] = uv[0] + ut;
+    tend[(size_t)(off_v + KX - 1) * GR + p] = uv[1] + vt;
+    for (int k = 1; k <= KX; ++k) {
+        double t_pbl = pt[k], q_pbl = pq[k];
+        if (k == KX) { t_pbl = t_pbl + xb[2] * c.rps * L.grdscp[KX]; q_pbl = q_pbl + xb[3] * c.rps * L.grdsig[KX]; }
+        const double t_moist = tt[k] + a1[k] + b1[k], q_moist = qt[k] + a2[k] + b2[k];
+        const double t_rad = t_moist + tt_rsw[k] + tt_rlw[k];
+        tend[(size_t)(off_t + k - 1) * GR + p] = t_rad + t_pbl;
+        tend[(size_t)(off_q + k - 1) * GR + p] = q_moist + q_pbl;
     }
 }
 

@@ -80,9 +80,10 @@ class Dynamics:
 
     @staticmethod
     def select_physics_form(fused):
-        """True / 1 (default): grtend's grid-point part and the physics as one two-wave launch; False / 0: two launches; 2: the
-        one-wavefront fused launch (same bits in all three; 2 is the regression subject of the round-1 repeatability failure)"""
-        check(_lib.lib().sml_dyn_select_physics_form(2 if fused == 2 else 1 if fused else 0))
+        """3 (default): grtend's grid-point part and the physics as one launch of three wavefronts per 64 columns; True / 1: the
+        two-wavefront launch of rounds 2-3; False / 0: two launches; 2: the one-wavefront fused launch (same bits in all four; 2 is the
+        regression subject of the round-1 repeatability failure)"""
+        check(_lib.lib().sml_dyn_select_physics_form(int(fused) if fused in (2, 3) else 1 if fused else 0))
 
     def physics_diag(self, on):
         """keep (default) or skip the physics' 2-D diagnostics during time steps"""

@@ -202,9 +202,10 @@ def device_window(st, phis, surf, nsteps):
 
 
 def test_fused_forms_agree_bit_for_bit():
-    """The three forms of grtend's grid-point part + phypar -- two launches (k_gridtend, k_physics), one two-wavefront launch (the
-    default) and one one-wavefront launch -- leave identical bits after stepone + 7 steps (short-wave and other steps), and each
-    fused form repeats itself.  The one-wavefront form is the shape that was non-repeatable at -O3 in round 1."""
+    """The four forms of grtend's grid-point part + phypar -- two launches (k_gridtend, k_physics), one two-wavefront launch, one
+    one-wavefront launch and the three-wavefront launch (the default since round 4) -- leave identical bits after stepone + 7 steps
+    (short-wave and other steps), and each fused form repeats itself.  The one-wavefront form is the shape that was non-repeatable at -O3
+    in round 1."""
     from make_physics_golden import coupled_inputs
     from speedy_ml_amd.dynamics import Dynamics
     _, st, phis, surf = coupled_inputs(seed=4)
@@ -219,17 +220,24 @@ def test_fused_forms_agree_bit_for_bit():
         Dynamics.select_physics_form(True)
         one, _, ph_one = device_window(st, phis, surf, 7)
         again, _, _ = device_window(st, phis, surf, 7)
+        Dynamics.select_physics_form(3)
+        three, _, ph_three = device_window(st, phis, surf, 7)
+        three_again, _, _ = device_window(st, phis, surf, 7)
+        diag_three = {k: ph_three.diag(k).copy() for k in diag_two}
     finally:
-        Dynamics.select_physics_form(True)
+        Dynamics.select_physics_form(3)
     for k in ("vor", "div", "t", "tr", "ps"):
         assert np.all(np.isfinite(one[k]))
         assert np.array_equal(one[k], two[k]), k
         assert np.array_equal(one[k], again[k]), k
         assert np.array_equal(single[k], two[k]), k
         assert np.array_equal(single[k], single_again[k]), k
+        assert np.array_equal(three[k], two[k]), k
+        assert np.array_equal(three[k], three_again[k]), k
     for k, v in diag_two.items():
         assert np.array_equal(ph_one.diag(k), v), k
         assert np.array_equal(diag_single[k], v), k
+        assert np.array_equal(diag_three[k], v), k
 
 
 def test_window_with_physics_matches_reference_fixture():
