@@ -410,7 +410,9 @@ def main():
     comm = None
     host = model
     if args.host == "native" and not python_only:
-        if world > 1:
+        # the rank exchange: torch.distributed's all-gather between the engine's two half-steps by default; SML_ENGINE_COMM=engine (or
+        # the slab coupling, whose second all-gather lives in the engine) gives the engine its own RCCL communicator, as under a Fortran host
+        if world > 1 and (os.environ.get("SML_ENGINE_COMM", "torch") == "engine" or args.slab):
             comm = hybrid.make_comm(world, rank)
         host = hybrid.NativeEngine(model, comm=comm)
 

@@ -302,6 +302,9 @@ int sml_hybrid_attach_physics(sml_hybrid *h, const double *hsg9, const double *r
                               const double *snowc, int nstrad);
 int sml_hybrid_get_phis0(sml_hybrid *h, double *phis0_host);
 int sml_hybrid_set_fordate_fields(sml_hybrid *h, const double *fmask_s, const double *alb0, const double *snowd_am, const double *sice_am);
+/* the coupler's daily output between two windows (land temperature, soil wetness, snow depth, sea-ice fraction; (96,48) each, NULL =
+ * unchanged): the coupler stays with the host, its results enter here and the next window's fordate and physics read them */
+int sml_hybrid_update_surface(sml_hybrid *h, const double *stl_am, const double *soilw_am, const double *snowd_am, const double *sice_am);
 int sml_hybrid_initial_inputs(sml_hybrid *h, void *stream);
 int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream);
 int sml_hybrid_safe(sml_hybrid *h, int *safe_out);
@@ -326,6 +329,10 @@ int sml_hybrid_set_comm(sml_hybrid *h, sml_comm *comm);
 int sml_hybrid_restart(sml_hybrid *h, int start_hours);
 int sml_hybrid_slab_due(sml_hybrid *h);
 int sml_hybrid_step(sml_hybrid *h, int leapfrog_steps, void *stream);
+/* the same iteration in two calls for a host that owns the rank exchange (its own all-gather of the banks' outvec buffers in between);
+ * all_outvec_dev = the gathered region-ordered slab [number_of_regions][max_n_out], NULL = the engine's own exchange */
+int sml_hybrid_step_predict(sml_hybrid *h, void *stream);
+int sml_hybrid_step_finish(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream);
 double *sml_hybrid_g_dev(sml_hybrid *h);
 double *sml_hybrid_f_dev(sml_hybrid *h);
 
@@ -504,6 +511,8 @@ int sml_phys_destroy(sml_phys *phys);
  * albsfc, snowc (mod_radcon, set by fordate); sflset(phis0) is applied here */
 int sml_phys_set_surface(sml_phys *phys, const double *fmask, const double *phis0, const double *tland, const double *tsea,
                          const double *swav, const double *alb_l, const double *alb_s, const double *albsfc, const double *snowc);
+/* the coupler's daily output (stl_am, soilw_am; snowd_am, sice_am for fordate's albedos), host [48][96], each optional */
+int sml_phys_update_surface(sml_phys *phys, const double *tland, const double *swav, const double *snowd_am, const double *sice_am);
 /* the hybrid model's SST grid (G's SST segment, device) becomes sst_am */
 int sml_phys_set_sst_dev(sml_phys *phys, const double *tsea_dev, void *stream);
 /* ... or read in place: later launches take the sea temperature straight from tsea_dev ([48][96] doubles on the device, e.g. the

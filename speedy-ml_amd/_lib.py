@@ -58,8 +58,8 @@ EXPORTS = [
     "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
     "sml_comm_unique_id", "sml_comm_create", "sml_comm_bootstrap", "sml_comm_destroy", "sml_comm_allgather_outvec", "sml_comm_unpack_regions",
     "sml_hybrid_create", "sml_hybrid_destroy", "sml_hybrid_set_state", "sml_hybrid_get_state", "sml_hybrid_set_base_sst", "sml_hybrid_set_orography",
-    "sml_hybrid_set_tisr_table", "sml_hybrid_get_phis0", "sml_hybrid_set_fordate_fields", "sml_hybrid_attach_physics", "sml_hybrid_initial_inputs", "sml_hybrid_exchange_and_speedy", "sml_hybrid_safe", "sml_hybrid_timing", "sml_hybrid_timing_collect",
-    "sml_hybrid_g_dev", "sml_hybrid_f_dev", "sml_hybrid_attach_slab", "sml_hybrid_set_comm", "sml_hybrid_restart", "sml_hybrid_slab_due", "sml_hybrid_step",
+    "sml_hybrid_set_tisr_table", "sml_hybrid_get_phis0", "sml_hybrid_update_surface", "sml_hybrid_set_fordate_fields", "sml_hybrid_attach_physics", "sml_hybrid_initial_inputs", "sml_hybrid_exchange_and_speedy", "sml_hybrid_safe", "sml_hybrid_timing", "sml_hybrid_timing_collect",
+    "sml_hybrid_g_dev", "sml_hybrid_f_dev", "sml_hybrid_attach_slab", "sml_hybrid_set_comm", "sml_hybrid_restart", "sml_hybrid_slab_due", "sml_hybrid_step", "sml_hybrid_step_predict", "sml_hybrid_step_finish",
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_predict_hybrid", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",
@@ -70,7 +70,7 @@ EXPORTS = [
     "sml_dyn_set_state_host", "sml_dyn_get_state_host", "sml_dyn_set_boundary_host", "sml_dyn_grtend",
     "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_attach_physics", "sml_dyn_set_lradsw", "sml_dyn_set_range_guard", "sml_dyn_physics_diag", "sml_dyn_select_physics_form", "sml_dyn_select_window_form",
     "sml_phys_create", "sml_phys_destroy", "sml_phys_set_surface", "sml_phys_set_sst_dev", "sml_phys_bind_sst_dev", "sml_phys_sol_oz", "sml_phys_get_tables",
-    "sml_phys_tendencies", "sml_phys_tendencies_sfcwind", "sml_phys_diag", "sml_phys_set_fordate_fields", "sml_phys_fordate", "sml_phys_get_surface",
+    "sml_phys_tendencies", "sml_phys_tendencies_sfcwind", "sml_phys_diag", "sml_phys_set_fordate_fields", "sml_phys_update_surface", "sml_phys_fordate", "sml_phys_get_surface",
     "sml_makesparse", "sml_makesparse_draws", "sml_makesparse_from_draws", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",
     "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit", "sml_train_fit_batched", "sml_train_select_solver", "sml_train_release_workspace",
 ]

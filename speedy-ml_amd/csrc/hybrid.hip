@@ -43,6 +43,7 @@ struct sml_hybrid {
     std::vector<void *> owned;
     // phase timing (sml_hybrid_timing): six events per step on the step's stream -- start | predict | all-gather | scatter | SPEEDY leg | gather
     bool timing = false, in_step = false;
+    size_t step_marks0 = 0;
     std::vector<hipEvent_t> marks, spare;
 };
 
@@ -287,6 +288,16 @@ int sml_hybrid_set_fordate_fields(sml_hybrid *h, const double *fmask_s, const do
     return sml_phys_set_fordate_fields(h->phys, fmask_s, alb0, snowd_am, sice_am);
 }
 
+/* the coupler's daily output between two windows (the land model's stl_am and soilw_am, snow depth, sea-ice fraction: src/cpl_land.f90,
+ * src/cpl_sea.f90 -- the coupler itself stays with the host); each array (96,48) or NULL = unchanged.  The next window's
+ * fordate and physics read the new values.  Synchronous. */
+int sml_hybrid_update_surface(sml_hybrid *h, const double *stl_am, const double *soilw_am, const double *snowd_am, const double *sice_am)
+{
+    SML_REQUIRE(h && h->phys, "sml_hybrid_update_surface: sml_hybrid_attach_physics comes first");
+    SML_HIP(hipDeviceSynchronize());
+    return sml_phys_update_surface(h->phys, stl_am, soilw_am, snowd_am, sice_am);
+}
+
 static int tisr_to_G(sml_hybrid *h, int timestep, hipStream_t st)
 {
     if (!h->tisr) return SML_OK;
@@ -444,17 +455,36 @@ int sml_hybrid_slab_due(sml_hybrid *h)
  * leapfrog_steps < 0) of every resident reservoir, predict_slab_ml of the slab reservoirs when due, then the exchange above. */
 int sml_hybrid_step(sml_hybrid *h, int leapfrog_steps, void *stream)
 {
-    SML_REQUIRE(h, "sml_hybrid_step: null handle");
-    const size_t before = h->marks.size();
+    int rc = sml_hybrid_step_predict(h, stream);
+    return rc ? rc : sml_hybrid_step_finish(h, nullptr, leapfrog_steps, stream);
+}
+
+/* The same iteration in two calls, for a host that owns the rank exchange (an MPI or torch.distributed all-gather of the banks' outvec
+ * buffers between the two): step_predict = predict of every resident reservoir (+ predict_slab_ml when due); step_finish = everything
+ * after it, with all_outvec_dev the region-ordered slab [number_of_regions][max_n_out] the host gathered (NULL: the engine's own
+ * exchange, i.e. sml_hybrid_step).  Phase timing covers the pair like a single step (the host's collective counts as the exchange). */
+int sml_hybrid_step_predict(sml_hybrid *h, void *stream)
+{
+    SML_REQUIRE(h, "sml_hybrid_step_predict: null handle");
+    SML_REQUIRE(!h->in_step, "sml_hybrid_step_predict: the previous step was not finished (sml_hybrid_step_finish)");
+    h->step_marks0 = h->marks.size();
     h->in_step = true;
     mark(h, sml::as_stream(stream));
     int rc = sml_bank_predict_all(h->bank, 0, stream);
     if (!rc && sml_hybrid_slab_due(h)) rc = sml_bank_predict_all(h->slab_bank, 0, stream);
     mark(h, sml::as_stream(stream));
-    if (!rc) rc = sml_hybrid_exchange_and_speedy(h, nullptr, leapfrog_steps, stream);
+    if (rc) h->in_step = false;
+    return rc;
+}
+
+int sml_hybrid_step_finish(sml_hybrid *h, const double *all_outvec_dev, int leapfrog_steps, void *stream)
+{
+    SML_REQUIRE(h, "sml_hybrid_step_finish: null handle");
+    SML_REQUIRE(h->in_step, "sml_hybrid_step_finish: sml_hybrid_step_predict comes first");
+    const int rc = sml_hybrid_exchange_and_speedy(h, all_outvec_dev, leapfrog_steps, stream);
     h->in_step = false;
-    if (h->timing && h->marks.size() != before + 6) {          // (a failed step leaves no partial record)
-        while (h->marks.size() > before) { h->spare.push_back(h->marks.back()); h->marks.pop_back(); }
+    if (h->timing && h->marks.size() != h->step_marks0 + 6) {          // (a failed step leaves no partial record)
+        while (h->marks.size() > h->step_marks0) { h->spare.push_back(h->marks.back()); h->marks.pop_back(); }
     }
     return rc;
 }

@@ -135,6 +135,19 @@ int sml_phys_set_surface(sml_phys *ph, const double *fmask, const double *phis0,
     return SML_OK;
 }
 
+int sml_phys_update_surface(sml_phys *ph, const double *tland, const double *swav, const double *snowd_am, const double *sice_am)
+{   // the coupler's daily output (src/cpl_land.f90 / cpl_sea.f90 -> stl_am, soilw_am, snowd_am, sice_am), host arrays [48][96], each optional
+    SML_REQUIRE(ph, "sml_phys_update_surface: null handle");
+    if (tland) SML_HIP(hipMemcpy(ph->surf + 2 * (size_t)GR, tland, GR * sizeof(double), hipMemcpyHostToDevice));
+    if (swav) SML_HIP(hipMemcpy(ph->surf + 4 * (size_t)GR, swav, GR * sizeof(double), hipMemcpyHostToDevice));
+    if (snowd_am || sice_am) {
+        SML_REQUIRE(ph->fordate && ph->fordate_albedo, "sml_phys_update_surface: snow depth / sea ice only enter through fordate's albedos (sml_phys_set_fordate_fields with alb0)");
+        if (snowd_am) SML_HIP(hipMemcpy(ph->fordate + 2 * (size_t)GR, snowd_am, GR * sizeof(double), hipMemcpyHostToDevice));
+        if (sice_am) SML_HIP(hipMemcpy(ph->fordate + 3 * (size_t)GR, sice_am, GR * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return SML_OK;
+}
+
 int sml_phys_set_sst_dev(sml_phys *ph, const double *tsea_dev, void *stream)
 {   // the hybrid model supplies the sea-surface temperature every step (G's SST segment)
     SML_REQUIRE(ph && tsea_dev, "sml_phys_set_sst_dev: bad arguments");

@@ -381,6 +381,11 @@ module speedyml_hip
       real(c_double), intent(in) :: phi0(*)
       integer(c_int) :: rc
     end function
+    function sml_hybrid_update_surface(h, stl_am, soilw_am, snowd_am, sice_am) bind(C, name="sml_hybrid_update_surface") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, stl_am, soilw_am, snowd_am, sice_am          ! c_loc of (96,48) real(8) arrays, or c_null_ptr = unchanged
+      integer(c_int) :: rc
+    end function
     function sml_hybrid_get_phis0(h, phis0) bind(C, name="sml_hybrid_get_phis0") result(rc)
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h

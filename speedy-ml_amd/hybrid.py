@@ -641,10 +641,15 @@ class NativeEngine:
     communicator is given), scatter + clamps, iogrid(30), fordate, the 6-hour window, iogrid(31), TISR, gather + standardise."""
 
     def __init__(self, model, comm=None):
+        """comm: an sml_comm (make_comm) -> the engine all-gathers the outvec slabs itself (RCCL through the C-ABI, as under a Fortran
+        host); None with model.world > 1 -> the rank exchange is the host's: torch.distributed's all-gather between
+        sml_hybrid_step_predict and sml_hybrid_step_finish (the same RCCL, through torch's communicator)."""
         import ctypes as C
 
         from ._lib import check, dp, ip, lib
         assert model.mode == "hybrid" and not model.pipeline
+        assert comm is not None or model.world == 1 or model.slab is None, "the slab coupling across ranks needs the engine's own communicator"
+        self.host_collective = comm is None and model.world > 1
         self.model, self.L, self.C = model, lib(), C
         L, regions, classes = self.L, model.regions, model.classes
         self._h = h = C.c_void_p()
@@ -682,8 +687,14 @@ class NativeEngine:
             self._h = None
 
     def step(self, stream):
-        from ._lib import check, vp
-        check(self.L.sml_hybrid_step(self._h, self.leapfrog_steps, vp(stream)))
+        from ._lib import check, dp, vp
+        if not self.host_collective:
+            check(self.L.sml_hybrid_step(self._h, self.leapfrog_steps, vp(stream)))
+            return True
+        m = self.model
+        check(self.L.sml_hybrid_step_predict(self._h, vp(stream)))
+        allv = gather_outvec_slab(m.outvec, m.regions, m.all_out, m.even_split)          # `stream` must be torch's current stream
+        check(self.L.sml_hybrid_step_finish(self._h, dp(allv.data_ptr()), self.leapfrog_steps, vp(stream)))
         return True
 
     def safe(self):
@@ -723,5 +734,6 @@ class NativeEngine:
         d = self.model.describe()
         d["host"] = "native engine: one sml_hybrid_step call per step (csrc/hybrid.hip), what the Fortran drop-in's sendrecievegrid drives"
         if self.model.world > 1:
-            d["parallelism"] = d["parallelism"].replace("one all-gather", "one sml_comm (RCCL) all-gather")
+            d["parallelism"] = d["parallelism"].replace("one all-gather", "one RCCL all-gather through torch.distributed (between sml_hybrid_step_predict and "
+                                                        "sml_hybrid_step_finish)" if self.host_collective else "one sml_comm (RCCL) all-gather inside the engine")
         return d

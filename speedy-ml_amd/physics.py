@@ -56,6 +56,12 @@ class Physics:
         self._fordate_keep = a
         check(_lib.lib().sml_phys_set_fordate_fields(self._h, *[dp(x) for x in a]))
 
+    def update_surface(self, tland=None, swav=None, snowd_am=None, sice_am=None):
+        """the coupler's daily output between two windows; (48, 96) arrays, None = unchanged"""
+        a = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (tland, swav, snowd_am, sice_am)]
+        assert all(x is None or x.shape == (48, 96) for x in a)
+        check(_lib.lib().sml_phys_update_surface(self._h, *[dp(x) for x in a]))
+
     def fordate(self, spectral, corh_spec, stream=None):
         """fordate(0) on the device: albedos (when their inputs were given), then tcorh | qcorh into corh_spec: a [2, 32, 62] CUDA
         tensor or a raw device address (Dynamics.boundary_ptr() + 32 * 62 * 8)"""

@@ -63,6 +63,61 @@ def test_two_ranks_equal_one_rank(tmp_path):
         assert np.array_equal(d["fb"], fb[regs]) and np.array_equal(d["lm"], lm[regs]), r
 
 
+def _host_collective_worker(rank, world, port, out_dir):
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+    load_package()
+    from speedy_ml_amd import domain, hybrid, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = [int(r) for r in domain.processor_decomposition_manual(rank, world, NREG)]
+    m = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2)
+    eng = hybrid.NativeEngine(m)                    # no sml_comm: the host's collective between the engine's two half-steps
+    assert eng.host_collective
+    stream = torch.cuda.current_stream()
+    eng.timing(True)
+    for _ in range(2):
+        eng.step(stream)
+    t = eng.timing_collect()
+    assert set(t["phases_ms_per_step"]) == {"predict", "allgather", "scatter", "speedy", "gather"} and t["phases_ms_per_step"]["speedy"] > 0
+    g, f = eng.state()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), G=g, F=f, fb=m.feedback.cpu().numpy(), lm=m.local_model.cpu().numpy(), regions=np.array(regions))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_native_engine_with_the_hosts_collective_equals_one_rank(tmp_path):
+    """bench.py's N > 1 path: NativeEngine without an sml_comm -- sml_hybrid_step_predict, the host's all-gather of the outvec slab
+    (torch.distributed; gloo here because both ranks share the box's one GPU, RCCL with one GPU per rank), sml_hybrid_step_finish --
+    against the single-rank engine, bit for bit."""
+    import torch.multiprocessing as mp
+    from speedy_ml_amd import hybrid, synth
+    mp.spawn(_host_collective_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    single = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2)
+    eng = hybrid.NativeEngine(single)
+    stream = torch.cuda.current_stream()
+    for _ in range(2):
+        eng.step(stream)
+    G, F = eng.state()
+    fb, lm = single.feedback.cpu().numpy(), single.local_model.cpu().numpy()
+    for r in range(2):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(d["G"], G) and np.array_equal(d["F"][:152064], F[:152064]), r
+        regs = d["regions"]
+        assert np.array_equal(d["fb"], fb[regs]) and np.array_equal(d["lm"], lm[regs]), r
+    eng.close()
+
+
 def test_rccl_from_the_cabi_single_rank():
     """sml_comm_*: the C-ABI's own RCCL communicator (for a non-Python multi-rank host).  One rank is all a 1-GPU box can
     rehearse: the all-gather must reproduce the bank's outvec slab; the N > 1 path is the same call with a wider communicator."""

@@ -107,6 +107,22 @@ def test_device_fordate_against_the_reference(with_albedo):
     for name in ("snowc", "alb_l", "alb_s", "albsfc"):
         got = ph.surface(name).ravel()
         assert np.array_equal(got, want[name] if with_albedo else given[name].ravel()), name
+    # the coupler's daily output enters between windows: a new land temperature moves qcorh, new snow the albedos
+    if with_albedo:
+        ph.update_surface(tland=i["stl_am"] + 2.0, snowd_am=i["snowd_am"] * 0.5)
+        ph.fordate(sp, dyn.boundary_ptr() + 32 * 62 * 8)
+        bcu = dyn.boundary()
+        assert not np.array_equal(bcu[2], bc[2]) and np.array_equal(bcu[1], bc[1])
+        assert np.array_equal(ph.surface("snowc").ravel(), np.minimum(1.0, i["snowd_am"] * 0.5 / 60.0).ravel())
+        if RefPhys.available():
+            upd = RefPhys(HSG, gaussian_latitudes()).fordate(TYEAR, **dict(i, stl_am=i["stl_am"] + 2.0, snowd_am=i["snowd_am"] * 0.5))
+            assert rel(bcu[2].T, upd["qcorh"]) <= 1e-12 and np.array_equal(ph.surface("albsfc").ravel(), upd["albsfc"])
+        ph.update_surface(tland=i["stl_am"], snowd_am=i["snowd_am"])
+        ph.fordate(sp, dyn.boundary_ptr() + 32 * 62 * 8)
+        assert np.array_equal(dyn.boundary()[2], bc[2])
+    else:
+        with pytest.raises(Exception):
+            ph.update_surface(snowd_am=i["snowd_am"])          # no albedo inputs were given: nothing the snow depth could enter
     # a second call after the SST changed follows it (the hybrid's per-window recomputation)
     sst += 1.5
     ph.fordate(sp, dyn.boundary_ptr() + 32 * 62 * 8)
