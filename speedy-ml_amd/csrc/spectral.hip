@@ -306,8 +306,46 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     GSTAMP(3);
     __syncthreads();
     GSTAMP(4);
-    // Fourier synthesis (gridx) of the 31 retained modes, two longitudes per work item: with A = sum_k Re_k cos(k i t)
+    // Fourier synthesis (gridx) of the 31 retained modes, two longitudes per result: with A = sum_k Re_k cos(k i t)
     // and B = sum_k Im_k sin(k i t),  x_i = a0 + 2(A - B)  and  x_{96-i} = a0 + 2(A + B)   (i = 0..48).
+    if constexpr (FPW == 1) {
+        // On the matrix cores since round 4 (as the forward DFT of k_spec): A and B are two small dense products, (2 LATG rows x 30 modes)
+        // times (30 modes x 49 longitudes), v_mfma_f64_4x4x4_4b with a block = (quad of latitude rows, quad of longitudes) and 8 k-steps
+        // over the modes 1..30 (+ two zero columns).  Operand lane = 16 k + 4 blk + (row | longitude), result lane = 16 row + 4 blk +
+        // longitude.  The vector loop this replaces read four LDS words per multiply-add pair (3.1 of a workgroup's 8 us at the old
+        // geometry, LDS-pipe bound).
+        constexpr int NRQ = 2 * LATG / 4, NIQ = (IX / 2 + 1 + 3) / 4, NBLK = NRQ * NIQ, NGRP = (NBLK + 3) / 4;
+        static_assert((2 * LATG) % 4 == 0, "latitude rows of a workgroup come in quads");
+        const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, x = lane & 3;
+        for (int gq = threadIdx.x >> 6; gq < NGRP; gq += TG / 64) {
+            const int B = 4 * gq + blk, iq = B / NRQ, rq = B % NRQ;
+            const bool bok = B < NBLK && active;
+            const double *fa = sf[rq * 4 + x];                             // this lane's row of Fourier coefficients (A operand)
+            const int ib = iq * 4 + x;                                     // this lane's longitude (B operand)
+            const bool iok = bok && ib <= IX / 2;
+            double A = 0.0, Bq = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int k = 1 + 4 * ks + kq;                             // zonal wavenumber of this lane's operand column
+                const bool kok = k <= MX - 1;
+                const int ph = (k * ib) % IX;
+                const double are = (bok && kok) ? fa[2 * k] : 0.0, aim = (bok && kok) ? fa[2 * k + 1] : 0.0;
+                const double bc = (iok && kok) ? stc[ph] : 0.0, bs = (iok && kok) ? sts[ph] : 0.0;
+                A = __builtin_amdgcn_mfma_f64_4x4x4f64(are, bc, A, 0, 0, 0);
+                Bq = __builtin_amdgcn_mfma_f64_4x4x4f64(aim, bs, Bq, 0, 0, 0);
+            }
+            const int r = rq * 4 + kq, i = iq * 4 + x;                     // result lane = 16 row + 4 blk + longitude
+            if (bok && i <= IX / 2) {
+                const int j = lg * LATG + (r >> 1);
+                const int row = (r & 1) ? IL - 1 - j : j;
+                const double a0 = sf[r][0];
+                double x0 = a0 + 2.0 * (A - Bq), x1 = a0 + 2.0 * (A + Bq);
+                if (kcos != 1) { const double cg = T.cosgr[row]; x0 = x0 * cg; x1 = x1 * cg; }
+                g[row * IX + i] = x0;
+                if (i != 0 && i != IX / 2) g[row * IX + IX - i] = x1;
+            }
+        }
+    } else {
     for (int w = active ? tid : 2 * LATG * (IX / 2 + 1); w < 2 * LATG * (IX / 2 + 1); w += TG) {
         const int i = w % (IX / 2 + 1), r = w / (IX / 2 + 1);
         const int j = lg * LATG + (r >> 1);
@@ -326,6 +364,7 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
         if (kcos != 1) { const double cg = T.cosgr[row]; x0 = x0 * cg; x1 = x1 * cg; }
         g[row * IX + i] = x0;
         if (i != 0 && i != IX / 2) g[row * IX + IX - i] = x1;
+    }
     }
     GSTAMP(5);
 }
@@ -367,30 +406,36 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     GSTAMP(9);
     __syncthreads();
     GSTAMP(10);
-    // forward DFT (specx): a0 = sum x / 96 ; Re_k = sum x cos / 96 ; Im_k = - sum x sin / 96 ; Im of k=0 is set to 0
-    if constexpr (TT == 64 * MG) {
-        // One wavefront per zonal wavenumber, lanes 0..47 = latitudes.  The wavenumber's 49 twiddle pairs are wave-uniform: lane l
-        // keeps pair l and v_readlane broadcasts pair i into scalar registers, so an iteration reads only the two folded data values
-        // from LDS (98 ds_read per thread instead of 196: phase stamps put this phase at 2.7 of a workgroup's 8 us, bound by the
-        // LDS pipe).  Same products in the same order.
-        const int kk = threadIdx.x >> 6, j = threadIdx.x & 63;
-        if (kk < nk) {
-            const double cmine = j <= IX / 2 ? twc[kk][j] : 0.0, smine = j <= IX / 2 ? tws[kk][j] : 0.0;
-            const int clo = __double2loint(cmine), chi = __double2hiint(cmine), slo = __double2loint(smine), shi = __double2hiint(smine);
-            const int jj = j < IL ? j : 0;
-            const double *xs = ss[jj], *xd = sd[jj];
+    // forward DFT (specx): a0 = sum x / 96 ; Re_k = sum x cos / 96 ; Im_k = - sum x sin / 96 ; Im of k=0 is set to 0.
+    // On the matrix cores since round 4: Re[m][lat] = sum_i twc[m][i] ss[lat][i] and S[m][lat] = sum_i tws[m][i] sd[lat][i] are two small
+    // dense products (MG x 49 times 49 x 48), v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 blocks per instruction, a block = (quad of
+    // zonal wavenumbers, quad of latitudes), 13 k-steps over the 49 folded longitudes.  Operand lane = 16 k + 4 blk + (row | column)
+    // and result lane = 16 i + 4 blk + j (measured layout, csrc/train.hip): every lane reads one twiddle and one data value from LDS per
+    // instruction.  The vector form this replaces (one wavefront per wavenumber, lanes = latitudes, twiddles by v_readlane) spent 4.2 of a
+    // workgroup's 8.5 us here at 18 % of the vector rate: 48 of 64 lanes, 11 wavefronts on 4 SIMDs, unfused multiply + add.  Fused
+    // multiply-adds in a fixed order: deterministic, within 1e-15 of the vector form (the DFT never was FFTPACK's operation order).
+    {
+        constexpr int NQ_L = IL / 4, NBLK = ((MG + 3) / 4) * NQ_L, NGRP = (NBLK + 3) / 4;
+        const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, x = lane & 3;
+        const double sc = 1. / (double)IX;
+        for (int g = threadIdx.x >> 6; g < NGRP; g += TT / 64) {
+            const int B = 4 * g + blk, mq = B / NQ_L, lq = B % NQ_L;
+            const int mrow = mq * 4 + x, lrow = lq * 4 + x;               // this lane's twiddle row (A operand) and data row (B operand)
+            const bool bok = B < NBLK, aok = bok && mrow < nk;
             double re = 0.0, im = 0.0;
 #pragma unroll
-            for (int i = 0; i <= IX / 2; ++i) {
-                const double ci = __hiloint2double(__builtin_amdgcn_readlane(chi, i), __builtin_amdgcn_readlane(clo, i));
-                const double si = __hiloint2double(__builtin_amdgcn_readlane(shi, i), __builtin_amdgcn_readlane(slo, i));
-                re += xs[i] * ci;
-                im -= xd[i] * si;          // sd[.][0] = x_0 and sd[.][48] = x_48 meet sin = 0
+            for (int i0 = 0; i0 < IX / 2 + 4; i0 += 4) {
+                const int i = i0 + kq;
+                const bool in = i <= IX / 2;                               // (49 longitudes: the last k-step is one real column and three zeros)
+                const double ac = (aok && in) ? twc[mrow][i] : 0.0, as = (aok && in) ? tws[mrow][i] : 0.0;
+                const double bs = (bok && in) ? ss[lrow][i] : 0.0, bd = (bok && in) ? sd[lrow][i] : 0.0;
+                re = __builtin_amdgcn_mfma_f64_4x4x4f64(ac, bs, re, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f64_4x4x4f64(as, bd, im, 0, 0, 0);
             }
-            if (j < IL) {
-                const double sc = 1. / (double)IX;
-                sf[j][2 * kk] = re * sc;
-                sf[j][2 * kk + 1] = (k0 + kk == 0) ? 0.0 : im * sc;
+            const int kk = mq * 4 + kq, lat = lq * 4 + x;                  // result lane = 16 i + 4 blk + j: i = wavenumber, j = latitude of the quad
+            if (bok && kk < nk) {
+                sf[lat][2 * kk] = re * sc;
+                sf[lat][2 * kk + 1] = (k0 + kk == 0) ? 0.0 : -im * sc;    // sd[.][0] = x_0 and sd[.][48] = x_48 meet sin = 0
             }
         }
     }

@@ -211,8 +211,10 @@ def test_state_of_rest_stays_at_rest(dyn):
 @pytest.mark.parametrize("two_kernel", [False, True])
 def test_window_equals_step_by_step(dyn, oracle, two_kernel, monkeypatch):
     """sml_dyn_window enqueues the whole schedule; with two_kernel it runs every time step as two kernels (zonal-wavenumber
-    space <-> latitude space, k_mspace / k_latspace) instead of four launches over whole fields.  All forms keep the
-    reference's summation orders, so a window must give the same BITS as the same schedule issued step by step."""
+    space <-> latitude space, k_mspace / k_latspace) instead of four launches over whole fields.  The four-launch window must give the
+    same BITS as the same schedule issued step by step.  The two-kernel form (a rejected design kept selectable) keeps the
+    reference's Legendre summation orders but evaluates the Fourier sums with vector multiply-adds, where the four-launch kernels use the
+    matrix cores since round 4: it agrees to 1e-12 of each field's maximum over the 7 steps, not bit for bit."""
     from speedy_ml_amd import _lib
     check = _lib.check
     check(_lib.lib().sml_dyn_select_window_form(1 if two_kernel else 0))
@@ -236,13 +238,18 @@ def test_window_equals_step_by_step(dyn, oracle, two_kernel, monkeypatch):
         dyn.step(b, 2, 2, 2 * DELT)
     torch.cuda.synchronize()
     assert torch.isfinite(a).all()
-    diff = float((a - b).abs().max())
-    assert torch.equal(a, b), diff
+
+    def same(p, q):
+        if not two_kernel:
+            return torch.equal(p, q)
+        scale = q.abs().amax(dim=(2, 3), keepdim=True).clamp(min=1e-300)
+        return float(((p - q).abs() / scale).max()) <= 1e-12
+    assert same(a, b), float((a - b).abs().max())
     # a window without the starter steps (start=False) continues a leapfrog run
     dyn.window(a, 3, start=False)
     for _ in range(3):
         dyn.step(b, 2, 2, 2 * DELT)
-    assert torch.equal(a, b)
+    assert same(a, b)
     check(_lib.lib().sml_dyn_select_window_form(-1))
 
 
