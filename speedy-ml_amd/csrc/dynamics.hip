@@ -629,6 +629,14 @@ struct StepArgs {
 //   FROM_FLUX = true : tendencies start from the forward batch S[73] (dyn_grtend.f90:232-288)
 //   FROM_FLUX = false: tendencies are read from tend_in[33] (testing entry point sml_dyn_spectral_step)
 //   tend_out (optional): the tendencies after sptend/implic/hordif, [vordt(8) | divdt(8) | tdt(8) | trdt(8) | psdt]
+// phase time stamps of workgroup 100 of k_spectral (profiles/micro/spectral_step_stamps.py); compiled in with -DSML_KSPEC_STAMPS only
+__device__ unsigned long long g_kspec_dbg[16];
+#ifdef SML_KSPEC_STAMPS
+#define KSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); \
+        if (blockIdx.x == 100 && threadIdx.x == 0) g_kspec_dbg[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define KSTAMP(slot) do { } while (0)
+#endif
 constexpr int LV_DHS = 0, LV_DHSR = 1, LV_XG1 = 2, LV_XG2 = 3, LV_TCORV = 4, LV_QCORV = 5, LV_TREF = 6, LV_TREF1 = 7, LV_TREF2 = 8,
               LV_TREF3 = 9, LV_DHSX = 10, LV_CORF = 11, LV_FSGR = 12, LV_ROWS = 13;
 
@@ -641,6 +649,7 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
                                                   double *__restrict__ phi_out)
 {
     SML_SPAN(4);
+    KSTAMP(0);
     __shared__ double lv[LV_ROWS][KX];          // level tables, indexed by a lane-varying level
     __shared__ double xdc[2][KX * KX];          // xd, xc
     __shared__ double d4[KX][8], t4[KX][8];     // div and t of time level j4, [level][coefficient]
@@ -648,59 +657,90 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
     const int tid = threadIdx.x, ci = tid & 7, k = tid >> 3;
     const int e = blockIdx.x * 8 + ci;
     const int c = e % MX2, n = e / MX2, m = c >> 1, hm = n * MX + m;
-    {   // level tables (indexed by a lane-varying level below) and the two dense 8x8 matrices -> LDS
-        const double *lvg = imp_x + 128 + LMAX * 64;
-        double *lvf = &lv[0][0];
-        for (int i = tid; i < LV_ROWS * KX; i += 64) lvf[i] = lvg[i];
-        xdc[0][tid] = imp_x[tid];
-        xdc[1][tid] = imp_x[64 + tid];
-    }
-    double vordt, divdt, tdt, trdt, psdt;
+    // ---- EVERY operand of the launch in ONE unconditional batch of loads (round 4).  The version before this one looked batched in the
+    // source, but its conditional loads -- the stencils' first / last total wavenumber, `two ? s2[..] : 0`, the partial second round of
+    // the level tables, `ll != 0 ? ...` -- compiled into 30 exec-masked branches, each with its own s_waitcnt vmcnt(0): a chain of
+    // dependent round trips that was 4.7 of the kernel's 7 us (profiles/micro/spectral_step_stamps.py).  Here every address is clamped
+    // into its array, every load is issued, and what a branch used to skip is selected away afterwards (v_cndmask); the arithmetic keeps
+    // the reference's expressions (a term that is absent at n = 0 or n = 31 enters as a product with zero).
+    const double *lvg = imp_x + 128 + LMAX * 64;
+    const int lv_second = tid + 64 < LV_ROWS * KX ? tid + 64 : LV_ROWS * KX - 1;
+    const double lv_a = lvg[tid], lv_b = lvg[lv_second], xd_v = imp_x[tid], xc_v = imp_x[64 + tid];
+    const int row = n * MX2, rm = (n > 0 ? row - MX2 : row) + c, rp = (n < NX - 1 ? row + MX2 : row) + c, rc = row + (c ^ 1);
+    double s_pm[3], s_pp[3], s_pc[3], s_qm[3], s_qp[3], s_qc[3], s_one[4], t_in[5];
+    double gx = 0., ym = 0., yp = 0., el2 = H.el2[hm];
     if (FROM_FLUX) {
-        const double gx = H.gradx[m], ym = H.vddym[hm], yp = H.vddyp[hm], el2 = H.el2[hm];
-        double dummy;
-        stencil(S + (size_t)k * SP, S + (size_t)(8 + k) * SP, n, c, gx, ym, yp, vordt, divdt);
-        const double lapke = -S[(size_t)(48 + k) * SP + e] * el2;
-        divdt = divdt - lapke;
-        stencil(S + (size_t)(16 + k) * SP, S + (size_t)(24 + k) * SP, n, c, gx, ym, yp, dummy, tdt);
-        tdt = tdt + S[(size_t)(56 + k) * SP + e];
-        stencil(S + (size_t)(32 + k) * SP, S + (size_t)(40 + k) * SP, n, c, gx, ym, yp, dummy, trdt);
-        trdt = trdt + S[(size_t)(64 + k) * SP + e];
-        psdt = S[(size_t)72 * SP + e];
-        if (e < 2) psdt = 0.;
+        gx = H.gradx[m]; ym = H.vddym[hm]; yp = H.vddyp[hm];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double *P = S + (size_t)(16 * q + k) * SP, *Q = S + (size_t)(16 * q + 8 + k) * SP;
+            s_pm[q] = P[rm]; s_pp[q] = P[rp]; s_pc[q] = P[rc];
+            s_qm[q] = Q[rm]; s_qp[q] = Q[rp]; s_qc[q] = Q[rc];
+        }
+        s_one[0] = S[(size_t)(48 + k) * SP + e]; s_one[1] = S[(size_t)(56 + k) * SP + e]; s_one[2] = S[(size_t)(64 + k) * SP + e];
+        s_one[3] = S[(size_t)72 * SP + e];
     } else {
-        vordt = tend_in[(size_t)(F_VOR + k) * SP + e];
-        divdt = tend_in[(size_t)(F_DIV + k) * SP + e];
-        tdt = tend_in[(size_t)(F_T + k) * SP + e];
-        trdt = tend_in[(size_t)(F_TR + k) * SP + e];
-        psdt = tend_in[(size_t)F_PS * SP + e];
+        t_in[0] = tend_in[(size_t)(F_VOR + k) * SP + e]; t_in[1] = tend_in[(size_t)(F_DIV + k) * SP + e];
+        t_in[2] = tend_in[(size_t)(F_T + k) * SP + e]; t_in[3] = tend_in[(size_t)(F_TR + k) * SP + e];
+        t_in[4] = tend_in[(size_t)F_PS * SP + e];
     }
     double *s1 = state, *s2 = state + (size_t)NSTATE * SP;
-    // Everything the diffusion and the leapfrog update need from memory is fetched HERE, in the same batch as the tendencies: the
-    // kernel is a chain of exposed round trips (10.6 us per launch for 0.1 ms of arithmetic), and loads issued after the LDS
-    // phases below each cost another one.
     const size_t ov = (size_t)(F_VOR + k) * SP + e, od = (size_t)(F_DIV + k) * SP + e, ot = (size_t)(F_T + k) * SP + e,
                  oq = (size_t)(F_TR + k) * SP + e, op = (size_t)F_PS * SP + e;
     const bool two = a.j1 != 1;
     const double v1 = s1[ov], d1 = s1[od], t1 = s1[ot], q1 = s1[oq], p1 = s1[op];
-    const double v2 = two ? s2[ov] : 0., d2 = two ? s2[od] : 0., t2 = two ? s2[ot] : 0., q2 = two ? s2[oq] : 0., p2 = two ? s2[op] : 0.;
+    const double v2r = s2[ov], d2r = s2[od], t2r = s2[ot], q2r = s2[oq], p2r = s2[op];          // (always loaded; `two` selects below)
     const double dmp = H.dmp[hm], dmpd = H.dmpd[hm], dmps = H.dmps[hm];
     const double dmp1 = imp_h[hm], dmp1d = imp_h[NX * MX + hm], dmp1s = imp_h[2 * NX * MX + hm];
     const double tch = tcorh[e], qch = qcorh[e], tf = H.trfilt[hm], phis_e = phis[e];
-    // the semi-implicit operands too (a load behind the first barrier is a round trip of its own: barriers fence memory operations)
     const int ll = m + n;
     const double elz = imp_h[3 * NX * MX + hm];
     double xl[KX];
+    {
+        const double *xrow = imp_x + 128 + (size_t)(ll > 0 ? ll - 1 : 0) * 64 + k;
 #pragma unroll
-    for (int k1 = 0; k1 < KX; ++k1) xl[k1] = (a.implicit && ll != 0) ? imp_x[128 + (size_t)(ll - 1) * 64 + k1 * KX + k] : 0.0;
+        for (int k1 = 0; k1 < KX; ++k1) xl[k1] = xrow[k1 * KX];
+    }
+    // ---- from here on nothing is loaded from memory ----
+    {
+        double *lvf = &lv[0][0];
+        lvf[tid] = lv_a;
+        if (tid + 64 < LV_ROWS * KX) lvf[tid + 64] = lv_b;
+        xdc[0][tid] = xd_v;
+        xdc[1][tid] = xc_v;
+    }
+    const double v2 = two ? v2r : 0., d2 = two ? d2r : 0., t2 = two ? t2r : 0., q2 = two ? q2r : 0., p2 = two ? p2r : 0.;
+#pragma unroll
+    for (int k1 = 0; k1 < KX; ++k1) xl[k1] = (a.implicit && ll != 0) ? xl[k1] : 0.0;
+    double vordt, divdt, tdt, trdt, psdt;
+    if (FROM_FLUX) {
+        // the 3-point-in-n stencil of vds (src/spe_spectral.f90:307-349) with the outer rows' missing terms as zero factors:
+        //   A = ym P(n-1) - yp P(n+1) + i x Q ;  B = -ym Q(n-1) + yp Q(n+1) + i x P      (n = 0: no ym term; n = 31: the ym term alone)
+        const double ym_e = n == 0 ? 0. : ym, yp_e = n == NX - 1 ? 0. : yp, g_e = n == NX - 1 ? 0. : gx, sgx = (c & 1) ? g_e : -g_e;
+        double sa[3], sb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            sa[q] = ym_e * s_pm[q] - yp_e * s_pp[q] + sgx * s_qc[q];
+            sb[q] = -ym_e * s_qm[q] + yp_e * s_qp[q] + sgx * s_pc[q];
+        }
+        vordt = sa[0]; divdt = sb[0];
+        const double lapke = -s_one[0] * el2;
+        divdt = divdt - lapke;
+        tdt = sb[1] + s_one[1];
+        trdt = sb[2] + s_one[2];
+        psdt = s_one[3];
+        if (e < 2) psdt = 0.;
+    } else {
+        vordt = t_in[0]; divdt = t_in[1]; tdt = t_in[2]; trdt = t_in[3]; psdt = t_in[4];
+    }
     if (!stop_after_grtend) {
         // ---- sptend (src/dyn_sptend.f90) on time level j4
-        const double *s4 = a.j4 == 1 ? s1 : s2;
-        d4[k][ci] = s4[(size_t)(F_DIV + k) * SP + e];
-        t4[k][ci] = s4[(size_t)(F_T + k) * SP + e];
-        const double ps4 = s4[(size_t)F_PS * SP + e];
-        const double el2 = H.el2[hm];
+        d4[k][ci] = a.j4 == 1 ? d1 : d2r;
+        t4[k][ci] = a.j4 == 1 ? t1 : t2r;
+        const double ps4 = a.j4 == 1 ? p1 : p2r;
+        KSTAMP(1);
         __syncthreads();
+        KSTAMP(2);
         double dmeanc = 0.0;
 #pragma unroll
         for (int j = 0; j < KX; ++j) dmeanc = dmeanc + d4[j][ci] * lv[LV_DHS][j];
@@ -728,6 +768,7 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
             const double g2 = -g1 * el2;
             divdt = divdt - g2;
         }
+        KSTAMP(3);
         // ---- implic (src/dyn_implic.f90)
         if (a.implicit) {
             tds[k][ci] = tdt;
@@ -750,6 +791,7 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
 #pragma unroll
             for (int k1 = 0; k1 < KX; ++k1) tdt = tdt + xdc[1][k1 * KX + k] * dvs[k1][ci];
         }
+        KSTAMP(4);
         // ---- horizontal diffusion (src/dyn_step.f90:60-104, hordif :130-150), always on time level 1
         const double ct = t1 + tch * lv[LV_TCORV][k];
         const double cq = q1 + qch * lv[LV_QCORV][k];
@@ -793,6 +835,7 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
     s1[ot] = nt1; s2[ot] = nt2;
     s1[oq] = nq1; s2[oq] = nq2;
     if (k == 0) { s1[op] = np1; s2[op] = np2; }
+    KSTAMP(5);
     if (phi_out) {
         // geop(1) of the time level 1 this step leaves behind (src/dyn_geop.f90:19-35): what the NEXT step's phypar reads as phig1
         // (src/dyn_grtend.f90:222-224).  The 8 levels of a coefficient are in this wavefront anyway (lane 8 j + ci holds level j); the
@@ -814,6 +857,7 @@ __global__ __launch_bounds__(64) void k_spectral(DevHoriz H, LevelTables L, Step
         }
         phi_out[(size_t)k * SP + e] = phi;
     }
+    KSTAMP(6);
 }
 
 
@@ -1602,6 +1646,13 @@ int sml_dyn_set_boundary(sml_dyn *d, const double *phis_dev, const double *tcorh
 }
 
 SML_SPAN_ATTACH(sml_span_attach_dyn)
+
+int sml_dyn_kspec_stamps(unsigned long long *out16)       // not part of the C-ABI: KSTAMP records of k_spectral (-DSML_KSPEC_STAMPS builds)
+{
+    SML_HIP(hipDeviceSynchronize());
+    SML_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_kspec_dbg), sizeof(unsigned long long) * 16));
+    return SML_OK;
+}
 
 int sml_dyn_phys_stamps(unsigned long long *out48)        // not part of the C-ABI: CSTAMP records of k_gridtend_physics (-DSML_PHYS_STAMPS builds)
 {
