@@ -253,40 +253,95 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     const bool active = f < nf;
     double *sv = sv_all + sub * SPEC_N;
     double (*sf)[MX2] = reinterpret_cast<double (*)[MX2]>(sf_all + sub * 2 * LATG * MX2);
-    int kcos = kcos_all, type = 0, src0 = f, src1 = f;
+    int kcos = kcos_all, type = 0, src0 = active ? f : 0, src1 = src0;      // (an idle half of a two-field workgroup stages field 0 and drops it)
     if (active) {
         if (kcos_of_field) kcos = kcos_of_field[f];
-        if (desc) { type = desc[4 * f]; src0 = desc[4 * f + 1]; src1 = desc[4 * f + 2]; kcos = desc[4 * f + 3]; }
+        if (desc) { const int4 d4 = *reinterpret_cast<const int4 *>(desc + 4 * f); type = d4.x; src0 = d4.y; src1 = d4.z; kcos = d4.w; }
     }
     const double *v = type == 8 ? aux + 24 + SPEC_N + (size_t)src1 * SPEC_N : vorm + (size_t)src0 * SPEC_N;
     double *g = vorg + (size_t)f * GRID_N;
-    // every global load of the workgroup is issued here, in one batch (one exposed memory latency)
-    // Only the coefficients inside the triangular truncation are ever read below (c < nsh2(n), i.e. m < nsh2(n) / 2): staging
-    // just those is 45 % fewer bytes, and the staging phase is where all 462 workgroups of a launch hit L2 at the same moment
-    // (phase stamps: 3.0 of a workgroup's 9 us).  nsh2(n) = min(62, 2 (32 - n)) (parmtr, src/spe_spectral.f90:99-125).
-    // The Legendre slab does not depend on the field's descriptor: its loads go out first and fly under the descriptor round trip.
-    {
-        const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
-        double *pl = &sp[0][0][0];
-        const int m = threadIdx.x & 31;                                  // two (latitude, n) rows of 31 zonal wavenumbers per wavefront
-        for (int row = (threadIdx.x >> 5); row < LATG * NX; row += TG * FPW / 32) {
-            if (m < MX && 2 * m < nsh2_of(row % NX)) pl[row * MX + m] = pg[row * MX + m];
-        }
+    // ---- staging: EVERY global load of the workgroup goes out before the first LDS write (round 4).  The loops this replaces were
+    // rolled -- load, wait, ds_write, next iteration -- so a workgroup walked through 8 + 2 dependent round trips, and the derived rows
+    // (uvspec, grad) added a branch with its own wait per edge case of n.  Now: clamped addresses, unconditional loads into registers,
+    // selects instead of branches; what a branch used to skip enters as a zero factor (the same values up to the sign of a zero).  Only
+    // the coefficients inside the triangular truncation are staged (c < nsh2(n) = min(62, 2 (32 - n)), src/spe_spectral.f90:99-125).
+    constexpr int RPP = TG * FPW / 32, NPASS = (LATG * NX + RPP - 1) / RPP, NFP = (NX + TG / 64 - 1) / (TG / 64);
+    const int pm = threadIdx.x & 31, prow0 = threadIdx.x >> 5;             // Legendre slab: two (latitude, n) rows of 31 wavenumbers per wavefront
+    const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
+    double pv[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+        const int row = prow0 + it * RPP;
+        const bool ok = row < LATG * NX && pm < MX && 2 * pm < nsh2_of(row % NX);
+        pv[it] = pg[ok ? row * MX + pm : 0];
     }
-    // (a wavefront stages whole rows: lane = coefficient within total wavenumber n, no index division per element)
+    // (a wavefront stages whole rows of the field: lane = coefficient within total wavenumber n, no index division per element)
     const int wv = tid >> 6, ln = tid & 63;
-    if (active) {
-        if (type == 0 || type == 8) {
-            for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = v[n * MX2 + ln]; }
-        } else if (type == 7) {
-            for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = derived_coeff(T, 7, v, v, n, ln, src1, aux); }
-        } else {
-            const double *q = vorm + (size_t)src1 * SPEC_N;
-            for (int n = wv; n < NX; n += TG / 64) { if (ln < nsh2_of(n)) sv[n * MX2 + ln] = derived_coeff(T, type, v, q, n, ln); }
+    double fv[NFP];
+    if (type == 0 || type == 8) {
+#pragma unroll
+        for (int it = 0; it < NFP; ++it) {
+            const int n = wv + it * (TG / 64);
+            fv[it] = v[(n < NX && ln < nsh2_of(n)) ? n * MX2 + ln : 0];
+        }
+    } else if (type == 7) {
+#pragma unroll
+        for (int it = 0; it < NFP; ++it) {
+            const int n = wv + it * (TG / 64);
+            fv[it] = (n < NX && ln < nsh2_of(n)) ? derived_coeff(T, 7, v, v, n, ln, src1, aux) : 0.0;       // (first step of a window only)
+        }
+    } else {
+        // uvspec (types 1 | 2, :351-387) and grad (3 | 4, :271-305) of the fields P = src0, Q = src1, as derived_coeff writes them, branch-free:
+        //   1: ym P(n-1) - yp P(n+1) + i gx Q     2: -ym Q(n-1) + yp Q(n+1) + i gx P     3: i gradx P     4: -gradym P(n-1) + gradyp P(n+1)
+        // (n = 0 has no (n-1) term, n = 31 only its (n-1) term)
+        const double *q = vorm + (size_t)src1 * SPEC_N;
+        const double *tx = type <= 2 ? T.uvdx : T.gradx, *tm = type <= 2 ? T.uvdym : T.gradym, *tp = type <= 2 ? T.uvdyp : T.gradyp;
+        const double *M = type == 2 ? q : v, *X = type == 1 ? q : v;        // neighbours in n come from M, the rotated partner from X
+        double dm[NFP], dp[NFP], dx[NFP], cm[NFP], cp[NFP], cx[NFP];
+#pragma unroll
+        for (int it = 0; it < NFP; ++it) {
+            const int n = wv + it * (TG / 64);
+            const bool ok = n < NX && ln < nsh2_of(n);
+            const int nn = ok ? n : 0, c = ok ? ln : 0, m = c >> 1, row = nn * MX2;
+            dm[it] = M[(nn > 0 ? row - MX2 : row) + c];
+            dp[it] = M[(nn < NX - 1 ? row + MX2 : row) + c];
+            dx[it] = X[row + (c ^ 1)];
+            cm[it] = tm[nn * MX + m];
+            cp[it] = tp[nn * MX + m];
+            cx[it] = type >= 3 ? tx[m] : tx[nn * MX + m];                 // (gradx is per zonal wavenumber, uvdx per coefficient; unused by type 4)
+        }
+#pragma unroll
+        for (int it = 0; it < NFP; ++it) {
+            const int n = wv + it * (TG / 64);
+            const double ym_e = n == 0 ? 0. : cm[it], yp_e = n == NX - 1 ? 0. : cp[it];
+            const double gx_e = (type <= 2 && n == NX - 1) ? 0. : cx[it], sgx = (ln & 1) ? gx_e : -gx_e;
+            if (type == 1) fv[it] = ym_e * dm[it] - yp_e * dp[it] + sgx * dx[it];
+            else if (type == 2) fv[it] = -ym_e * dm[it] + yp_e * dp[it] + sgx * dx[it];
+            else if (type == 3) fv[it] = sgx * dx[it];
+            else fv[it] = -ym_e * dm[it] + yp_e * dp[it];
         }
     }
-    for (int i = threadIdx.x; i < IX; i += TG * FPW) { stc[i] = T.twc[i]; sts[i] = T.tws[i]; }
-    if (threadIdx.x < NX) snsh[threadIdx.x] = T.nsh2[threadIdx.x];
+    const int ti = threadIdx.x < IX ? threadIdx.x : 0, ni = threadIdx.x < NX ? threadIdx.x : 0;
+    const double twc_v = T.twc[ti], tws_v = T.tws[ti];
+    const int nsh_v = T.nsh2[ni];
+    // ---- nothing is loaded below this line ----
+    {
+        double *pl = &sp[0][0][0];
+#pragma unroll
+        for (int it = 0; it < NPASS; ++it) {
+            const int row = prow0 + it * RPP;
+            if (row < LATG * NX && pm < MX && 2 * pm < nsh2_of(row % NX)) pl[row * MX + pm] = pv[it];
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int it = 0; it < NFP; ++it) {
+            const int n = wv + it * (TG / 64);
+            if (n < NX && ln < nsh2_of(n)) sv[n * MX2 + ln] = fv[it];
+        }
+    }
+    if (threadIdx.x < IX) { stc[threadIdx.x] = twc_v; sts[threadIdx.x] = tws_v; }
+    if (threadIdx.x < NX) snsh[threadIdx.x] = nsh_v;
     GSTAMP(1);
     __syncthreads();
     GSTAMP(2);
@@ -388,21 +443,49 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     const int k0 = mg * MG, nk = min(MG, MX - k0);
     const double *g = vorg + (size_t)f * GRID_N;
     double *v = vorm + (size_t)f * SPEC_N;
-    for (int w = threadIdx.x; w < IL * (IX / 2 + 1); w += TT) {
-        const int i = w % (IX / 2 + 1), j = w / (IX / 2 + 1);
-        double a = g[j * IX + i], b = (i == 0 || i == IX / 2) ? 0.0 : g[j * IX + IX - i];
-        if (scale == 1) { const double cg = T.cosgr[j]; a = a * cg; b = b * cg; }
-        else if (scale == 2) { const double cg = T.cosgr2[j]; a = a * cg; b = b * cg; }
-        ss[j][i] = a + b;
-        sd[j][i] = a - b;
+    // staging: all of these global loads first (registers), the LDS writes after them -- as a rolled loop (load, wait, fold, ds_write,
+    // next) this was four dependent round trips per thread (round 4, see k_grid).  The 24 Legendre-table values of the analysis at the
+    // end stay where they are: fetched here as well they make the launch's start slower by what they save at its end (measured again
+    // in round 4: workgroup 6.6 against 5.5 us).
+    constexpr int NSP = (IL * (IX / 2 + 1) + TT - 1) / TT;
+    double ga[NSP], gb[NSP], cgv[NSP];
+#pragma unroll
+    for (int it = 0; it < NSP; ++it) {
+        const int w = threadIdx.x + it * TT, wc = w < IL * (IX / 2 + 1) ? w : 0;
+        const int i = wc % (IX / 2 + 1), j = wc / (IX / 2 + 1);
+        ga[it] = g[j * IX + i];
+        gb[it] = g[j * IX + ((i == 0 || i == IX / 2) ? i : IX - i)];
+        cgv[it] = scale == 2 ? T.cosgr2[j] : T.cosgr[j];
     }
-    for (int w = threadIdx.x; w < MG * (IX / 2 + 1); w += TT) {
-        const int i = w % (IX / 2 + 1), kk = w / (IX / 2 + 1);
+    constexpr int NTP = (MG * (IX / 2 + 1) + TT - 1) / TT;
+    double tcv[NTP], tsv[NTP];
+#pragma unroll
+    for (int it = 0; it < NTP; ++it) {
+        const int w = threadIdx.x + it * TT, wc = w < MG * (IX / 2 + 1) ? w : 0;
+        const int i = wc % (IX / 2 + 1), kk = wc / (IX / 2 + 1);
         const int ph = ((k0 + kk) * i) % IX;
-        twc[kk][i] = T.twc[ph];
-        tws[kk][i] = T.tws[ph];
+        tcv[it] = T.twc[ph];
+        tsv[it] = T.tws[ph];
     }
-    if (threadIdx.x < IY) swt[threadIdx.x] = T.wt[threadIdx.x];
+    const double wt_v = T.wt[threadIdx.x < IY ? threadIdx.x : 0];
+    // ---- nothing is loaded from here to the Legendre table below ----
+#pragma unroll
+    for (int it = 0; it < NSP; ++it) {
+        const int w = threadIdx.x + it * TT;
+        if (w < IL * (IX / 2 + 1)) {
+            const int i = w % (IX / 2 + 1), j = w / (IX / 2 + 1);
+            double a = ga[it], b = (i == 0 || i == IX / 2) ? 0.0 : gb[it];
+            if (scale == 1 || scale == 2) { a = a * cgv[it]; b = b * cgv[it]; }
+            ss[j][i] = a + b;
+            sd[j][i] = a - b;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NTP; ++it) {
+        const int w = threadIdx.x + it * TT;
+        if (w < MG * (IX / 2 + 1)) { twc[w / (IX / 2 + 1)][w % (IX / 2 + 1)] = tcv[it]; tws[w / (IX / 2 + 1)][w % (IX / 2 + 1)] = tsv[it]; }
+    }
+    if (threadIdx.x < IY) swt[threadIdx.x] = wt_v;
     GSTAMP(9);
     __syncthreads();
     GSTAMP(10);
