@@ -50,6 +50,19 @@ struct TrainSlot { double *states; int n; };      // a slot's states(n, .) buffe
 // train_slots (optional): the training pass also wants the new state as column train_col of the slot's states buffer, in the
 // REFERENCE's row order with the even (1-based) rows squared (src/mod_reservoir.f90:1133) -- stored from here, one launch less
 // per time column than a separate copy kernel.
+// Pointers that come out of a reservoir descriptor in memory are generic to the compiler, and loads through them are FLAT loads: they
+// count on BOTH wait counters, so every wait for an LDS gather (lgkmcnt) also waits for whatever global loads are in flight -- which is
+// what kept a prefetch of the next slice's entries from ever overlapping the current slice's gathers (rounds 2-3: "prefetch: slower").
+// The descriptor's arrays live in device memory by construction (sml_bank_load_*): say so, and the loads are global loads (vmcnt only).
+typedef const double __attribute__((address_space(1))) *gcd_t;
+typedef double __attribute__((address_space(1))) *gd_t;
+typedef const unsigned short __attribute__((address_space(1))) *gcus_t;
+typedef const int __attribute__((address_space(1))) *gci_t;
+__device__ __forceinline__ gcd_t as_global(const double *p) { return (gcd_t)p; }
+__device__ __forceinline__ gd_t as_global(double *p) { return (gd_t)p; }
+__device__ __forceinline__ gcus_t as_global(const unsigned short *p) { return (gcus_t)p; }
+__device__ __forceinline__ gci_t as_global(const int *p) { return (gci_t)p; }
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
                                                      int parts, const double *__restrict__ u_all, int u_stride, int cur, int square_input,
@@ -67,41 +80,51 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     if (res >= res_end) return;
     const ResDesc &D = descs[res];   // (by reference: a copy with x[cur] indexed at run time lives in scratch, 136 B per lane)
     if (!D.loaded) return;
-    const double *__restrict__ x = cur ? D.x[1] : D.x[0];
-    double *__restrict__ xn = cur ? D.x[0] : D.x[1];
-    const double *__restrict__ u = u_all + (size_t)res * u_stride;
-    // stage [x ; u] with 16-byte loads (x is 256-byte aligned)
-    const int n2 = D.n >> 1;
-    if (!square_input) {
-        for (int i = threadIdx.x; i < n2; i += THREADS) reinterpret_cast<f64x2 *>(xu)[i] = reinterpret_cast<const f64x2 *>(x)[i];
-    } else {
-        for (int i = threadIdx.x; i < n2; i += THREADS) {
-            f64x2 v = reinterpret_cast<const f64x2 *>(x)[i];
-            v[1] = v[1] * v[1];                      // device position parity == reference row parity (see load_common)
-            reinterpret_cast<f64x2 *>(xu)[i] = v;
-        }
-    }
-    if ((D.n & 1) && threadIdx.x == 0) xu[D.n - 1] = x[D.n - 1];
-    for (int i = threadIdx.x; i < D.d; i += THREADS) xu[D.n + i] = u[i];
-    __syncthreads();
+    const gcd_t x = as_global(cur ? D.x[1] : D.x[0]);
+    const gd_t xn = as_global(cur ? D.x[0] : D.x[1]);
+    const gcd_t u = as_global(u_all) + (size_t)res * u_stride;
+    const gci_t slice_off = as_global(D.slice_off);
+    const gcus_t sell_col = as_global(D.sell_col);
+    const gcd_t sell_val = as_global(D.sell_val);
+    const int nslices = D.nslices, n = D.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = THREADS / 64;
     const int stride = parts * NW;
     int s = part * NW + wave;
+    // the first slice's metadata goes out before [x ; u] is staged
+    int off_n = 0, end_n = 0;
+    if (s < nslices) { off_n = slice_off[s]; end_n = slice_off[s + 1]; }
+    // stage [x ; u] with 16-byte loads (x is 256-byte aligned)
+    typedef const f64x2 __attribute__((address_space(1))) *gcd2_t;
+    const int n2 = n >> 1;
+    if (!square_input) {
+        for (int i = threadIdx.x; i < n2; i += THREADS) reinterpret_cast<f64x2 *>(xu)[i] = ((gcd2_t)x)[i];
+    } else {
+        for (int i = threadIdx.x; i < n2; i += THREADS) {
+            f64x2 v = ((gcd2_t)x)[i];
+            v[1] = v[1] * v[1];                      // device position parity == reference row parity (see load_common)
+            reinterpret_cast<f64x2 *>(xu)[i] = v;
+        }
+    }
+    if ((n & 1) && threadIdx.x == 0) xu[n - 1] = x[n - 1];
+    for (int i = threadIdx.x; i < D.d; i += THREADS) xu[n + i] = u[i];
+    __syncthreads();
     // slice metadata is fetched one slice ahead (and, for the first slice, before [x ; u] is staged), so each slice costs
     // one exposed memory round trip (its entries) instead of two
-    int off_n = 0, end_n = 0;
-    if (s < D.nslices) { off_n = D.slice_off[s]; end_n = D.slice_off[s + 1]; }
-    for (; s < D.nslices; s += stride) {
+    for (; s < nslices; s += stride) {
         const int off = off_n, width = (end_n - off_n) >> 6;
-        if (s + stride < D.nslices) { off_n = D.slice_off[s + stride]; end_n = D.slice_off[s + stride + 1]; }
+        if (s + stride < nslices) { off_n = slice_off[s + stride]; end_n = slice_off[s + stride + 1]; }
         const int r = s * 64 + lane;                      // device position == sorted position: contiguous stores
-        const unsigned short *__restrict__ cp = D.sell_col + off + lane;
-        const double *__restrict__ vp = D.sell_val + off + lane;
+        const gcus_t cp = sell_col + off + lane;
+        const gcd_t vp = sell_val + off + lane;
         double acc = 0.0;
         // The whole row (makesparse gives 6-8 stored entries per row incl. W_in) is fetched in ONE batch of loads before
         // the first LDS gather: PMC showed 78 % of the wave cycles parked in s_waitcnt, and a 4-wide loop plus a scalar tail
         // exposed the memory latency four times per slice.  Accumulation stays in storage order (A in COO order, then W_in).
+        // (Round 4: the descriptor's arrays are addressed as GLOBAL memory -- through the generic pointers of the descriptor these were
+        // flat loads, which count on the LDS wait counter as well.  With that out of the way the next slice's batch was prefetched under
+        // this slice's gathers once more: 0.178 ms at the 111 registers it needs (4 wavefronts per SIMD), 0.32 ms spilling at 80 --
+        // against 0.112: the kernel lives on 24 wavefronts per CU, not on one wavefront's look-ahead.)
         constexpr int WB = 8;
         int cc[WB];
         double vv[WB];
@@ -133,19 +156,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc += v4[q] * x4[q];
         }
-        if (r < D.n) {
+        if (r < n) {
 #ifdef SML_EXPERIMENT_NO_TANH                            // (profiles/micro/update_floor.sh: what the update costs without its tanh)
             const double xt = acc;
 #else
             const double xt = tanh(acc);
 #endif
-            const double v = (1.0 - D.leak) * (square_input ? x[r] : xu[r]) + D.leak * xt;
+            const double v = (1.0 - D.leak) * (square_input ? (double)x[r] : xu[r]) + D.leak * xt;
             xn[r] = v;
             if (train_slots) {
                 const TrainSlot t = train_slots[res];
                 if (t.states) {
                     const int rr = D.perm[r];              // device position -> reference row (same parity)
-                    t.states[(size_t)train_col * D.n + rr] = (rr & 1) ? v * v : v;
+                    t.states[(size_t)train_col * n + rr] = (rr & 1) ? v * v : v;
                 }
             }
         }
