@@ -35,7 +35,7 @@ if stats:
             out["kernels"][k] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
                                  "ms_per_step": float(row["TotalDurationNs"]) / steps / 1e6}
 for ctr, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{ctr}_{tag}", "*", "*counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{ctr}_{tag}", "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)[:1]:
         agg = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             k = short(row["Kernel_Name"])

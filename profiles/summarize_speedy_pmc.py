@@ -31,7 +31,7 @@ out = {"tag": tag, "passes": {}, "kernels": {}}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 for p in ("sq1", "sq2", "tcc", "fetch", "write"):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", f"spmc_{p}_{tag}", "*", "*counter_collection.csv"))
+    files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"spmc_{p}_{tag}", "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not files:
         continue
     out["passes"][p] = os.path.relpath(files[0], ROOT)
