@@ -402,6 +402,11 @@ int sml_spectral_grid_derived_aux(sml_spectral *sp, const double *spec_base_dev,
  * (:307-349); truncate != 0 applies trunct (:540-551).  iogrid(30)'s vdspec/spec/trunct (src/ppo_iogrid.f90:530-547) is
  * sml_spectral_spec_mixed + this. */
 int sml_spectral_spec_post(sml_spectral *sp, const double *spec_in_dev, const int32_t *desc_dev, double *spec_out_dev, int nf_out, void *stream);
+/* the same with the last nf_out2 output fields written to a second array (desc_dev has nf_out + nf_out2 rows): the hybrid engine
+ * transforms fordate's two correction fields (spec(corh, tcorh), spec(corh, qcorh), src/ini_fordate.f90:86,113) in iogrid(30)'s
+ * launch and wants them in the time steps' boundary arrays */
+int sml_spectral_spec_post_split(sml_spectral *sp, const double *spec_in_dev, const int32_t *desc_dev, double *spec_out_dev, int nf_out,
+                                 double *spec_out2_dev, int nf_out2, void *stream);
 int sml_spectral_vdspec(sml_spectral *sp, const double *ug_dev, const double *vg_dev, double *vorm_dev,
                         double *divm_dev, int nf, int kcos, void *stream);                                    /* :416-452 */
 int sml_spectral_uvspec(sml_spectral *sp, const double *vorm_dev, const double *divm_dev, double *ucosm_dev,

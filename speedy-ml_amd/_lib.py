@@ -63,7 +63,7 @@ EXPORTS = [
     "sml_slab_sizes", "sml_slab_create", "sml_slab_destroy", "sml_slab_scatter_sst", "sml_slab_predict_hybrid", "sml_slab_update_inputs",
     "sml_exchange_pack_outvec", "sml_handoff_to_fields", "sml_handoff_from_fields", "sml_handoff_check",
     "sml_spectral_create", "sml_spectral_destroy", "sml_spectral_get_table", "sml_spectral_grid",
-    "sml_spectral_spec", "sml_spectral_grid_mixed", "sml_spectral_grid_derived", "sml_spectral_grid_derived_aux", "sml_spectral_spec_post", "sml_spectral_spec_mixed", "sml_spectral_vdspec", "sml_spectral_uvspec", "sml_spectral_vds", "sml_spectral_grad",
+    "sml_spectral_spec", "sml_spectral_grid_mixed", "sml_spectral_grid_derived", "sml_spectral_grid_derived_aux", "sml_spectral_spec_post", "sml_spectral_spec_post_split", "sml_spectral_spec_mixed", "sml_spectral_vdspec", "sml_spectral_uvspec", "sml_spectral_vds", "sml_spectral_grad",
     "sml_spectral_lap", "sml_spectral_invlap", "sml_spectral_trunct",
     "parmtr_", "inifft_", "grid_", "spec_", "vdspec_", "uvspec_", "vds_", "grad_", "lap_", "invlap_", "trunct_",
     "sml_dyn_create", "sml_dyn_destroy", "sml_dyn_impint", "sml_dyn_get_table", "sml_dyn_set_boundary", "sml_dyn_boundary_dev", "sml_dyn_state_dev",

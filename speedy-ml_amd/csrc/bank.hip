@@ -595,7 +595,7 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
         attr_set = true;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (b->timing) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
+    if (b->timing) { SML_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence)); SML_HIP(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence)); SML_HIP(hipEventRecord(e0, st)); }
     if (threads == 1024)
         hipLaunchKernelGGL(k_update<1024>, dim3(nblocks), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     else if (threads == 256)
@@ -653,7 +653,7 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
         const int parts = (b->max_n_out_loaded + 17 - 1) / 17;
         const unsigned total = (unsigned)(nres8 * parts);
         if (flags & 8) SML_HIP(hipMemsetAsync(b->d_counter, 0, sizeof(unsigned), st));
-        if (timed) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
+        if (timed) { SML_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence)); SML_HIP(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence)); SML_HIP(hipEventRecord(e0, st)); }
 #define ROP_LAUNCH(W, MINW, NWG)                                                                                                     \
         hipLaunchKernelGGL((k_readout_persist<17, W, MINW>), dim3(NWG), dim3((W) * 64), 0, st, b->d_descs, res_begin, res_end, parts, \
                            b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags & 7, b->d_partial, b->d_counter, total)
@@ -666,7 +666,7 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
         if (timed) { SML_HIP(hipEventRecord(e1, st)); b->ev_readout.emplace_back(e0, e1); }
         return SML_OK;
     }
-    if (timed) { SML_HIP(hipEventCreate(&e0)); SML_HIP(hipEventCreate(&e1)); SML_HIP(hipEventRecord(e0, st)); }
+    if (timed) { SML_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence)); SML_HIP(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence)); SML_HIP(hipEventRecord(e0, st)); }
 #define RO_LAUNCH(R, T, NT)                                                                                             \
     {                                                                                                                   \
         const int parts = (b->max_n_out_loaded + (R) - 1) / (R);                                                        \

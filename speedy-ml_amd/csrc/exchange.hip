@@ -159,6 +159,61 @@ __global__ void k_check(const double *__restrict__ fields, int32_t *__restrict__
     if (bad || v != v) *safe = 0;
 }
 
+// The end of a hybrid step in ONE launch (the engine's form of k_from_fields + the TISR copy + k_gather2, three launches of 4-9 us
+// each with their boundaries): blocks [0, nblk_fields) write SPEEDY's forecast F from iogrid(31)'s 33 grid fields (k_from_fields) and
+// the TISR slice of the next step into G; the blocks after them, one per resident reservoir, gather + standardise its next feedback
+// (from G) and local_model (from F).  The gathering blocks do not wait for the first group: what they would read from F or from G's TISR
+// segment they form themselves from the fields / the slice, with the same expressions, so both groups hold the same values.
+__global__ __launch_bounds__(256) void k_egress(const ResDesc *__restrict__ descs, const double *__restrict__ fields, const double *__restrict__ tisr_slice,
+                                                 double *__restrict__ g, double *__restrict__ fo, GatherArgs a0, GatherArgs a1, int nblk_fields, int nslots)
+{
+    if ((int)blockIdx.x < nblk_fields) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        if (t < NFIELD * NGP) {
+            const int f = t / NGP, p = t % NGP;
+            double v = fields[t];
+            if (f < 32) {
+                const int var = f >> 3, k = f & 7;
+                if (var == 3 && v < 0.000001) v = 0.000001;          // run_model, src/mpires.f90:1648-1650
+                fo[SML_G4_OFF + ((size_t)k * NGP + p) * 4 + var] = v;
+            } else {
+                fo[SML_G2_OFF + p] = v;
+            }
+        } else if (t < (NFIELD + 1) * NGP && tisr_slice) {
+            g[SML_GT_OFF + t - NFIELD * NGP] = tisr_slice[t - NFIELD * NGP];
+        }
+        return;
+    }
+    const int slot = blockIdx.x - nblk_fields;
+    if (slot >= nslots) return;
+    const ResDesc &D = descs[slot];
+    for (int j = threadIdx.x; j < a0.stride + a1.stride; j += 256) {
+        const bool first = j < a0.stride;
+        const GatherArgs &a = first ? a0 : a1;
+        const int jj = first ? j : j - a0.stride;
+        const int gi = a.map[(size_t)slot * a.stride + jj];
+        if (gi < 0) continue;
+        double v;
+        if (first) {
+            v = (gi >= SML_GT_OFF && tisr_slice) ? tisr_slice[gi - SML_GT_OFF] : a.src[gi];
+        } else if (gi < SML_G2_OFF) {
+            const int var = gi & 3, rest = gi >> 2, k = rest / NGP, p = rest % NGP;
+            v = fields[(size_t)(var * 8 + k) * NGP + p];
+            if (var == 3 && v < 0.000001) v = 0.000001;
+        } else if (gi < SML_GP_OFF) {
+            v = fields[(size_t)32 * NGP + gi - SML_G2_OFF];
+        } else {
+            v = a.src[gi];                                           // (segments of F this launch does not write)
+        }
+        const int si = a.stat[(size_t)slot * a.stride + jj];
+        if (si >= 0) {
+            v = __dsub_rn(v, D.mean[si]);
+            v = v / D.stdv[si];
+        }
+        a.dst[(size_t)slot * a.stride + jj] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -293,3 +348,20 @@ int sml_exchange_gather(sml_exchange *ex, const double *g_dev, const double *f_d
 }
 
 }  // extern "C"
+
+namespace sml {
+// engine-internal (csrc/hybrid.hip): iogrid(31)'s copy-out, the next TISR slice and both gathers in one launch (k_egress)
+int exchange_egress(sml_exchange *ex, const double *fields_out_dev, const double *tisr_slice_dev, double *g_dev, double *f_dev, hipStream_t st)
+{
+    SML_REQUIRE(ex && fields_out_dev && g_dev && f_dev, "exchange_egress: bad arguments");
+    int rc = sml::bank_sync_descs(ex->bank);
+    if (rc) return rc;
+    GatherArgs a0{g_dev, ex->d_in_map, ex->d_in_stat, ex->bank->d_feedback, ex->in_stride};
+    GatherArgs a1{f_dev, ex->d_lm_map, ex->d_lm_stat, ex->bank->d_local_model, ex->lm_stride};
+    const int nblk_fields = ((NFIELD + 1) * NGP + 255) / 256;
+    hipLaunchKernelGGL(k_egress, dim3(nblk_fields + ex->nslots), dim3(256), 0, st, ex->bank->d_descs, fields_out_dev, tisr_slice_dev, g_dev, f_dev, a0, a1,
+                       nblk_fields, ex->nslots);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+}  // namespace sml

@@ -8,9 +8,11 @@
 // -- on top of the same kernels the Python host (speedy-ml_amd/hybrid.py) drives: sml_exchange_*, sml_handoff_*, sml_spectral_*,
 // sml_dyn_window.  SPEEDY is one global T30 model: every rank runs this replica on the full grids.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "bank.h"
+#include "physics_dev.h"
 
 namespace {
 constexpr int IX = 96, IL = 48, GR = IX * IL, SPF = 32 * 62, NFIELD = 33, NSTATE = 33;
@@ -31,6 +33,10 @@ struct sml_hybrid {
     double *base_sst = nullptr, *tisr = nullptr, *all_out = nullptr;
     int32_t *sea_mask = nullptr, *in_scale = nullptr, *in_desc = nullptr, *out_desc = nullptr, *safe = nullptr;
     int32_t *region_index = nullptr;
+    int32_t *src_of_cell = nullptr;          // [SML_GS_OFF] which outvec element lands in a cell of G's grid4d | logp | precip: region * 256 + k, -1 = none
+    int32_t *slot_of_region = nullptr;       // [nreg] this rank's slot of a region, -1 = not resident
+    int32_t *in_desc35 = nullptr, *in_scale35 = nullptr;
+    bool fused = true;                       // SML_HYBRID_FUSED_HANDOFF=0: the hand-off as the separate launches the Python host issues
     int start_hours = 12000 + 24 * 14, timestep_hours = 6, t = 0, phys_day = -1;
     // optional: the rank exchange (RCCL all-gather of the outvec slabs) and the slab-ocean coupling (config 5)
     sml_comm *comm = nullptr;
@@ -66,12 +72,74 @@ __global__ void k_place_rows(const double *__restrict__ outvec, const int32_t *_
     all_out[(long)region_of_slot[s] * width + o] = outvec[t];
 }
 
+// The start of a hybrid step's SPEEDY leg in ONE launch (the engine's form of k_place_rows + k_scatter + k_sst + k_to_fields + k_fordate,
+// five launches of about 4 us each with their boundaries).  Written as a gather: every cell of G's grid4d | logp | precip segments is
+// tiled by exactly one region's outvec element (src/res_domain.f90:791-826), so the thread of a cell fetches that element, applies the
+// clamps of src/mpires.f90:460-462,486-490, stores the cell and -- for the 33 fields of iogrid(30) -- its real(4)-rounded copy with
+// q < 0 cleared (src/ppo_iogrid.f90:499-513).  The SST cells follow k_sst (base SST under the sea mask, 272 K floor, :470-484) and
+// go straight on into fordate's grid-point statements (smlphys::fordate_point), whose two correction fields land behind the 33.
+// Same expressions on the same values as the separate kernels: the Python host, which still issues those, gives the same bits.
+struct IngestArgs {
+    const double *bank_out, *all_out;       // this rank's outvec rows [slot][stride] | the region-ordered slab [region][stride]
+    const int32_t *src_of_cell, *slot_of_region;       // slot_of_region == NULL: every row comes from the slab
+    int stride;
+    double *G, *fields;
+    const double *base_sst;
+    const int32_t *sea_mask;
+    int with_fordate;
+    smlphys::FordatePoint fd;
+    double *corh;                            // the physics handle's copy of fordate's two grid fields (sml_phys_get_surface 10 / 11)
+};
+__global__ __launch_bounds__(256) void k_ingest(IngestArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (NFIELD + 2) * GR) return;
+    const int f = t / GR, p = t % GR;
+    if (f == NFIELD + 1) {                   // SST cell (k_sst), then fordate at this point
+        double v = a.G[SML_GS_OFF + p];
+        if (a.base_sst && (!a.sea_mask || a.sea_mask[p] > 0)) v = a.base_sst[p];
+        if (v < 272.0) v = 272.0;
+        a.G[SML_GS_OFF + p] = v;
+        if (a.with_fordate) {
+            double ct, cq;
+            smlphys::fordate_point(a.fd, p, v, ct, cq);
+            a.corh[p] = ct; a.corh[GR + p] = cq;
+            a.fields[(size_t)NFIELD * GR + p] = ct; a.fields[(size_t)(NFIELD + 1) * GR + p] = cq;
+        }
+        return;
+    }
+    int gi;
+    if (f < 32) gi = SML_G4_OFF + ((f & 7) * GR + p) * 4 + (f >> 3);          // field f: 0..7 T(k), 8..15 u(k), 16..23 v(k), 24..31 q(k)
+    else if (f == 32) gi = SML_G2_OFF + p;
+    else gi = SML_GP_OFF + p;
+    const int src = a.src_of_cell[gi];
+    double v;
+    if (src >= 0) {
+        const int r = src >> 8, k = src & 255;
+        const int slot = a.slot_of_region ? a.slot_of_region[r] : -1;
+        v = slot >= 0 ? a.bank_out[(size_t)slot * a.stride + k] : a.all_out[(size_t)r * a.stride + k];
+        if (gi < SML_G2_OFF) {
+            if ((gi & 3) == 3 && v < 0.000001) v = 0.000001;                 // specific humidity floor (mpires.f90:460-462)
+        } else if (gi >= SML_GP_OFF) {
+            if (v < 0.00001) v = 0.0;                                       // precip (:486-490)
+        }
+        a.G[gi] = v;
+    } else {
+        v = a.G[gi];
+    }
+    if (f < NFIELD) {
+        float v4 = (float)v;                           // ugr4..psgr4 are real(4): quirk Q3
+        if (f >= 24 && f < 32 && v4 < 0.0f) v4 = 0.0f;  // where(qgr4 < 0.0) qgr4 = 0.0
+        a.fields[t] = (double)v4;
+    }
+}
+
 void mark(sml_hybrid *h, hipStream_t st)
 {
     if (!h->timing || !h->in_step) return;
     hipEvent_t e = nullptr;
     if (!h->spare.empty()) { e = h->spare.back(); h->spare.pop_back(); }
-    else if (hipEventCreate(&e) != hipSuccess) return;
+    else if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return;      // (timing only: no system-scope release with every mark)
     (void)hipEventRecord(e, st);
     h->marks.push_back(e);
 }
@@ -148,9 +216,9 @@ int sml_hybrid_create(sml_bank *bank, int number_of_regions, const int32_t *regi
     HY(sml_dyn_state_dev(h->dyn, &h->state));
     HY(dalloc(h, &h->G, SML_G_SIZE));
     HY(dalloc(h, &h->F, SML_G_SIZE));
-    HY(dalloc(h, &h->fields, (size_t)NFIELD * GR));
+    HY(dalloc(h, &h->fields, (size_t)(NFIELD + 2) * GR));            // (+ fordate's two correction fields, transformed in the same launch)
     HY(dalloc(h, &h->fields_out, (size_t)NFIELD * GR));
-    HY(dalloc(h, &h->raw_spec, (size_t)NFIELD * SPF));
+    HY(dalloc(h, &h->raw_spec, (size_t)(NFIELD + 2) * SPF));
     HY(dalloc(h, &h->bc, (size_t)3 * SPF));
     HY(dalloc(h, &h->base_sst, (size_t)GR));
     HY(dalloc(h, &h->safe, 1));
@@ -173,6 +241,32 @@ int sml_hybrid_create(sml_bank *bank, int number_of_regions, const int32_t *regi
     HY(upload_i32(h, &h->in_scale, scale));
     HY(upload_i32(h, &h->in_desc, ind));
     HY(upload_i32(h, &h->out_desc, outd));
+    {
+        std::vector<int32_t> scale35(scale), ind35(ind);
+        scale35.insert(scale35.end(), {0, 0});                                     // spec(corh, tcorh), spec(corh, qcorh): plain spec, no trunct
+        ind35.insert(ind35.end(), {0, NFIELD, NFIELD, 0, 0, NFIELD + 1, NFIELD + 1, 0});
+        HY(upload_i32(h, &h->in_scale35, scale35));
+        HY(upload_i32(h, &h->in_desc35, ind35));
+    }
+    {
+        // the scatter of src/res_domain.f90:791-826 turned round: which outvec element tiles a cell of G (k_ingest)
+        static const bool want_fused = !(getenv("SML_HYBRID_FUSED_HANDOFF") && atoi(getenv("SML_HYBRID_FUSED_HANDOFF")) == 0);
+        h->fused = want_fused && bank->max_n_out <= 256;
+        std::vector<int32_t> src(SML_GS_OFF, -1), slot_of(number_of_regions, -1), tmp_g(8 * 96 * 48 * 8), tmp_s(8 * 96 * 48 * 8);
+        for (int s = 0; s < nslots; ++s) slot_of[region_of_slot[s]] = s;
+        for (int r = 0; r < number_of_regions && h->fused; ++r) {
+            const int n = sml_domain_out_map(number_of_regions, r, 1, 1, 0, precip_bool, tmp_g.data(), tmp_s.data(), (int)tmp_g.size());
+            if (n < 0) { sml_hybrid_destroy(h); return n; }
+            for (int i = 0; i < n && i < bank->max_n_out; ++i) {
+                const int gi = tmp_g[i];
+                if (gi < 0) continue;
+                if (gi >= SML_GS_OFF || src[gi] >= 0) { h->fused = false; break; }      // (a layout the gather form does not cover: separate launches)
+                src[gi] = r * 256 + i;
+            }
+        }
+        HY(upload_i32(h, &h->src_of_cell, src));
+        HY(upload_i32(h, &h->slot_of_region, slot_of));
+    }
     HY(upload_i32(h, &h->region_index, std::vector<int32_t>(region_of_slot, region_of_slot + nslots)));
     HY(sml_dyn_set_range_guard(h->dyn, h->safe));
 #undef HY
@@ -334,9 +428,13 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
         hipLaunchKernelGGL(k_place_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double *)bank->d_outvec, h->region_index, h->nslots,
                            bank->max_n_out, all);
     };
+    const bool fused = h->fused;
+    bool rows_from_bank = false;
     if (!slab) {
         // the gather-to-root of src/mpires.f90:347-454: with a communicator, ONE all-gather of the outvec slab; a single rank places its rows
+        // (fused hand-off: k_ingest reads them where they are)
         if (h->comm) { if ((rc = sml_comm_allgather_outvec(h->comm, h->bank, h->nreg, h->all_out, stream))) return rc; }
+        else if (fused) rows_from_bank = true;
         else { place(h->bank, h->all_out); SML_HIP(hipGetLastError()); }
         slab = h->all_out;
     }
@@ -347,17 +445,41 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
         else { place(h->slab_bank, h->all_slab_out); SML_HIP(hipGetLastError()); }
         if ((rc = sml_slab_scatter_sst(h->slab, h->all_slab_out, h->slab_bank->max_n_out, h->sea_of_region, h->G, stream))) return rc;
     }
-    if ((rc = sml_exchange_scatter(h->ex, slab, h->G, h->base_sst, h->sea_mask, stream))) return rc;
-    mark(h, st);
-    // iogrid(30)
-    if ((rc = sml_handoff_to_fields(h->G, h->fields, stream))) return rc;
-    if ((rc = sml_spectral_spec_mixed(h->sp, h->fields, h->raw_spec, NFIELD, h->in_scale, stream))) return rc;
-    if ((rc = sml_spectral_spec_post(h->sp, h->raw_spec, h->in_desc, h->state, NSTATE, stream))) return rc;
+    if (fused) {
+        // scatter + clamps + SST + iogrid(30)'s real(4) fields + fordate(0)'s grid-point work: one launch; then ONE forward transform of
+        // the 33 fields and fordate's two, and one pointwise pass that leaves time level 1 in the state and tcorh | qcorh in the boundary
+        sml_phys *ph = h->phys;
+        IngestArgs a{};
+        a.bank_out = h->bank->d_outvec; a.all_out = slab; a.src_of_cell = h->src_of_cell; a.slot_of_region = rows_from_bank ? h->slot_of_region : nullptr;
+        a.stride = h->bank->max_n_out; a.G = h->G; a.fields = h->fields; a.base_sst = h->base_sst; a.sea_mask = h->sea_mask;
+        a.with_fordate = ph ? 1 : 0;
+        if (ph) {
+            SML_REQUIRE(ph->fordate, "sml_hybrid_step: sml_phys_set_fordate_fields has not been called");
+            double *f = ph->fordate, *surf = ph->surf;
+            a.fd = smlphys::FordatePoint{ph->dev.fmask, f, ph->dev.phis0, ph->dev.tland, ph->fordate_albedo ? f + GR : nullptr, f + 2 * GR, f + 3 * GR,
+                                         surf + 5 * GR, surf + 6 * GR, surf + 7 * GR, surf + 8 * GR};
+            a.corh = f + 4 * GR;
+        }
+        hipLaunchKernelGGL(k_ingest, dim3(((NFIELD + 2) * GR + 255) / 256), dim3(256), 0, st, a);
+        SML_HIP(hipGetLastError());
+        mark(h, st);
+        const int extra = ph ? 2 : 0;
+        if ((rc = sml_spectral_spec_mixed(h->sp, h->fields, h->raw_spec, NFIELD + extra, ph ? h->in_scale35 : h->in_scale, stream))) return rc;
+        if ((rc = sml_spectral_spec_post_split(h->sp, h->raw_spec, ph ? h->in_desc35 : h->in_desc, h->state, NSTATE,
+                                               ph ? sml_dyn_boundary_dev(h->dyn) + SPF : nullptr, extra, stream))) return rc;
+    } else {
+        if ((rc = sml_exchange_scatter(h->ex, slab, h->G, h->base_sst, h->sea_mask, stream))) return rc;
+        mark(h, st);
+        // iogrid(30)
+        if ((rc = sml_handoff_to_fields(h->G, h->fields, stream))) return rc;
+        if ((rc = sml_spectral_spec_mixed(h->sp, h->fields, h->raw_spec, NFIELD, h->in_scale, stream))) return rc;
+        if ((rc = sml_spectral_spec_post(h->sp, h->raw_spec, h->in_desc, h->state, NSTATE, stream))) return rc;
+    }
     if (h->phys) {
         // fordate(0) of this window's agcm_init (src/ini_agcm_init.f90:86): albedos, tcorh, and qcorh from sst_am = the SST just
         // scattered into G, straight into the time steps' boundary fields; then its sol_oz(tyear), tyear = (day of the 365-day year
         // - 0.5) / 365 (src/ini_fordate.f90:52), which changes once a day
-        if ((rc = sml_phys_fordate(h->phys, h->sp, sml_dyn_boundary_dev(h->dyn) + SPF, stream))) return rc;
+        if (!fused && (rc = sml_phys_fordate(h->phys, h->sp, sml_dyn_boundary_dev(h->dyn) + SPF, stream))) return rc;
         int32_t date[4];
         if ((rc = sml_calendar_date(1981, h->start_hours + h->t * h->timestep_hours, date)) < 0) return rc;
         static const int ndaycal[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};
@@ -375,12 +497,25 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
     }
     // iogrid(31)
     if ((rc = sml_spectral_grid_derived(h->sp, h->state, h->out_desc, h->fields_out, NFIELD, stream))) return rc;
-    if ((rc = sml_handoff_from_fields(h->fields_out, h->F, stream))) return rc;
-    mark(h, st);
-    // next inputs: get_tisr_by_date(timestep - 1) (src/mpires.f90:750), then tile + standardise
-    h->t += 1;
-    if ((rc = tisr_to_G(h, h->t - 1, st))) return rc;
-    if ((rc = sml_exchange_gather(h->ex, h->G, h->F, stream))) return rc;
+    if (fused) {
+        // F from the 33 grid fields, get_tisr_by_date(timestep - 1) (src/mpires.f90:750) and the next inputs (tile + standardise): one launch
+        mark(h, st);
+        h->t += 1;
+        const double *slice = nullptr;
+        if (h->tisr) {
+            const int idx = sml_tisr_index(1981, h->start_hours + (h->t - 1) * h->timestep_hours);
+            if (idx < 1) return idx;
+            slice = h->tisr + (size_t)(idx - 1) * GR;
+        }
+        if ((rc = sml::exchange_egress(h->ex, h->fields_out, slice, h->G, h->F, st))) return rc;
+    } else {
+        if ((rc = sml_handoff_from_fields(h->fields_out, h->F, stream))) return rc;
+        mark(h, st);
+        // next inputs: get_tisr_by_date(timestep - 1) (src/mpires.f90:750), then tile + standardise
+        h->t += 1;
+        if ((rc = tisr_to_G(h, h->t - 1, st))) return rc;
+        if ((rc = sml_exchange_gather(h->ex, h->G, h->F, stream))) return rc;
+    }
     // the slab reservoirs' inputs: ring column mod(timestep - 1, R) + 1 and the running mean (src/mpires.f90:776-781)
     if (h->slab && (rc = sml_slab_update_inputs(h->slab, h->t, stream))) return rc;
     mark(h, st);

@@ -61,23 +61,11 @@ __global__ __launch_bounds__(256) void k_fordate(const double *__restrict__ fmas
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= GR) return;
-    if (alb0) {                                                        // :54-61
-        const double sc = fmin(1., snowd_am[p] / SD2SC);
-        const double al = alb0[p] + sc * (ALBSN - alb0[p]);
-        const double as = ALBSEA + sice_am[p] * (ALBICE - ALBSEA);
-        snowc[p] = sc; alb_l[p] = al; alb_s[p] = as;
-        albsfc[p] = as + fmask_l[p] * (al - as);
-    }
-    const double gamlat = GAMMA / (1000. * GG);                        // setgam :116-136
-    const double ct = gamlat * phis0[p];                               // :77
-    const double pexp = 1. / (RD * gamlat);                            // :91
-    const double tsfc = fmask_l[p] * stl_am[p] + fmask_s[p] * sst_am[p];
-    const double tref = tsfc + ct;
-    const double psfc = pow(tsfc / tref, pexp);
-    const double qref = qsat_of(tref, 1.0);                            // shtorh(0, ngp, tref, psfc_dummy = 1, -1., ...): P = ps(1)
-    const double qsfc = qsat_of(tsfc, 1. * psfc);                      // shtorh(0, ngp, tsfc, psfc, 1., ...): P = sig ps(j), sig = 1
+    const FordatePoint a{fmask_l, fmask_s, phis0, stl_am, alb0, snowd_am, sice_am, alb_l, alb_s, albsfc, snowc};
+    double ct, cq;
+    fordate_point(a, p, sst_am[p], ct, cq);
     corh[p] = ct;
-    corh[GR + p] = REFRH1 * (qref - qsfc);                             // :109
+    corh[GR + p] = cq;
 }
 
 }  // namespace

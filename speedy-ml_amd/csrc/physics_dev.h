@@ -148,6 +148,34 @@ __device__ __forceinline__ double qsat_of(double ta, double p)
     return 622. * q / (p - 0.378 * q);
 }
 
+// fordate(0)'s grid-point work for one point (src/ini_fordate.f90:54-61,72-109), statements in the reference's order; sst = sst_am
+// of the point (in the hybrid: the SST just assembled from the reservoirs' outputs).  Shared by the stand-alone kernel (physics.hip)
+// and the hybrid engine's ingest kernel (hybrid.hip), which has the SST in a register when it gets here.
+struct FordatePoint {
+    const double *fmask_l, *fmask_s, *phis0, *stl_am, *alb0, *snowd_am, *sice_am;      // alb0 == NULL: albedos are the host's
+    double *alb_l, *alb_s, *albsfc, *snowc;
+};
+__device__ __forceinline__ void fordate_point(const FordatePoint &a, int p, double sst, double &corh_t, double &corh_q)
+{
+    if (a.alb0) {                                                      // :54-61
+        const double sc = fmin(1., a.snowd_am[p] / SD2SC);
+        const double al = a.alb0[p] + sc * (ALBSN - a.alb0[p]);
+        const double as = ALBSEA + a.sice_am[p] * (ALBICE - ALBSEA);
+        a.snowc[p] = sc; a.alb_l[p] = al; a.alb_s[p] = as;
+        a.albsfc[p] = as + a.fmask_l[p] * (al - as);
+    }
+    const double gamlat = GAMMA / (1000. * GG);                        // setgam :116-136
+    const double ct = gamlat * a.phis0[p];                             // :77
+    const double pexp = 1. / (RD * gamlat);                            // :91
+    const double tsfc = a.fmask_l[p] * a.stl_am[p] + a.fmask_s[p] * sst;
+    const double tref = tsfc + ct;
+    const double psfc = pow(tsfc / tref, pexp);
+    const double qref = qsat_of(tref, 1.0);                            // shtorh(0, ngp, tref, psfc_dummy = 1, -1., ...): P = ps(1)
+    const double qsfc = qsat_of(tsfc, 1. * psfc);                      // shtorh(0, ngp, tsfc, psfc, 1., ...): P = sig ps(j), sig = 1
+    corh_t = ct;
+    corh_q = REFRH1 * (qref - qsfc);                                   // :109
+}
+
 // Level arrays are 1-based like the Fortran.  Every level index below is a compile-time constant once the loops are unrolled
 // (run-time tops -- convection top, cloud top -- are predicates inside fixed-bound loops), so the arrays live in registers: with
 // run-time indices the compiler put them in scratch (1264 B per lane) and the kernel spent most of its 26 us waiting on scratch

@@ -605,7 +605,10 @@ __global__ void k_uvvds(DevTables T, const double *__restrict__ P, const double 
 
 // Spectral post-processing by descriptor (sml_spectral_spec_post): out field f = trunct?( type 0: field src0 | type 5 / 6: vor /
 // div of vds(ucos = src0, vcos = src1) ).  Same expressions as k_uvvds followed by k_scale(OP_TRUNCT).
-__global__ void k_post(DevTables T, const double *__restrict__ in, const int *__restrict__ desc, double *__restrict__ out, int total)
+// Output fields past the first total_main / SPEC_N go to out2 (the hybrid engine transforms fordate's two correction fields in the same
+// launch as iogrid(30)'s 33 and wants them in the time steps' boundary arrays, not behind the state).
+__global__ void k_post(DevTables T, const double *__restrict__ in, const int *__restrict__ desc, double *__restrict__ out, int total,
+                       double *__restrict__ out2, int total_main)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -629,7 +632,8 @@ __global__ void k_post(DevTables T, const double *__restrict__ in, const int *__
         }
     }
     if (trunc) v = v * T.trfilt[n * MX + m];
-    out[t] = v;
+    if (t < total_main) out[t] = v;
+    else out2[t - total_main] = v;
 }
 
 // grad (:271-305)
@@ -835,7 +839,21 @@ int sml_spectral_spec_post(sml_spectral *sp, const double *spec_in, const int32_
     SML_REQUIRE(sp && nf_out >= 0 && (nf_out == 0 || (spec_in && desc_dev && spec_out)), "sml_spectral_spec_post: bad arguments");
     if (!nf_out) return SML_OK;
     const int total = nf_out * SPEC_N;
-    hipLaunchKernelGGL(k_post, dim3((total + 255) / 256), dim3(256), 0, sml::as_stream(stream), sp->d, spec_in, (const int *)desc_dev, spec_out, total);
+    hipLaunchKernelGGL(k_post, dim3((total + 255) / 256), dim3(256), 0, sml::as_stream(stream), sp->d, spec_in, (const int *)desc_dev, spec_out, total,
+                       (double *)nullptr, total);
+    SML_HIP(hipGetLastError());
+    return SML_OK;
+}
+
+int sml_spectral_spec_post_split(sml_spectral *sp, const double *spec_in, const int32_t *desc_dev, double *spec_out, int nf_out, double *spec_out2,
+                                 int nf_out2, void *stream)
+{
+    SML_REQUIRE(sp && nf_out >= 0 && nf_out2 >= 0 && spec_in && desc_dev && (nf_out == 0 || spec_out) && (nf_out2 == 0 || spec_out2),
+                "sml_spectral_spec_post_split: bad arguments");
+    if (!(nf_out + nf_out2)) return SML_OK;
+    const int total = (nf_out + nf_out2) * SPEC_N;
+    hipLaunchKernelGGL(k_post, dim3((total + 255) / 256), dim3(256), 0, sml::as_stream(stream), sp->d, spec_in, (const int *)desc_dev, spec_out, total,
+                       spec_out2, nf_out * SPEC_N);
     SML_HIP(hipGetLastError());
     return SML_OK;
 }

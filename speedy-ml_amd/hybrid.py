@@ -558,10 +558,12 @@ class HybridRank:
     def _phase_events(self, stream):
         return self._Phases(self.torch, stream, self._phase_log)
 
-    def timing(self, on):
+    def timing(self, on, phases=True):
+        """HIP events around the bank's two predict kernels; phases: also around each phase of the step (five more event records per
+        step on the step's stream -- each one a barrier packet the dependent launches queue behind)"""
         from ._lib import check, lib
         check(lib().sml_bank_timing(self.bank._h, 1 if on else 0))
-        self._phase_on = bool(on) and self.mode == "hybrid" and not self.pipeline
+        self._phase_on = bool(on) and phases and self.mode == "hybrid" and not self.pipeline
 
     def timing_collect(self):
         """per-kernel totals of the bank (HIP events around k_update / k_readout) and, for the sequential hybrid step, the time of
@@ -713,10 +715,10 @@ class NativeEngine:
         check(self.L.sml_hybrid_get_state(self._h, dp(g), dp(f)))
         return g, f
 
-    def timing(self, on):
+    def timing(self, on, phases=True):
         from ._lib import check
         check(self.L.sml_bank_timing(self.model.bank._h, 1 if on else 0))
-        check(self.L.sml_hybrid_timing(self._h, 1 if on else 0))
+        check(self.L.sml_hybrid_timing(self._h, 1 if (on and phases) else 0))
 
     def timing_collect(self):
         from ._lib import check, dp
