@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) void k_gridtend(DevHoriz H, LevelTables L, cons
 // components) and the flux products go straight to the forward batch O; ttend and qtend go to the workgroup's park (P_TT, P_QT), where
 // phypar's accumulators start from them; utend(kx), vtend(kx) are returned (the physics adds the surface stress to them).
 __device__ __forceinline__ void gridpoint_dynamics(const DevHoriz &H, const LevelTables &L, const double *__restrict__ G, double *__restrict__ O, int p,
-                                                   double *park, int lane, double &u_dyn_out, double &v_dyn_out)
+                                                   double *park, int lane, double &u_dyn_out, double &v_dyn_out, int32_t *guard = nullptr)
 {
         const int j = p / IX;
         smlphys::LA tt = smlphys::park_array(park, smlphys::P_TT, lane), qt = smlphys::park_array(park, smlphys::P_QT, lane);   // 1-based levels
@@ -370,6 +370,16 @@ __device__ __forceinline__ void gridpoint_dynamics(const DevHoriz &H, const Leve
             vg[k] = G[(size_t)(40 + k) * GR + p];
         }
         double px = G[(size_t)48 * GR + p], py = G[(size_t)49 * GR + p];
+        if (guard) {
+            // iogrid(30)'s range guard (see k_range_guard) on the values this wavefront has just loaded: the first time step of a hybrid
+            // window checks T, q, u, v of time level 1 here instead of in a launch of its own behind the step
+            bool ok = true;
+    #pragma unroll
+            for (int k = 0; k < KX; ++k)
+                ok = ok && tg[k] >= 160.0 && tg[k] <= 330.0 && trg[k] >= -6.0 && trg[k] <= 30.0 && ug[k] >= -150.0 && ug[k] <= 150.0 && vg[k] >= -120.0 &&
+                     vg[k] <= 120.0;                                      // (a NaN fails every comparison)
+            if (!ok) *guard = 0;
+        }
         double umean = 0.0, vmean = 0.0, dmean = 0.0;
     #pragma unroll
         for (int k = 0; k < KX; ++k) {
@@ -510,7 +520,8 @@ __device__ __forceinline__ void park_barrier()
 struct ParkBarrier { __device__ __forceinline__ void operator()() const { park_barrier(); } };
 
 __global__ __launch_bounds__(192) void k_gridtend_physics3(DevHoriz H, LevelTables L, const double *__restrict__ G, double *__restrict__ O,
-                                                            smlphys::PhysLev PL, smlphys::PhysDev PD, smlphys::PhysIn PG, int lradsw, int want_diag)
+                                                            smlphys::PhysLev PL, smlphys::PhysDev PD, smlphys::PhysIn PG, int lradsw, int want_diag,
+                                                            int32_t *guard)
 {
     SML_SPAN(2);
     __shared__ double park[smlphys::PARK_DOUBLES];
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(192) void k_gridtend_physics3(DevHoriz H, LevelTabl
     CSTAMP(0);
     if (wave == 0) {
         double u_dyn, v_dyn;
-        gridpoint_dynamics(H, L, G, O, p, park, lane, u_dyn, v_dyn);
+        gridpoint_dynamics(H, L, G, O, p, park, lane, u_dyn, v_dyn, guard);
         smlphys::LA uv = smlphys::park_array(park, smlphys::P_UV, lane);
         uv[0] = u_dyn; uv[1] = v_dyn;
         CSTAMP(1);
@@ -1386,7 +1397,7 @@ int g_physics_fused = 3;     // sml_dyn_select_physics_form
 // phi_ready: the previous launch of this window's k_spectral left geop(1) of the current time level 1 in d->aux (its phi_out), so
 // the inverse set takes the physics' eight geopotential levels from there (descriptor type 8) instead of rebuilding them (type 7)
 int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend, double *tend_out, hipStream_t st, int lradsw = 1, bool phi_ready = false,
-             bool leave_phi = false)
+             bool leave_phi = false, int32_t *guard = nullptr)
 {
     const double *sj2 = state + (size_t)(a.j2 - 1) * NSTATE * SP;
     // the 50 inverse transforms of grtend (:61-99) straight from the state: uvspec and grad are formed while the fields are staged.
@@ -1401,7 +1412,7 @@ int run_step(sml_dyn *d, double *state, const StepArgs &a, int stop_after_grtend
         smlphys::PhysIn in{pg, pg + (size_t)GR, pg + (size_t)2 * GR, pg + (size_t)10 * GR, pg + (size_t)18 * GR, pg + (size_t)26 * GR};
         if (g_physics_fused == 3)
             hipLaunchKernelGGL(k_gridtend_physics3, dim3(GR / 64), dim3(192), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
-                               d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag);
+                               d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag, guard);
         else if (g_physics_fused == 2)
             hipLaunchKernelGGL(k_gridtend_physics_onewave, dim3(GR / 64), dim3(64), 0, st, d->d, d->cur->lv, d->batch_grid, d->tend_grid, d->phys->lev,
                                d->phys->dev, in, lradsw ? 1 : 0, d->phys_diag);
@@ -1814,8 +1825,11 @@ int sml_dyn_window(sml_dyn *d, double *state_dev, int start, int nsteps, double 
             rc = sml_dyn_impint(d, sched[i].dt_imp, alph);
             // (within one window every step integrates, so step i > 0 finds the geopotential of its time level 1 where step i - 1's
             // spectral kernel left it; the first step -- after a hand-off, or a host that touched the state -- rebuilds it)
-            if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st, sched[i].lradsw, i > 0, i + 1 < sched.size());
-            if (!rc && i == 0 && start && d->guard) {       // the first step's inverse set is still in batch_grid
+            // iogrid(30)'s range guard looks at the first step's inverse set: inside that step's grid-point kernel (three-wavefront form),
+            // else in a launch of its own behind the step, while the set is still in batch_grid
+            const bool guard_now = i == 0 && start && d->guard, guard_inside = guard_now && d->phys && g_physics_fused == 3;
+            if (!rc) rc = run_step(d, state_dev, sched[i].a, 0, nullptr, st, sched[i].lradsw, i > 0, i + 1 < sched.size(), guard_inside ? d->guard : nullptr);
+            if (!rc && guard_now && !guard_inside) {
                 hipLaunchKernelGGL(k_range_guard, dim3((32 * GR + 255) / 256), dim3(256), 0, st, (const double *)d->batch_grid, d->guard);
                 SML_HIP(hipGetLastError());
             }

@@ -176,6 +176,26 @@ def test_safety_guard_trips(model):
         assert int(safe.item()) == expect, (f, val)
 
 
+@pytest.mark.parametrize("physics", [True, False])
+def test_window_range_guard_trips_on_unphysical_wind(physics):
+    """The guard of iogrid(30) inside the window (src/ppo_iogrid.f90:563-577 on the grids of the truncated state): with the physics attached
+    the first time step's grid-point kernel checks the T, q, u, v it has just loaded, without it a launch of its own behind that step does;
+    a physical state passes both, a jet of several hundred m/s trips both."""
+    sea = synth.land_mask()
+    m = hybrid.HybridRank(list(range(hybrid.NREG)), hybrid.region_classes(sea), sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2, physics=physics)
+    stream = torch.cuda.current_stream()
+    assert m.step(stream) is True
+    torch.cuda.synchronize()
+    assert int(m.safe.item()) == 1
+    m.dyn.window(m.state, 1, start=True, stream=stream)
+    torch.cuda.synchronize()
+    assert int(m.safe.item()) == 1
+    m.state[0, 2] *= 40.0                                          # vorticity of the third level, time level 1
+    m.dyn.window(m.state, 1, start=True, stream=stream)
+    torch.cuda.synchronize()
+    assert int(m.safe.item()) == 0
+
+
 def test_hybrid_closed_loop_stays_physical(model):
     """Two days of closed-loop hybrid steps: states stay finite and inside iogrid(30)'s physical-range guard."""
     m = model
