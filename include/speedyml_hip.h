@@ -540,6 +540,8 @@ int sml_phys_fordate(sml_phys *phys, sml_spectral *sp, double *corh_spec_dev, vo
 int sml_phys_get_surface(sml_phys *phys, int which, double *out_host);
 /* sol_oz(tyear) (src/phy_radiat.f90:1-83): zonal solar / ozone fields for the day, tyear = fraction of the year */
 int sml_phys_sol_oz(sml_phys *phys, double tyear);
+/* the same enqueued on a stream (the values travel as kernel arguments): no host synchronisation -- what the hybrid engine calls once per model day */
+int sml_phys_sol_oz_async(sml_phys *phys, double tyear, void *stream);
 /* host copies for tests: zonal [6][48] = fsol ozone ozupp zenit stratz sqrt(clat); fband [301][4]; levels [9][9] = sig sigl
  * dsig sigh grdsig grdscp wvi(:,2) wvi(:,1) entr with level index 1..8 (NULL to skip any) */
 int sml_phys_get_tables(sml_phys *phys, double *zonal_host, double *fband_host, double *levels_host);

@@ -69,7 +69,7 @@ EXPORTS = [
     "sml_dyn_create", "sml_dyn_destroy", "sml_dyn_impint", "sml_dyn_get_table", "sml_dyn_set_boundary", "sml_dyn_boundary_dev", "sml_dyn_state_dev",
     "sml_dyn_set_state_host", "sml_dyn_get_state_host", "sml_dyn_set_boundary_host", "sml_dyn_grtend",
     "sml_dyn_spectral_step", "sml_dyn_step", "sml_dyn_window", "sml_dyn_attach_physics", "sml_dyn_set_lradsw", "sml_dyn_set_range_guard", "sml_dyn_physics_diag", "sml_dyn_select_physics_form", "sml_dyn_select_window_form",
-    "sml_phys_create", "sml_phys_destroy", "sml_phys_set_surface", "sml_phys_set_sst_dev", "sml_phys_bind_sst_dev", "sml_phys_sol_oz", "sml_phys_get_tables",
+    "sml_phys_create", "sml_phys_destroy", "sml_phys_set_surface", "sml_phys_set_sst_dev", "sml_phys_bind_sst_dev", "sml_phys_sol_oz", "sml_phys_sol_oz_async", "sml_phys_get_tables",
     "sml_phys_tendencies", "sml_phys_tendencies_sfcwind", "sml_phys_diag", "sml_phys_set_fordate_fields", "sml_phys_update_surface", "sml_phys_fordate", "sml_phys_get_surface",
     "sml_makesparse", "sml_makesparse_draws", "sml_makesparse_from_draws", "sml_spectral_radius", "sml_gen_res", "sml_bank_train_pass",
     "sml_train_accumulate", "sml_train_symmetrize", "sml_train_fit", "sml_train_fit_batched", "sml_train_select_solver", "sml_train_release_workspace",

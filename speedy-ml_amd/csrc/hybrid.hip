@@ -486,7 +486,7 @@ int sml_hybrid_exchange_and_speedy(sml_hybrid *h, const double *all_outvec_dev, 
         const int day = ndaycal[date[1] - 1] + date[2];
         if (day != h->phys_day) {
             h->phys_day = day;
-            if ((rc = sml_phys_sol_oz(h->phys, (day - 0.5) / 365.0))) return rc;
+            if ((rc = sml_phys_sol_oz_async(h->phys, (day - 0.5) / 365.0, stream))) return rc;
         }
     }
     if (leapfrog_steps >= 0) {

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256) void k_fordate(const double *__restrict__ fmas
     corh[GR + p] = cq;
 }
 
+struct ZonalArgs { double z[6 * IL]; };
+__global__ void k_set_zonal(ZonalArgs a, double *__restrict__ zonal) { zonal[threadIdx.x] = a.z[threadIdx.x]; }
+
 }  // namespace
 
 extern "C" {
@@ -199,6 +202,19 @@ int sml_phys_sol_oz(sml_phys *ph, double tyear)
     sol_oz(tyear, ph->clat, ph->slat, z, z + IL, z + 2 * IL, z + 3 * IL, z + 4 * IL);
     for (int j = 0; j < IL; ++j) z[5 * IL + j] = std::sqrt(ph->clat[j]);
     SML_HIP(hipMemcpy(ph->zonal, z, sizeof z, hipMemcpyHostToDevice));
+    return SML_OK;
+}
+
+/* the same in stream order: the 288 values travel as kernel arguments (no host synchronisation: a blocking copy once per model day
+ * drained the hybrid engine's queue every fourth step) */
+int sml_phys_sol_oz_async(sml_phys *ph, double tyear, void *stream)
+{
+    SML_REQUIRE(ph, "sml_phys_sol_oz_async: null handle");
+    ZonalArgs a;
+    sol_oz(tyear, ph->clat, ph->slat, a.z, a.z + IL, a.z + 2 * IL, a.z + 3 * IL, a.z + 4 * IL);
+    for (int j = 0; j < IL; ++j) a.z[5 * IL + j] = std::sqrt(ph->clat[j]);
+    hipLaunchKernelGGL(k_set_zonal, dim3(1), dim3(6 * IL), 0, sml::as_stream(stream), a, ph->zonal);
+    SML_HIP(hipGetLastError());
     return SML_OK;
 }
 

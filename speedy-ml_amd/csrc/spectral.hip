@@ -347,7 +347,24 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     GSTAMP(2);
     // Legendre synthesis (gridy): E over odd n (1-based), O over even n; north = E+O, south = E-O.
     // Summation order is the reference's, so without FMA contraction this is bit-identical to gridy.
-    if (active && tid < LATG * MX2) {
+    // (Two threads per output pair since the end of round 4: lane 2q sums E, lane 2q + 1 sums O -- each sum in the order it always had --
+    // and they exchange the results by DPP: half the chain length per thread, twice the threads busy, same bits.)
+    if constexpr (TG >= 2 * LATG * MX2) {
+        const int q = tid >> 1, par = tid & 1;
+        const bool on = active && q < LATG * MX2;
+        const int c = on ? q % MX2 : 0, jj = on ? q / MX2 : 0, m = c >> 1;
+        double acc = 0.0;
+#pragma unroll
+        for (int n = 0; n < NX; n += 2) {
+            const int nn = n + par;
+            if (c < nsh2_of(nn)) acc = acc + sv[nn * MX2 + c] * sp[jj][nn][m];
+        }
+        const double other = __shfl_xor(acc, 1);
+        if (on) {
+            if (par == 0) sf[2 * jj + 1][c] = acc + other;       // northern row il+1-j: E + O
+            else sf[2 * jj][c] = other - acc;                    // southern row j: E - O
+        }
+    } else if (active && tid < LATG * MX2) {
         const int c = tid % MX2, jj = tid / MX2, m = c >> 1;
         double e = 0.0, o = 0.0;
 #pragma unroll
