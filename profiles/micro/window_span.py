@@ -31,7 +31,7 @@ from speedy_ml_amd import _lib, hybrid, synth  # noqa: E402
 NAMES = {1: "k_grid", 2: "k_gridtend_physics", 3: "k_spec", 4: "k_spectral"}
 WAVES_CAP, LAUNCHES_CAP, HEAD = 4096, 32, 64
 REC = np.dtype([("start", "<u8"), ("end", "<u8"), ("hw", "<u4"), ("xcc", "<u4"), ("pad", "<u8")])
-WAVES = {1: int(os.environ.get("SML_SPAN_GRID_WAVES", 231 * 16)), 2: 72 * 3, 3: int(os.environ.get("SML_SPAN_SPEC_WAVES", 219 * 11)), 4: 248}        # waves per launch of the shipped geometries (checked against the records)
+WAVES = {1: int(os.environ.get("SML_SPAN_GRID_WAVES", 231 * 16)), 2: int(os.environ.get("SML_SPAN_PHYS_WAVES", 72 * 3)), 3: int(os.environ.get("SML_SPAN_SPEC_WAVES", 219 * 11)), 4: 248}        # waves per launch of the shipped geometries (checked against the records)
 
 
 def main():

@@ -535,6 +535,7 @@ __global__ __launch_bounds__(192) void k_gridtend_physics3(DevHoriz H, LevelTabl
         smlphys::LA uv = smlphys::park_array(park, smlphys::P_UV, lane);
         uv[0] = u_dyn; uv[1] = v_dyn;
         CSTAMP(1);
+        SML_SPAN_MARK();
         park_barrier();
         CSTAMP(2);
     } else if (wave == 1) {
@@ -549,6 +550,7 @@ __global__ __launch_bounds__(192) void k_gridtend_physics3(DevHoriz H, LevelTabl
         double pt[smlphys::NLP], pq[smlphys::NLP];
         smlphys::vdifsc(PL, c, icnv, pt, pq);
         CSTAMP(3);
+        SML_SPAN_MARK();
         park_barrier();                                                       // the dynamics and the radiation have left their results
         CSTAMP(4);
         smlphys::finish_and_store(PL, c, p, park, lane, O, 0, 8, 56, 64, a1, a2, b1, b2, pt, pq);
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(192) void k_gridtend_physics3(DevHoriz H, LevelTabl
             smlphys::lscond(PL, c, iptop, precls, s1, s2);
         }
         CSTAMP(2);
-        smlphys::chain_radiation(PL, PD, c, r, p, lradsw, want_diag, park, lane, precnv, precls, iptop, ParkBarrier());
+        smlphys::chain_radiation(PL, PD, c, r, p, lradsw, want_diag, park, lane, precnv, precls, iptop, [&]() { SML_SPAN_MARK(); park_barrier(); });
         CSTAMP(7);
     }
 }

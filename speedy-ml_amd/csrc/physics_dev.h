@@ -673,8 +673,23 @@ __device__ unsigned long long g_phys_dbg[48];
 #define PSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); \
         if (blockIdx.x == 36 && threadIdx.x == 0) g_phys_dbg[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 // the two-wavefront kernel of dynamics.hip: lane 0 of either wavefront stamps into its own half, [wave][16]
+#ifdef SML_PHYS_STAMPS_LIGHT      // without the wait for outstanding memory operations: where the wavefront IS at that moment, not when its loads have landed
+#define CSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 36 && (threadIdx.x & 63) == 0) smlphys::g_phys_dbg[(threadIdx.x >> 6) * 16 + (slot)] = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define CSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); \
         if (blockIdx.x == 36 && (threadIdx.x & 63) == 0) smlphys::g_phys_dbg[(threadIdx.x >> 6) * 16 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+// (Neither kind pins the ARITHMETIC: a scheduling barrier stops the machine scheduler, not the optimiser's sinking of a computation to its
+// first use -- in the three-wavefront kernel ~1000 double-precision instructions of the long-wave scheme sit behind the stamp that follows
+// radlw_up in the source.  What a wavefront's chain costs is therefore read from its arrival at the workgroup barrier, span.h.)
+#elif defined(SML_WAVE_SPAN)
+// the per-wavefront diagnostic build (span.h): lane 0 of a wavefront notes the clock at the chain's stamps in LDS (no wait added); the kernel
+// packs some of them into its wavefront record (SML_SPAN_PACK_MARKS)
+__shared__ unsigned long long g_wave_marks[4][8];
+#define PSTAMP(slot) do { } while (0)
+#define CSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) smlphys::g_wave_marks[(threadIdx.x >> 6) & 3][(slot) & 7] = (unsigned long long)wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PSTAMP(slot) do { } while (0)
 #define CSTAMP(slot) do { } while (0)

@@ -14,7 +14,7 @@ struct SpanRec { unsigned long long start, end; unsigned hw, xcc; unsigned long 
 struct SpanBuf { unsigned launch[8]; unsigned waves_cap, launches_cap, pad[6]; SpanRec rec[1]; };
 static __device__ SpanBuf *g_span;      // one per translation unit, all pointing at the same buffer (sml_span_attach_*)
 struct SpanScope {
-    unsigned long long t0;
+    unsigned long long t0, mark = 0;       // mark: one more clock reading of the wave's choice (SML_SPAN_MARK: e.g. its arrival at a barrier), stored in the record's pad
     unsigned idx, kid;
     __device__ __forceinline__ SpanScope(unsigned kernel_id) : t0((unsigned long long)wall_clock64()), idx(0), kid(kernel_id)
     {
@@ -32,13 +32,17 @@ struct SpanScope {
             if (idx < b->launches_cap && w < b->waves_cap) {
                 __builtin_amdgcn_s_waitcnt(0);                   // the wave's stores have been issued and its loads have landed
                 SpanRec r{t0, (unsigned long long)wall_clock64(), (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)),
-                          (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u, 0ull};
+                          (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u, mark};
                 b->rec[((size_t)(kid - 1) * b->launches_cap + idx) * b->waves_cap + w] = r;
             }
         }
     }
 };
 #define SML_SPAN(kernel_id) SpanScope span_scope_(kernel_id)
+#define SML_SPAN_MARK() (span_scope_.mark = (unsigned long long)wall_clock64())
+// four 16-bit offsets (10 ns ticks from the wave's start) of the clocks m[s0], m[s1], m[s2] and `now` -- for kernels that note several stamps
+#define SML_SPAN_PACK_MARKS(m, s0, s1, s2) (span_scope_.mark = (((m)[s0] - span_scope_.t0) & 0xffffull) | ((((m)[s1] - span_scope_.t0) & 0xffffull) << 16) | \
+        ((((m)[s2] - span_scope_.t0) & 0xffffull) << 32) | ((((unsigned long long)wall_clock64() - span_scope_.t0) & 0xffffull) << 48))
 #define SML_SPAN_ATTACH(fn)                                                                                  \
     extern "C" int fn(void *buf)                                                                             \
     {                                                                                                        \
@@ -47,5 +51,7 @@ struct SpanScope {
     }
 #else
 #define SML_SPAN(kernel_id) do { } while (0)
+#define SML_SPAN_MARK() do { } while (0)
+#define SML_SPAN_PACK_MARKS(m, s0, s1, s2) do { } while (0)
 #define SML_SPAN_ATTACH(fn)
 #endif
