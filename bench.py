@@ -427,9 +427,9 @@ def main():
     for _ in range(args.warmup):
         host.step(stream)
     barrier()
-    # Inside the timed region only the two predict kernels carry HIP events (the roofline is k_readout's measured duration); the
-    # per-phase split of the step needs six more event records per step on the step's stream, each a barrier packet in a chain of
-    # dependent 5-10 us launches, so it is measured on a pass of its own right after the timed one (SML_BENCH_PHASES_INLINE=1: inside).
+    # Inside the timed region only k_readout carries HIP events (the roofline is its measured duration); k_update's pair and the
+    # per-phase split of the step need eight more event records per step on the step's stream, each a barrier packet in a chain of
+    # dependent 5-10 us launches, so they are measured on a pass of its own right after the timed one (SML_BENCH_PHASES_INLINE=1: inside).
     phases_inline = os.environ.get("SML_BENCH_PHASES_INLINE", "0") == "1"
     host.timing(True, phases=phases_inline)
     t_start = time.perf_counter()
@@ -443,7 +443,9 @@ def main():
         for _ in range(min(args.steps, 20)):
             host.step(stream)
         barrier()
-        kern["phases_ms_per_step"] = host.timing_collect().get("phases_ms_per_step", {})
+        after = host.timing_collect()
+        kern["phases_ms_per_step"] = after.get("phases_ms_per_step", {})
+        kern["update_ms"], kern["update_launches"] = after["update_ms"], after["update_launches"]      # (k_update carries no events inside the timed region)
     host.timing(False)
     emulated_rank = world == 1 and args.regions != 1152          # (--regions: one rank's load without its peers' outvecs -- the grid is not physical)
     if host.aborted(wait=True) and not emulated_rank:
@@ -495,8 +497,8 @@ def main():
             "data": "synthetic",
             "config": host.describe(),
             "per_rank": ranks,
-            "per_rank_note": "update_ms / readout_ms: HIP events inside the timed region; the phase split (predict / allgather / scatter / speedy / gather) "
-                             + ("inside it as well" if phases_inline else f"from a pass of {min(args.steps, 20)} steps right after it (six more event records per step)"),
+            "per_rank_note": "readout_ms: HIP events inside the timed region; update_ms and the phase split (predict / allgather / scatter / speedy / gather) "
+                             + ("inside it as well" if phases_inline else f"from a pass of {min(args.steps, 20)} steps right after it (eight more event records per step)"),
             "roofline": {"bound": "hbm", "kernel": "k_readout<4,512> (W_out [local_model;x~] GEMV, all resident reservoirs)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,

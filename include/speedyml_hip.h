@@ -205,7 +205,8 @@ int sml_bank_algorithmic_bytes(sml_bank *bank, uint64_t *update_bytes, uint64_t 
 /* the same accounting for one column block of sml_bank_readout_part (the partial sums count as traffic of both parts) */
 int sml_bank_readout_part_bytes(sml_bank *bank, int part, uint64_t *bytes);
 /* Per-kernel timing with HIP events recorded on the launch stream (for bench.py's roofline block).
- * enable!=0 starts recording an event pair around every k_update / k_readout launch; collect synchronises the
+ * enable!=0 starts recording an event pair around every k_update / k_readout launch (enable == 2: around k_readout only -- an event
+ * record is a packet the dependent launches queue behind); collect synchronises the
  * recorded events, returns the summed milliseconds and launch counts since the last collect, and clears them. */
 int sml_bank_timing(sml_bank *bank, int enable);
 int sml_bank_timing_collect(sml_bank *bank, double *update_ms, int *update_launches, double *readout_ms, int *readout_launches);

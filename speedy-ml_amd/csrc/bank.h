@@ -43,6 +43,7 @@ struct sml_bank {
     unsigned *d_counter = nullptr;     // work counter of the persistent readout
     bool descs_dirty = true;
     bool timing = false;
+    bool timing_update = true;      // sml_bank_timing(b, 2): events around the readout only (the roofline kernel), none around the update
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_readout;
     std::vector<std::pair<double *, size_t>> train_states;     // per slot: the training pass's states buffer, kept between passes
 };

@@ -595,7 +595,8 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
         attr_set = true;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (b->timing) { SML_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence)); SML_HIP(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence)); SML_HIP(hipEventRecord(e0, st)); }
+    const bool timed_u = b->timing && b->timing_update;
+    if (timed_u) { SML_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence)); SML_HIP(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence)); SML_HIP(hipEventRecord(e0, st)); }
     if (threads == 1024)
         hipLaunchKernelGGL(k_update<1024>, dim3(nblocks), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     else if (threads == 256)
@@ -603,7 +604,7 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     else
         hipLaunchKernelGGL(k_update<512>, dim3(nblocks), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     SML_HIP(hipGetLastError());
-    if (b->timing) { SML_HIP(hipEventRecord(e1, st)); b->ev_update.emplace_back(e0, e1); }
+    if (timed_u) { SML_HIP(hipEventRecord(e1, st)); b->ev_update.emplace_back(e0, e1); }
     b->cur ^= 1;
     return SML_OK;
 }
@@ -1093,6 +1094,7 @@ int sml_bank_timing(sml_bank *b, int enable)
 {
     SML_REQUIRE(b, "null bank");
     b->timing = enable != 0;
+    b->timing_update = enable != 2;
     return SML_OK;
 }
 

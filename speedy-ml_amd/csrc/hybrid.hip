@@ -250,7 +250,7 @@ int sml_hybrid_create(sml_bank *bank, int number_of_regions, const int32_t *regi
     }
     {
         // the scatter of src/res_domain.f90:791-826 turned round: which outvec element tiles a cell of G (k_ingest)
-        static const bool want_fused = !(getenv("SML_HYBRID_FUSED_HANDOFF") && atoi(getenv("SML_HYBRID_FUSED_HANDOFF")) == 0);
+        const bool want_fused = !(getenv("SML_HYBRID_FUSED_HANDOFF") && atoi(getenv("SML_HYBRID_FUSED_HANDOFF")) == 0);      // (read per engine: a test builds both)
         h->fused = want_fused && bank->max_n_out <= 256;
         std::vector<int32_t> src(SML_GS_OFF, -1), slot_of(number_of_regions, -1), tmp_g(8 * 96 * 48 * 8), tmp_s(8 * 96 * 48 * 8);
         for (int s = 0; s < nslots; ++s) slot_of[region_of_slot[s]] = s;

@@ -562,7 +562,7 @@ class HybridRank:
         """HIP events around the bank's two predict kernels; phases: also around each phase of the step (five more event records per
         step on the step's stream -- each one a barrier packet the dependent launches queue behind)"""
         from ._lib import check, lib
-        check(lib().sml_bank_timing(self.bank._h, 1 if on else 0))
+        check(lib().sml_bank_timing(self.bank._h, (1 if phases else 2) if on else 0))      # without the phases: k_readout's event pair only
         self._phase_on = bool(on) and phases and self.mode == "hybrid" and not self.pipeline
 
     def timing_collect(self):
@@ -717,7 +717,7 @@ class NativeEngine:
 
     def timing(self, on, phases=True):
         from ._lib import check
-        check(self.L.sml_bank_timing(self.model.bank._h, 1 if on else 0))
+        check(self.L.sml_bank_timing(self.model.bank._h, (1 if phases else 2) if on else 0))      # without the phases: k_readout's event pair only
         check(self.L.sml_hybrid_timing(self._h, 1 if (on and phases) else 0))
 
     def timing_collect(self):

@@ -92,6 +92,40 @@ def make_engine(model, regions, classes, comm=None):
     return h
 
 
+def test_fused_handoff_equals_separate_launches(monkeypatch):
+    """The engine brackets the SPEEDY window with two fused launches (k_ingest: rows + scatter + clamps + SST + real(4) fields + fordate's
+    grid-point work; k_egress: F, TISR slice, both gathers) and transforms fordate's two fields with iogrid(30)'s 33; with
+    SML_HYBRID_FUSED_HANDOFF=0 it issues the stand-alone kernels instead (the launches the Python host issues).  Two engines, one of each
+    kind, over the slab configuration: every state and every reservoir input identical after each of 4 steps."""
+    sea = synth.land_mask()
+    classes = hybrid.region_classes(sea)
+    regions = list(range(hybrid.NREG))
+    ma = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, slab=True)
+    mb = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, slab=True)
+    L, check = _lib.lib(), _lib.check
+    monkeypatch.delenv("SML_HYBRID_FUSED_HANDOFF", raising=False)
+    ha = make_engine(ma, regions, classes)
+    monkeypatch.setenv("SML_HYBRID_FUSED_HANDOFF", "0")
+    hb = make_engine(mb, regions, classes)
+    monkeypatch.delenv("SML_HYBRID_FUSED_HANDOFF")
+    stream = torch.cuda.current_stream()
+    for t in range(4):
+        check(L.sml_hybrid_step(ha, hybrid.LEAPFROG_PER_WINDOW, _lib.vp(stream)))
+        check(L.sml_hybrid_step(hb, hybrid.LEAPFROG_PER_WINDOW, _lib.vp(stream)))
+        torch.cuda.synchronize()
+        ga, fa, gb, fb = (np.zeros(domain.G_SIZE) for _ in range(4))
+        check(L.sml_hybrid_get_state(ha, _lib.dp(ga), _lib.dp(fa)))
+        check(L.sml_hybrid_get_state(hb, _lib.dp(gb), _lib.dp(fb)))
+        assert np.array_equal(ga, gb) and np.array_equal(fa, fb), t
+        assert torch.equal(ma.feedback, mb.feedback) and torch.equal(ma.local_model, mb.local_model) and torch.equal(ma.outvec, mb.outvec), t
+        assert torch.equal(ma.slab_feedback, mb.slab_feedback), t
+    for h in (ha, hb):
+        safe = C.c_int()
+        check(L.sml_hybrid_safe(h, C.byref(safe)))
+        assert safe.value == 1
+        check(L.sml_hybrid_destroy(h))
+
+
 def test_native_engine_with_slab_equals_python_over_30_steps():
     """config 5 in the native engine: sml_hybrid_attach_slab + sml_hybrid_step (predict, predict_slab_ml on the 28th step, SST
     assembly, mask / floor, the averaging ring of the slab inputs) against HybridRank(slab=True), bit for bit, over 30 steps -- the slab
