@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12     # 10 timed + 2 warm-up steps in collect.sh
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # hybrid steps in the traced run; 0: the number of k_readout launches (one per step)
 
 
 def short(name):
@@ -29,9 +29,11 @@ stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*", "*kernel_
 stats = sorted(stats, key=os.path.getmtime, reverse=True)
 if stats:
     shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    if not steps:
+        steps = max([int(row["Calls"]) for row in csv.DictReader(open(stats[0])) if "k_readout" in row["Name"]] or [12])
     for row in csv.DictReader(open(stats[0])):
         k = short(row["Name"])
-        if k:
+        if k and k not in out["kernels"]:      # (the first, i.e. the largest, row of a name: k_spec before k_spectral's short() collisions do not arise, k_gather2 / k_gather do)
             out["kernels"][k] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
                                  "ms_per_step": float(row["TotalDurationNs"]) / steps / 1e6}
 for ctr, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
