@@ -77,8 +77,12 @@ class Physics:
         check(_lib.lib().sml_phys_get_surface(self._h, self.SURFACE[name], dp(out)))
         return out
 
-    def sol_oz(self, tyear):
-        check(_lib.lib().sml_phys_sol_oz(self._h, C.c_double(tyear)))
+    def sol_oz(self, tyear, stream=None, asynchronous=False):
+        """sol_oz(tyear) of the forcing day; asynchronous: enqueued on `stream` (the values travel as kernel arguments) instead of a blocking copy"""
+        if asynchronous:
+            check(_lib.lib().sml_phys_sol_oz_async(self._h, C.c_double(tyear), vp(stream)))
+        else:
+            check(_lib.lib().sml_phys_sol_oz(self._h, C.c_double(tyear)))
 
     def tables(self):
         z, f, l = np.zeros((6, 48)), np.zeros((301, 4)), np.zeros((9, 9))

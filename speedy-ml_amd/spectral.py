@@ -100,6 +100,18 @@ class Spectral:
         check(_lib.lib().sml_spectral_spec_post(self._h, dp(spec_in.data_ptr()), _lib.ip(desc.data_ptr()), dp(out.data_ptr()), nf, vp(stream)))
         return out
 
+    def spec_post_split(self, spec_in, desc, out, out2, stream=None):
+        """spec_post with the last out2.shape[0] output fields written to a second array (what the hybrid engine uses to put fordate's
+        two spectra into the boundary arrays from iogrid(30)'s launch)."""
+        self._chk(spec_in, (NX, MX2))
+        nf, nf2 = out.shape[0], out2.shape[0]
+        assert desc.is_cuda and desc.element_size() == 4 and desc.is_contiguous() and tuple(desc.shape) == (nf + nf2, 4)
+        assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (nf, NX, MX2)
+        assert out2.is_cuda and out2.is_contiguous() and tuple(out2.shape) == (nf2, NX, MX2)
+        check(_lib.lib().sml_spectral_spec_post_split(self._h, dp(spec_in.data_ptr()), _lib.ip(desc.data_ptr()), dp(out.data_ptr()), nf, dp(out2.data_ptr()), nf2,
+                                                      vp(stream)))
+        return out, out2
+
     def spec_mixed(self, vorg, scale_flags, out=None, stream=None):
         """One launch for fields with different forward pre-scaling (0 none, 1 *cosgr, 2 *cosgr2 per field)."""
         nf = self._chk(vorg, (IL, IX))

@@ -269,3 +269,19 @@ def test_window_with_physics_matches_oracle_plus_compiled_reference():
         do.impint(dt, 0.5)
         dry = do.step_dry(j1, j2, dt, 0.5, 0.05, 0.53, dry, phis, zero, zero)
     assert rel(dry["t"], want["t"]) > 1e-6
+
+
+def test_sol_oz_enqueued_equals_the_blocking_upload():
+    """sml_phys_sol_oz_async (the hybrid engine's once-a-day call: the zonal solar / ozone fields travel as kernel arguments in stream
+    order) leaves the same table as sml_phys_sol_oz (host computation + blocking copy)."""
+    import torch
+    from speedy_ml_amd.physics import Physics
+    from make_physics_golden import gaussian_latitudes
+    ph = Physics(gaussian_latitudes())
+    for ty in (0.0, 0.31, 0.77):
+        ph.sol_oz(ty)
+        want = ph.tables()[0].copy()
+        ph.sol_oz(0.5)                                             # something else in between
+        ph.sol_oz(ty, stream=torch.cuda.current_stream(), asynchronous=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(ph.tables()[0], want), ty

@@ -252,3 +252,8 @@ def test_spec_post_equals_separate_operators(sp):
         if tr:
             sp.trunct(want)
         assert torch.equal(out[f], want[0]), (f, typ)
+    # the same rows with the last two written to a second array (the hybrid engine's iogrid(30) + fordate launch)
+    out_a = torch.zeros((len(rows) - 2, NX, MX2), dtype=torch.float64, device="cuda")
+    out_b = torch.full((2, NX, MX2), 7.0, dtype=torch.float64, device="cuda")
+    sp.spec_post_split(raw, desc, out_a, out_b)
+    assert torch.equal(out_a, out[:-2]) and torch.equal(out_b, out[-2:])
