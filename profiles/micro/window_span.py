@@ -29,7 +29,7 @@ load_package()
 from speedy_ml_amd import _lib, hybrid, synth  # noqa: E402
 
 NAMES = {1: "k_grid", 2: "k_gridtend_physics", 3: "k_spec", 4: "k_spectral"}
-WAVES_CAP, LAUNCHES_CAP, HEAD = 4096, 32, 64
+WAVES_CAP, LAUNCHES_CAP, HEAD = 4096, 64, 64
 REC = np.dtype([("start", "<u8"), ("end", "<u8"), ("hw", "<u4"), ("xcc", "<u4"), ("pad", "<u8")])
 WAVES = {1: int(os.environ.get("SML_SPAN_GRID_WAVES", 231 * 16)), 2: int(os.environ.get("SML_SPAN_PHYS_WAVES", 72 * 3)), 3: int(os.environ.get("SML_SPAN_SPEC_WAVES", 219 * 11)), 4: 248}        # waves per launch of the shipped geometries (checked against the records)
 
@@ -49,31 +49,45 @@ def main():
     for fn in ("sml_span_attach_dyn", "sml_span_attach_spectral"):
         _lib.check(getattr(L, fn)(C.c_void_p(buf.data_ptr())))
     out = {}
-    for label, pre in (("window alone", False), ("window right behind the full-size readout's stand-in (a 7.5 GB read)", True)):
+    variants = [("window alone", False), ("window right behind the full-size readout's stand-in (a 7.5 GB read)", True)]
+    if os.environ.get("SML_SPAN_MORE"):      # what is it about the read?  the same window behind a second window (the tables just used), behind 1 ms of matrix-core work
+        variants += [("window right behind another window", "window"), ("window right behind 1 ms of fp64 matrix products (no memory stream)", "mfma"),
+                     ("window behind the 7.5 GB read and then another window", "read+window")]
+    for label, pre in variants:
         buf.zero_()
         buf[:HEAD] = torch.from_numpy(head.view(np.uint8)).cuda()
-        junk = torch.empty(int(7.5e9 // 8), dtype=torch.float64, device="cuda") if pre else None
+        junk = torch.empty(int(7.5e9 // 8), dtype=torch.float64, device="cuda") if pre in (True, "read+window") else None
+        mm = torch.randn((2048, 2048), dtype=torch.float64, device="cuda") if pre == "mfma" else None
+        if pre in ("window", "read+window"):
+            saved = m.state.clone()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if pre:
+        if pre in (True, "read+window"):
             junk.sum()
+        if pre == "mfma":
+            for _ in range(3):
+                mm @ mm
+        if pre in ("window", "read+window"):
+            m.dyn.window(m.state, 24, start=True, stream=stream)
+            m.state.copy_(saved)                               # (device copy in stream order: the second window follows at once; its records start at launch 26)
         e0.record(stream)
         m.dyn.window(m.state, 24, start=True, stream=stream)
         e1.record(stream)
         torch.cuda.synchronize()
-        del junk
+        del junk, mm
         raw = buf.cpu().numpy()
         rec = raw[HEAD:].view(REC).reshape(4, LAUNCHES_CAP, WAVES_CAP)
         launches = []
-        for i in range(26):
+        base = 26 if pre in ("window", "read+window") else 0
+        for i in range(base, base + 26):
             for kid in (1, 2, 3, 4):
                 r = rec[kid - 1, i + (1 if kid == 4 else 0)]      # (the window's first k_grid has already bumped k_spectral's counter)
                 r = r[r["end"] != 0]
                 assert len(r) == WAVES[kid], (kid, i, len(r))
                 launches.append((kid, r))
-        if len(sys.argv) > 2 and not pre:          # raw records of the window (for offline study of which wavefronts are the slow ones)
+        if len(sys.argv) > 2 and pre is False:          # raw records of the window (for offline study of which wavefronts are the slow ones)
             np.savez_compressed(sys.argv[2], rec=rec[:, :27])
-        assert not rec[:3, 26:]["end"].any() and not rec[3, 27:]["end"].any() and not rec[3, 0]["end"].any()
+        assert base or (not rec[:3, 26:]["end"].any() and not rec[3, 27:]["end"].any() and not rec[3, 0]["end"].any())
         rows = []
         for kid, r in launches:
             s, e = r["start"].astype(np.float64) / 100.0, r["end"].astype(np.float64) / 100.0      # microseconds
