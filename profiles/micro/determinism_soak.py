@@ -13,14 +13,22 @@ finals = []
 for run in range(2):
     m = hybrid.HybridRank(list(range(1152)), classes, sea_mask=sea, mode="hybrid", n_override=None if os.environ.get("SML_FULL_SIZE") else 1)
     st = torch.cuda.current_stream()
+    eng = hybrid.NativeEngine(m) if os.environ.get("SML_SOAK_ENGINE") else None      # the native engine (sml_hybrid_step: fused hand-off) instead of the Python host
     t0 = time.time()
     for k in range(steps):
-        m.step(st)
+        (eng or m).step(st)
     torch.cuda.synchronize()
-    F = m.F[:domain.G2_OFF].reshape(8, 48, 96, 4)
-    print("run", run, "steps", steps, "%.1f s" % (time.time() - t0), "safe", int(m.safe.item()), "finite", bool(torch.isfinite(m.F[:domain.GP_OFF]).all()),
+    if eng:
+        g, f = eng.state()
+        G, Fs, safe = torch.from_numpy(g), torch.from_numpy(f), int(eng.safe())
+        state = m.feedback.clone()                                       # (the bank's next inputs: what the engine's last gather left)
+        eng.close()
+    else:
+        G, Fs, safe, state = m.G.clone(), m.F.clone(), int(m.safe.item()), m.state.clone()
+    F = Fs[:domain.G2_OFF].reshape(8, 48, 96, 4)
+    print("run", run, "engine" if eng else "python host", "steps", steps, "%.1f s" % (time.time() - t0), "safe", safe, "finite", bool(torch.isfinite(Fs[:domain.GP_OFF]).all()),
           "T %.1f..%.1f" % (float(F[..., 0].min()), float(F[..., 0].max())), flush=True)
-    finals.append((m.G.clone(), m.F.clone(), m.state.clone()))
+    finals.append((G, Fs, state))
     del m
 same = all(torch.equal(a, b) for a, b in zip(finals[0], finals[1]))
 print("bitwise identical:", same)
