@@ -278,6 +278,9 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     // (a wavefront stages whole rows of the field: lane = coefficient within total wavenumber n, no index division per element)
     const int wv = tid >> 6, ln = tid & 63;
     double fv[NFP];
+    bool pair_path = false, pair_ok = false;       // derived rows staged as (re, im) pairs (below)
+    int pair_at = 0;
+    double pair_o0 = 0., pair_o1 = 0.;
     if (type == 0 || type == 8) {
 #pragma unroll
         for (int it = 0; it < NFP; ++it) {
@@ -290,6 +293,31 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
             const int n = wv + it * (TG / 64);
             fv[it] = (n < NX && ln < nsh2_of(n)) ? derived_coeff(T, 7, v, v, n, ln, src1, aux) : 0.0;       // (first step of a window only)
         }
+    } else if (FPW == 1 && 2 * (TG / 64) >= NX) {
+        // uvspec / grad rows with one lane per COMPLEX coefficient (end of round 4): a lane fetches the (re, im) pair of each of its three
+        // operands with one 16-byte load and the three table values of its (n, m) once, a wavefront covers two rows of total wavenumber --
+        // 6 load instructions per lane where the element-per-lane form below issues 12.  The 60 workgroups of a time step's 20 derived
+        // fields were the last of every inverse launch by 1.2 us (7.7 against 6.5 us, per-wavefront records): what they wait for is the
+        // texture path working through their load instructions.  Same expressions on the same operands: same bits.
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const double *q = vorm + (size_t)src1 * SPEC_N;
+        const double *tx = type <= 2 ? T.uvdx : T.gradx, *tm = type <= 2 ? T.uvdym : T.gradym, *tp = type <= 2 ? T.uvdyp : T.gradyp;
+        const double *M = type == 2 ? q : v, *X = type == 1 ? q : v;
+        const int n = 2 * wv + (ln >> 5), mm = ln & 31;
+        pair_ok = n < NX && mm < MX && 2 * mm < nsh2_of(n);
+        const int nn = pair_ok ? n : 0, m = pair_ok ? mm : 0, row = nn * MX2, c0 = 2 * m;
+        const d2 dm2 = *reinterpret_cast<const d2 *>(M + (nn > 0 ? row - MX2 : row) + c0);
+        const d2 dp2 = *reinterpret_cast<const d2 *>(M + (nn < NX - 1 ? row + MX2 : row) + c0);
+        const d2 x2 = *reinterpret_cast<const d2 *>(X + row + c0);
+        const double cm = tm[nn * MX + m], cp = tp[nn * MX + m], cx = type >= 3 ? tx[m] : tx[nn * MX + m];
+        const double ym_e = n == 0 ? 0. : cm, yp_e = n == NX - 1 ? 0. : cp;
+        const double gx_e = (type <= 2 && n == NX - 1) ? 0. : cx, ngx = -gx_e;        // (re, im) -> (-g im, g re)
+        double o0, o1;
+        if (type == 1) { o0 = ym_e * dm2[0] - yp_e * dp2[0] + ngx * x2[1]; o1 = ym_e * dm2[1] - yp_e * dp2[1] + gx_e * x2[0]; }
+        else if (type == 2) { o0 = -ym_e * dm2[0] + yp_e * dp2[0] + ngx * x2[1]; o1 = -ym_e * dm2[1] + yp_e * dp2[1] + gx_e * x2[0]; }
+        else if (type == 3) { o0 = ngx * x2[1]; o1 = gx_e * x2[0]; }
+        else { o0 = -ym_e * dm2[0] + yp_e * dp2[0]; o1 = -ym_e * dm2[1] + yp_e * dp2[1]; }
+        pair_path = true; pair_at = nn * MX2 + c0; pair_o0 = o0; pair_o1 = o1;
     } else {
         // uvspec (types 1 | 2, :351-387) and grad (3 | 4, :271-305) of the fields P = src0, Q = src1, as derived_coeff writes them, branch-free:
         //   1: ym P(n-1) - yp P(n+1) + i gx Q     2: -ym Q(n-1) + yp Q(n+1) + i gx P     3: i gradx P     4: -gradym P(n-1) + gradyp P(n+1)
@@ -333,7 +361,10 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
             if (row < LATG * NX && pm < MX && 2 * pm < nsh2_of(row % NX)) pl[row * MX + pm] = pv[it];
         }
     }
-    if (active) {
+    if (active && pair_path) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        if (pair_ok) *reinterpret_cast<d2 *>(sv + pair_at) = d2{pair_o0, pair_o1};
+    } else if (active) {
 #pragma unroll
         for (int it = 0; it < NFP; ++it) {
             const int n = wv + it * (TG / 64);
