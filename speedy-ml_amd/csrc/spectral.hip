@@ -265,15 +265,19 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     // (uvspec, grad) added a branch with its own wait per edge case of n.  Now: clamped addresses, unconditional loads into registers,
     // selects instead of branches; what a branch used to skip enters as a zero factor (the same values up to the sign of a zero).  Only
     // the coefficients inside the triangular truncation are staged (c < nsh2(n) = min(62, 2 (32 - n)), src/spe_spectral.f90:99-125).
-    constexpr int RPP = TG * FPW / 32, NPASS = (LATG * NX + RPP - 1) / RPP, NFP = (NX + TG / 64 - 1) / (TG / 64);
-    const int pm = threadIdx.x & 31, prow0 = threadIdx.x >> 5;             // Legendre slab: two (latitude, n) rows of 31 wavenumbers per wavefront
+    constexpr int NFP = (NX + TG / 64 - 1) / (TG / 64);
     const double *pg = T.pol + (size_t)lg * LATG * NX * MX;
-    double pv[NPASS];
+    // The slab goes over as ONE flat run of 16-byte loads, entries outside the triangular truncation included (63 KB instead of the 34 KB
+    // inside it): 4 load instructions per thread where 8-byte loads of the rows' retained parts took 8 -- what a workgroup waits for at
+    // its start is the texture path working through its load instructions, not the bytes (7.8 -> 7.5 us per launch).
+    typedef double d2s __attribute__((ext_vector_type(2)));
+    constexpr int NSL = (LATG * NX * MX / 2 + TG * FPW - 1) / (TG * FPW);
+    static_assert((LATG * NX * MX) % 2 == 0, "the slab is a whole number of 16-byte pairs");
+    d2s pv2[NSL];
 #pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-        const int row = prow0 + it * RPP;
-        const bool ok = row < LATG * NX && pm < MX && 2 * pm < nsh2_of(row % NX);
-        pv[it] = pg[ok ? row * MX + pm : 0];
+    for (int it = 0; it < NSL; ++it) {
+        const int e = threadIdx.x + it * TG * FPW;
+        pv2[it] = reinterpret_cast<const d2s *>(pg)[e < LATG * NX * MX / 2 ? e : 0];
     }
     // (a wavefront stages whole rows of the field: lane = coefficient within total wavenumber n, no index division per element)
     const int wv = tid >> 6, ln = tid & 63;
@@ -281,7 +285,12 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     bool pair_path = false, pair_ok = false;       // derived rows staged as (re, im) pairs (below)
     int pair_at = 0;
     double pair_o0 = 0., pair_o1 = 0.;
-    if (type == 0 || type == 8) {
+    if ((type == 0 || type == 8) && FPW == 1 && TG >= SPEC_N / 2) {
+        // a plain field likewise: one flat 16-byte load per thread (the whole 15.9 KB, not only the part inside the truncation)
+        pair_path = true; pair_ok = tid < SPEC_N / 2; pair_at = 2 * (pair_ok ? tid : 0);
+        const d2s pv = reinterpret_cast<const d2s *>(v)[pair_ok ? tid : 0];
+        pair_o0 = pv[0]; pair_o1 = pv[1];
+    } else if (type == 0 || type == 8) {
 #pragma unroll
         for (int it = 0; it < NFP; ++it) {
             const int n = wv + it * (TG / 64);
@@ -356,9 +365,9 @@ __global__ __launch_bounds__(TG * FPW) void k_grid(DevTables T, const double *__
     {
         double *pl = &sp[0][0][0];
 #pragma unroll
-        for (int it = 0; it < NPASS; ++it) {
-            const int row = prow0 + it * RPP;
-            if (row < LATG * NX && pm < MX && 2 * pm < nsh2_of(row % NX)) pl[row * MX + pm] = pv[it];
+        for (int it = 0; it < NSL; ++it) {
+            const int e = threadIdx.x + it * TG * FPW;
+            if (e < LATG * NX * MX / 2) reinterpret_cast<d2s *>(pl)[e] = pv2[it];
         }
     }
     if (active && pair_path) {
