@@ -44,6 +44,7 @@ struct HostTables {
 
 struct DevTables {
     const double *pol;               // [24][32][31]
+    const double *polt;              // [32][31][24]: the same, latitude fastest (k_spec's Legendre analysis: a coefficient's 24 values in one 192-byte run)
     const double *wt, *cosgr, *cosgr2;
     const int *nsh2;
     const double *twc, *tws;
@@ -601,10 +602,24 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
             if (n < NTRUN1 && c < nsh2_of(n)) {
                 // (fetching these 24 table values ahead of the DFT was measured twice: the quadrature and Legendre phases shrink by
                 // 1.4 us per workgroup, the staging and DFT phases grow by as much -- the launch's loads all compete at its start)
-                const double *p = T.pol + (size_t)n * MX + m;
+                // Six 16-byte loads per lane instead of 24 8-byte ones (end of round 4): the (re, im) lanes of a coefficient need the
+                // same 24 table values, so the even lane fetches latitudes 0..11 and the odd one 12..23 from the latitude-fastest copy
+                // of the table and they swap halves by DPP.  Same values in the same sums.
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                const int par = cc & 1;
+                const d2 *p2 = reinterpret_cast<const d2 *>(T.polt + ((size_t)n * MX + m) * IY + (IY / 2) * par);
+                d2 mine[IY / 4];
+#pragma unroll
+                for (int i = 0; i < IY / 4; ++i) mine[i] = p2[i];
                 double pj[IY];
 #pragma unroll
-                for (int j = 0; j < IY; ++j) pj[j] = p[(size_t)j * NX * MX];
+                for (int i = 0; i < IY / 4; ++i) {
+                    const double o0 = __shfl_xor(mine[i][0], 1), o1 = __shfl_xor(mine[i][1], 1);
+                    pj[2 * i] = par ? o0 : mine[i][0];
+                    pj[2 * i + 1] = par ? o1 : mine[i][1];
+                    pj[IY / 2 + 2 * i] = par ? mine[i][0] : o0;
+                    pj[IY / 2 + 2 * i + 1] = par ? mine[i][1] : o1;
+                }
                 if ((n & 1) == 0) {
 #pragma unroll
                     for (int j = 0; j < IY; ++j) acc = acc + pj[j] * sf[j][cc];
@@ -758,6 +773,13 @@ int sml_spectral_create(double a, sml_spectral **out)
     int rc = 0;
 #define UP(field, src, n) if (!rc) rc = up(sp, &sp->d.field, src, n)
     UP(pol, &h.pol[0][0][0], (size_t)IY * NX * MX);
+    {
+        std::vector<double> pt((size_t)NX * MX * IY);
+        for (int j = 0; j < IY; ++j)
+            for (int n = 0; n < NX; ++n)
+                for (int m = 0; m < MX; ++m) pt[((size_t)n * MX + m) * IY + j] = h.pol[j][n][m];
+        UP(polt, pt.data(), pt.size());
+    }
     UP(wt, h.wt, IY); UP(cosgr, h.cosgr, IL); UP(cosgr2, h.cosgr2, IL); UP(nsh2, h.nsh2, NX);
     UP(twc, h.twc, IX); UP(tws, h.tws, IX);
     UP(el2, &h.el2[0][0], NX * MX); UP(elm2, &h.elm2[0][0], NX * MX); UP(trfilt, &h.trfilt[0][0], NX * MX);
