@@ -490,8 +490,8 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     SML_SPAN(3);
     // The field is folded about longitude index 48 while it is staged: ss = x_i + x_{96-i}, sd = x_i - x_{96-i}
     // (i = 1..47; ss[0] = x_0, ss[48] = x_48), which halves the DFT: Re_k = sum ss cos, Im_k = - sum sd sin.
-    __shared__ double ss[IL][IX / 2 + 2];      // padded rows: lanes that differ in latitude hit different banks
-    __shared__ double sd[IL][IX / 2 + 2];
+    __shared__ __attribute__((aligned(16))) double ss[IL][IX / 2 + 2];      // padded rows: lanes that differ in latitude hit different banks
+    __shared__ __attribute__((aligned(16))) double sd[IL][IX / 2 + 2];
     __shared__ double twc[MG][IX / 2 + 3], tws[MG][IX / 2 + 3];
     __shared__ double sf[IL][2 * MG];          // this workgroup's Fourier coefficients [lat][re/im of its wavenumbers]
     __shared__ double swt[IY];                 // Gaussian weights, staged with the field (a load after the DFT costs a round trip)
@@ -505,14 +505,20 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
     // next) this was four dependent round trips per thread (round 4, see k_grid).  The 24 Legendre-table values of the analysis at the
     // end stay where they are: fetched here as well they make the launch's start slower by what they save at its end (measured again
     // in round 4: workgroup 6.6 against 5.5 us).
-    constexpr int NSP = (IL * (IX / 2 + 1) + TT - 1) / TT;
-    double ga[NSP], gb[NSP], cgv[NSP];
+    // Two longitudes per item and 16-byte loads (end of round 4): item (j, p) takes x_{2p}, x_{2p+1} in one load and their mirror images
+    // x_{96-2p}, x_{95-2p} in another (8-byte aligned, which global loads allow) -- 6 load instructions per thread where one longitude per
+    // item took 12.  The folds and products are the same expressions on the same values.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    constexpr int NPAIR = IX / 4 + 1, NSP = (IL * NPAIR + TT - 1) / TT;      // 25 pairs per latitude row: (0,1) ... (46,47), (48,-)
+    d2 ga[NSP], gb[NSP];
+    double cgv[NSP];
 #pragma unroll
     for (int it = 0; it < NSP; ++it) {
-        const int w = threadIdx.x + it * TT, wc = w < IL * (IX / 2 + 1) ? w : 0;
-        const int i = wc % (IX / 2 + 1), j = wc / (IX / 2 + 1);
-        ga[it] = g[j * IX + i];
-        gb[it] = g[j * IX + ((i == 0 || i == IX / 2) ? i : IX - i)];
+        const int w = threadIdx.x + it * TT, wc = w < IL * NPAIR ? w : 0;
+        const int p = wc % NPAIR, j = wc / NPAIR;
+        ga[it] = *reinterpret_cast<const d2 *>(g + j * IX + 2 * p);
+        gb[it] = *reinterpret_cast<const d2u *>(g + j * IX + (p == 0 ? IX - 2 : IX - 1 - 2 * p));      // (x_{95-2p}, x_{96-2p}); p = 0: (x_94, x_95), inside the row
         cgv[it] = scale == 2 ? T.cosgr2[j] : T.cosgr[j];
     }
     constexpr int NTP = (MG * (IX / 2 + 1) + TT - 1) / TT;
@@ -530,12 +536,15 @@ __global__ __launch_bounds__(TT) void k_spec(DevTables T, const double *__restri
 #pragma unroll
     for (int it = 0; it < NSP; ++it) {
         const int w = threadIdx.x + it * TT;
-        if (w < IL * (IX / 2 + 1)) {
-            const int i = w % (IX / 2 + 1), j = w / (IX / 2 + 1);
-            double a = ga[it], b = (i == 0 || i == IX / 2) ? 0.0 : gb[it];
-            if (scale == 1 || scale == 2) { a = a * cgv[it]; b = b * cgv[it]; }
-            ss[j][i] = a + b;
-            sd[j][i] = a - b;
+        if (w < IL * NPAIR) {
+            const int p = w % NPAIR, j = w / NPAIR;
+            // longitude 2p (no mirror image at 0 and 48) and longitude 2p + 1 (mirror x_{95-2p}: gb[0], or gb[1] of the p = 0 load); the
+            // second half of pair 24 lands in the rows' padding column
+            double a0 = ga[it][0], b0 = (p == 0 || p == NPAIR - 1) ? 0.0 : gb[it][1];
+            double a1 = ga[it][1], b1 = p == 0 ? gb[it][1] : gb[it][0];
+            if (scale == 1 || scale == 2) { a0 = a0 * cgv[it]; b0 = b0 * cgv[it]; a1 = a1 * cgv[it]; b1 = b1 * cgv[it]; }
+            *reinterpret_cast<d2 *>(&ss[j][2 * p]) = d2{a0 + b0, a1 + b1};
+            *reinterpret_cast<d2 *>(&sd[j][2 * p]) = d2{a0 - b0, a1 - b1};
         }
     }
 #pragma unroll
