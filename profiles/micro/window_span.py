@@ -40,6 +40,8 @@ def main():
     sea = synth.land_mask()
     m = hybrid.HybridRank(list(range(hybrid.NREG)), hybrid.region_classes(sea), sea_mask=sea, mode="hybrid", n_override=1)
     stream = torch.cuda.current_stream()
+    if os.environ.get("SML_SPAN_NO_DIAG"):
+        m.dyn.physics_diag(False)                # (experiment: the physics without its 23 diagnostic fields)
     for _ in range(3):
         m.step(stream)
     nrec = 4 * LAUNCHES_CAP * WAVES_CAP
