@@ -202,6 +202,17 @@ int sml_bank_get_contribs(sml_bank *bank, int slot, double *v_p, double *v_ml);
 
 /* byte accounting for the roofline (algorithmic bytes as defined in DESIGN.md) */
 int sml_bank_algorithmic_bytes(sml_bank *bank, uint64_t *update_bytes, uint64_t *readout_bytes);
+/* Compact storage.  The reference's weight files hold win / wout / vals / mean / std as NF90_REAL (src/mod_io.f90, written by
+ * write_trained_res, src/mod_reservoir.f90:1727-1736): a reservoir loaded from them has weights that are exactly floats.  sml_bank_load /
+ * sml_bank_set_wout detect that (every value of W_out and of the operator must survive the round trip through float) and keep a second,
+ * 4-byte copy; when EVERY loaded reservoir of a bank has one, the predict kernels read those copies and convert back on the fly -- the
+ * same numbers, the same double-precision arithmetic, half the bytes of the two HBM-bound kernels.  The readout then sums four columns
+ * per 16-byte load instead of two, i.e. in another (fixed) association: results agree with the 8-byte kernels to ~1e-13, not bit for
+ * bit.  *compact = 1 when the bank is in that mode.  SML_BANK_COMPACT=0 disables it; sml_bank_algorithmic_bytes counts the bytes of
+ * the copies actually read. */
+int sml_bank_storage(sml_bank *bank, int *compact);
+/* allow = 0: this bank's predict kernels keep to the 8-byte copies whatever the weights are; 1 (default): automatic */
+int sml_bank_use_compact(sml_bank *bank, int allow);
 /* the same accounting for one column block of sml_bank_readout_part (the partial sums count as traffic of both parts) */
 int sml_bank_readout_part_bytes(sml_bank *bank, int part, uint64_t *bytes);
 /* Per-kernel timing with HIP events recorded on the launch stream (for bench.py's roofline block).

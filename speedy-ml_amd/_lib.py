@@ -54,7 +54,7 @@ EXPORTS = [
     "sml_bank_set_state", "sml_bank_get_state", "sml_bank_set_feedback", "sml_bank_set_local_model",
     "sml_bank_get_outvec", "sml_bank_feedback_dev", "sml_bank_local_model_dev", "sml_bank_outvec_dev",
     "sml_bank_predict_all", "sml_bank_predict_one", "sml_bank_synchronize_all", "sml_bank_synchronize_one", "sml_bank_advance_all", "sml_bank_readout_part", "sml_bank_outvec_contribs", "sml_bank_get_contribs",
-    "sml_bank_algorithmic_bytes", "sml_bank_readout_part_bytes", "sml_bank_timing", "sml_bank_timing_collect",
+    "sml_bank_algorithmic_bytes", "sml_bank_storage", "sml_bank_use_compact", "sml_bank_readout_part_bytes", "sml_bank_timing", "sml_bank_timing_collect",
     "sml_exchange_create", "sml_exchange_destroy", "sml_exchange_scatter", "sml_exchange_gather",
     "sml_comm_unique_id", "sml_comm_create", "sml_comm_bootstrap", "sml_comm_destroy", "sml_comm_allgather_outvec", "sml_comm_unpack_regions",
     "sml_hybrid_create", "sml_hybrid_destroy", "sml_hybrid_set_state", "sml_hybrid_get_state", "sml_hybrid_set_base_sst", "sml_hybrid_set_orography",

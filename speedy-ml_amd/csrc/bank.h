@@ -16,6 +16,11 @@ struct ResDesc {
     const unsigned char *row_len;     // nonzeros of the row at each device position (<= 255)
     double *x[2];              // ping-pong state
     const double *wout;        // [n_out][n_aug_pad] row-major, zero padded
+    // Compact copies, present when every value survives a round trip through float (weights read from the reference's NetCDF files are
+    // NF90_REAL, src/mod_io.f90): the same numbers in half the bytes, converted back exactly on the fly.  NULL otherwise.
+    const float *wout32;       // [n_out][n_aug_pad32], rows padded to whole 128-byte lines
+    const float *sell_val32;   // as sell_val
+    int n_aug_pad32, pad_;
     const double *mean, *stdv;
     const int *out_stat;       // [n_out] slot into mean/std, <0 = leave as is
     double leak;
@@ -25,6 +30,8 @@ struct HostRes {
     std::vector<void *> allocs;
     ResDesc desc{};
     uint64_t update_bytes = 0, readout_bytes = 0;
+    uint64_t update_bytes32 = 0, readout_bytes32 = 0;      // the same accounting with 4-byte values (compact copies)
+    float *wout32_alloc = nullptr;                         // the device buffer behind desc.wout32 (kept when the copy is withdrawn)
     std::vector<int> order;      // device position -> original row of the state vector
 };
 
@@ -43,6 +50,8 @@ struct sml_bank {
     unsigned *d_counter = nullptr;     // work counter of the persistent readout
     bool descs_dirty = true;
     bool timing = false;
+    bool allow_compact = true;      // sml_bank_use_compact(bank, 0): keep to the 8-byte copies whatever the weights are
+    int compact = -1;               // 1: every loaded reservoir has compact copies and the predict kernels read those (decided when the descriptors are synchronised)
     bool timing_update = true;      // sml_bank_timing(b, 2): events around the readout only (the roofline kernel), none around the update
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_readout;
     std::vector<std::pair<double *, size_t>> train_states;     // per slot: the training pass's states buffer, kept between passes

@@ -63,7 +63,12 @@ __device__ __forceinline__ gd_t as_global(double *p) { return (gd_t)p; }
 __device__ __forceinline__ gcus_t as_global(const unsigned short *p) { return (gcus_t)p; }
 __device__ __forceinline__ gci_t as_global(const int *p) { return (gci_t)p; }
 
-template <int THREADS>
+typedef const float __attribute__((address_space(1))) *gcf_t;
+__device__ __forceinline__ gcf_t as_global(const float *p) { return (gcf_t)p; }
+
+// VAL32: the operator's values come from the compact float copy (ResDesc::sell_val32: every value is exactly a float, so the conversion
+// back is exact and the sums are the same sums) -- 6 bytes per stored nonzero instead of 10.
+template <int THREADS, bool VAL32 = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_update(const ResDesc *__restrict__ descs, int res_begin, int res_end,
                                                      int parts, const double *__restrict__ u_all, int u_stride, int cur, int square_input,
                                                      int whole_blocks, const TrainSlot *__restrict__ train_slots, int train_col)
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const gci_t slice_off = as_global(D.slice_off);
     const gcus_t sell_col = as_global(D.sell_col);
     const gcd_t sell_val = as_global(D.sell_val);
+    const gcf_t sell_val32 = as_global(D.sell_val32);
     const int nslices = D.nslices, n = D.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = THREADS / 64;
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
         const int r = s * 64 + lane;                      // device position == sorted position: contiguous stores
         const gcus_t cp = sell_col + off + lane;
         const gcd_t vp = sell_val + off + lane;
+        const gcf_t vp32 = sell_val32 + off + lane;
         double acc = 0.0;
         // The whole row (makesparse gives 6-8 stored entries per row incl. W_in) is fetched in ONE batch of loads before
         // the first LDS gather: PMC showed 78 % of the wave cycles parked in s_waitcnt, and a 4-wide loop plus a scalar tail
@@ -128,10 +135,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
         constexpr int WB = 8;
         int cc[WB];
         double vv[WB];
+        float vf[WB];           // (VAL32: converted after the batch -- a conversion inside the guarded load made the compiler wait for every pair)
 #pragma unroll
         for (int q = 0; q < WB; ++q) {
-            cc[q] = 0; vv[q] = 0.0;
-            if (q < width) { cc[q] = cp[q * 64]; vv[q] = vp[q * 64]; }      // width is wave-uniform
+            cc[q] = 0; vv[q] = 0.0; vf[q] = 0.f;
+            if (VAL32) {
+                // (branch-free: an entry past the slice's width re-reads entry 0 and is replaced by the padding; guarded loads of the
+                //  float copy compiled into one waited-for pair per entry)
+                const int qq = q < width ? q : 0;                          // width is wave-uniform
+                const int c = cp[qq * 64];
+                const float f = vp32[qq * 64];
+                cc[q] = q < width ? c : 0;
+                vf[q] = q < width ? f : 0.f;
+            } else if (q < width) {
+                cc[q] = cp[q * 64];
+                vv[q] = vp[q * 64];
+            }
+        }
+        if (VAL32) {
+#pragma unroll
+            for (int q = 0; q < WB; ++q) vv[q] = (double)vf[q];
         }
         // The gathers are unconditional and issued together (one LDS round trip per slice, not one per entry behind a divergent
         // branch each): an entry past the row's length is the layout's padding (value +0.0, column 0), whose product is a zero
@@ -149,8 +172,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
         for (int j = WB; j < width; j += 4) {                                // long rows (rare): four more per trip
             int c4[4];
             double v4[4], x4[4];
+            float f4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { c4[q] = 0; v4[q] = 0.0; if (j + q < width) { c4[q] = cp[(j + q) * 64]; v4[q] = vp[(j + q) * 64]; } }
+            for (int q = 0; q < 4; ++q) {
+                c4[q] = 0; v4[q] = 0.0; f4[q] = 0.f;
+                if (j + q < width) { c4[q] = cp[(j + q) * 64]; if (VAL32) f4[q] = vp32[(j + q) * 64]; else v4[q] = vp[(j + q) * 64]; }
+            }
+            if (VAL32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v4[q] = (double)f4[q];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) x4[q] = xu[c4[q]];
 #pragma unroll
@@ -290,6 +321,80 @@ __global__ __launch_bounds__(RO_THREADS) void k_readout(const ResDesc *__restric
     }
 }
 
+// The readout from the COMPACT copy of W_out (ResDesc::wout32: every weight is exactly a float -- what a reservoir read from the reference's
+// NetCDF weight files holds, NF90_REAL -- so the conversion back to double is exact): half the bytes of the dominant kernel.  Same
+// structure as k_readout; a 16-byte load is four columns here, so a lane's partial sums associate differently from the 8-byte-value
+// kernel (each is a fixed order; the two agree to the last bits' accumulation, 1e-13).  The whole product only (no column split).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int R, int RO_THREADS>
+__global__ __launch_bounds__(RO_THREADS) void k_readout32(const ResDesc *__restrict__ descs, int res_begin, int res_end, int parts,
+                                                            const double *__restrict__ lm_all, int lm_stride,
+                                                            double *__restrict__ out_all, int out_stride, int cur, int flags)
+{
+    __shared__ double red[RO_THREADS / 64][R];
+    int res, grp;
+    decode_block(blockIdx.x, parts, res_begin, res, grp);
+    if (res >= res_end) return;
+    const ResDesc &D = descs[res];
+    if (!D.loaded) return;
+    const int r0 = grp * R;
+    if (r0 >= D.n_out) return;
+    const double *__restrict__ x = cur ? D.x[1] : D.x[0];
+    const double *__restrict__ lm = lm_all + (size_t)res * lm_stride;
+    const size_t ld = (size_t)D.n_aug_pad32;
+    const float *wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = D.wout32 + (size_t)min(r0 + r, D.n_out - 1) * ld;
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    const bool aligned_model = (D.n_model & 3) == 0;
+    for (int kk = threadIdx.x * 4; kk < D.n_aug_pad32; kk += RO_THREADS * 4) {
+        double a[4];
+        if (kk + 3 < D.n_model) { a[0] = lm[kk]; a[1] = lm[kk + 1]; a[2] = lm[kk + 2]; a[3] = lm[kk + 3]; }
+        else if (aligned_model && kk >= D.n_model && kk + 3 < D.n_aug) {
+            const double2 x0 = *reinterpret_cast<const double2 *>(x + (kk - D.n_model)), x1 = *reinterpret_cast<const double2 *>(x + (kk - D.n_model) + 2);
+            a[0] = x0.x; a[1] = x0.y * x0.y; a[2] = x1.x; a[3] = x1.y * x1.y;      // 0-based odd entry == the reference's even (1-based) entry
+        } else {
+            auto aug = [&](int i) -> double {
+                if (i < D.n_model) return lm[i];
+                if (i >= D.n_aug) return 0.0;
+                const int j = i - D.n_model;
+                const double v = x[j];
+                return (j & 1) ? v * v : v;
+            };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = aug(kk + q);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wrow[r] + kk));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r] += (double)w[q] * a[q];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double s = wave_sum(acc[r]);
+        if (lane == 0) red[wave][r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < R) {
+        const int row = r0 + threadIdx.x;
+        if (row < D.n_out) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < RO_THREADS / 64; ++w) v += red[w][threadIdx.x];
+            if (!(flags & 1)) {
+                const int si = D.out_stat[row];
+                if (si >= 0) v = __dadd_rn(__dmul_rn(v, D.stdv[si]), D.mean[si]);
+            }
+            out_all[(size_t)res * out_stride + row] = v;
+        }
+    }
+}
+
 // The same product as k_readout<R, 64, .>, as a PERSISTENT kernel with a bounded footprint, for the pipelined hybrid step
 // (hybrid.py): the readout then runs on a side stream underneath the SPEEDY window, whose small latency-bound kernels
 // must keep finding free wave slots and LDS.  A plain launch floods every CU with single-wave workgroups and a 512-thread
@@ -396,6 +501,11 @@ int sml::bank_sync_descs(sml_bank *b)
     if (!b->descs_dirty) return SML_OK;
     std::vector<ResDesc> h(b->capacity);
     for (int i = 0; i < b->capacity; ++i) h[i] = b->res[i].desc;
+    // the compact copies are used when EVERY loaded reservoir of the bank has them (one kernel shape per launch)
+    int loaded = 0, with32 = 0;
+    for (int i = 0; i < b->capacity; ++i)
+        if (h[i].loaded) { ++loaded; with32 += (h[i].wout32 && h[i].sell_val32) ? 1 : 0; }
+    b->compact = (b->allow_compact && loaded > 0 && with32 == loaded) ? 1 : 0;
     SML_HIP(hipMemcpy(b->d_descs, h.data(), sizeof(ResDesc) * b->capacity, hipMemcpyHostToDevice));
     b->descs_dirty = false;
     return SML_OK;
@@ -408,6 +518,7 @@ void free_slot(HostRes &r)
     for (void *p : r.allocs) (void)hipFree(p);
     r.allocs.clear();
     r.desc = ResDesc{};
+    r.wout32_alloc = nullptr;
 }
 
 template <class T>
@@ -520,6 +631,24 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
     if ((rc = upload(R, &D.perm, perm))) return rc;
     if ((rc = upload(R, &D.row_len, row_len))) return rc;
     if ((rc = upload(R, &D.wout, wrm))) return rc;
+    {
+        // compact copies when nothing is lost (SML_BANK_COMPACT=0: never): W_out with rows padded to 32 floats, the operator's values as they are
+        static const bool want = !(getenv("SML_BANK_COMPACT") && atoi(getenv("SML_BANK_COMPACT")) == 0);
+        bool exact = want;
+        for (size_t i = 0; i < wrm.size() && exact; ++i) exact = (double)(float)wrm[i] == wrm[i];
+        for (size_t i = 0; i < sval.size() && exact; ++i) exact = (double)(float)sval[i] == sval[i];
+        if (exact) {
+            const int pad32 = (n_aug + 31) & ~31;
+            std::vector<float> w32((size_t)n_out * pad32, 0.f), v32(sval.size());
+            for (int i = 0; i < n_out; ++i)
+                for (int j = 0; j < n_aug; ++j) w32[(size_t)i * pad32 + j] = (float)wrm[(size_t)i * n_aug_pad + j];
+            for (size_t i = 0; i < sval.size(); ++i) v32[i] = (float)sval[i];
+            D.n_aug_pad32 = pad32;
+            if ((rc = upload(R, &D.wout32, w32))) return rc;
+            R.wout32_alloc = const_cast<float *>(D.wout32);
+            if ((rc = upload(R, &D.sell_val32, v32))) return rc;
+        }
+    }
     if ((rc = upload(R, &D.mean, hmean))) return rc;
     if ((rc = upload(R, &D.stdv, hstd))) return rc;
     if ((rc = upload(R, &D.out_stat, hstat))) return rc;
@@ -534,6 +663,8 @@ int load_common(sml_bank *bank, int slot, int n, int d, int k, int n_model, int 
     R.update_bytes = (uint64_t)k * 12 + (uint64_t)(n + 1) * 4 + (uint64_t)n * 16 + (uint64_t)wr.size() * 8 + (uint64_t)d * 8;
     // W_out n_out*n_aug*8 ; local_model + outvec + mean/std
     R.readout_bytes = (uint64_t)n_out * n_aug * 8 + (uint64_t)(n_model + n_out + 2 * nstat) * 8;
+    R.update_bytes32 = R.update_bytes - ((uint64_t)k + (uint64_t)wr.size()) * 4;
+    R.readout_bytes32 = R.readout_bytes - (uint64_t)n_out * n_aug * 4;
     bank->max_nd = std::max(bank->max_nd, n + d);
     bank->max_n_out_loaded = std::max(bank->max_n_out_loaded, n_out);
     bank->descs_dirty = true;
@@ -590,6 +721,7 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
     static bool attr_set = false;                            // (one process drives one GPU: the attribute is set once per process)
     if (!attr_set) {
         SML_HIP(hipFuncSetAttribute((const void *)k_update<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SML_HIP(hipFuncSetAttribute((const void *)k_update<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SML_HIP(hipFuncSetAttribute((const void *)k_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SML_HIP(hipFuncSetAttribute((const void *)k_update<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -601,6 +733,8 @@ int launch_update(sml_bank *b, int res_begin, int res_end, const double *u_all, 
         hipLaunchKernelGGL(k_update<1024>, dim3(nblocks), dim3(1024), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     else if (threads == 256)
         hipLaunchKernelGGL(k_update<256>, dim3(nblocks), dim3(256), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
+    else if (b->compact == 1)          // every loaded reservoir's values are floats: the compact copies (6 B per nonzero)
+        hipLaunchKernelGGL((k_update<512, true>), dim3(nblocks), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     else
         hipLaunchKernelGGL(k_update<512>, dim3(nblocks), dim3(512), lds, st, b->d_descs, res_begin, res_end, parts, u_all, b->max_d, b->cur, square_input, whole, train_slots, train_col);
     SML_HIP(hipGetLastError());
@@ -668,6 +802,35 @@ int launch_readout(sml_bank *b, int res_begin, int res_end, int flags, hipStream
         return SML_OK;
     }
     if (timed) { SML_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence)); SML_HIP(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence)); SML_HIP(hipEventRecord(e0, st)); }
+    if (b->compact == 1 && !(flags & 6) && forced < 0) {
+        // every loaded reservoir's W_out is floats: the compact copy, the whole product (the column split keeps the 8-byte kernel)
+        static const int rows32 = getenv("SML_RO32_ROWS") ? atoi(getenv("SML_RO32_ROWS")) : 8;
+        static const int thr32 = getenv("SML_RO32_THREADS") ? atoi(getenv("SML_RO32_THREADS")) : 256;
+#define RO32_LAUNCH(R, T)                                                                                                  \
+        {                                                                                                                  \
+            const int parts = (b->max_n_out_loaded + (R) - 1) / (R);                                                       \
+            hipLaunchKernelGGL((k_readout32<R, T>), dim3(nres8 * parts), dim3(T), 0, st, b->d_descs, res_begin, res_end, parts, \
+                               b->d_local_model, b->max_n_model, b->d_outvec, b->max_n_out, b->cur, flags);                \
+        }
+        if (rows32 == 8 && thr32 == 512) RO32_LAUNCH(8, 512)
+        else if (rows32 == 8 && thr32 == 256) RO32_LAUNCH(8, 256)
+        else if (rows32 == 4 && thr32 == 256) RO32_LAUNCH(4, 256)
+        else if (rows32 == 4 && thr32 == 1024) RO32_LAUNCH(4, 1024)
+        else if (rows32 == 2 && thr32 == 512) RO32_LAUNCH(2, 512)
+        else if (rows32 == 17 && thr32 == 256) RO32_LAUNCH(17, 256)
+        else if (rows32 == 16 && thr32 == 256) RO32_LAUNCH(16, 256)
+        else if (rows32 == 12 && thr32 == 256) RO32_LAUNCH(12, 256)
+        else if (rows32 == 6 && thr32 == 256) RO32_LAUNCH(6, 256)
+        else if (rows32 == 8 && thr32 == 128) RO32_LAUNCH(8, 128)
+        else if (rows32 == 17 && thr32 == 128) RO32_LAUNCH(17, 128)
+        else if (rows32 == 8 && thr32 == 384) RO32_LAUNCH(8, 384)
+        else if (rows32 == 4 && thr32 == 512) RO32_LAUNCH(4, 512)
+        else RO32_LAUNCH(8, 256)
+#undef RO32_LAUNCH
+        SML_HIP(hipGetLastError());
+        if (timed) { SML_HIP(hipEventRecord(e1, st)); b->ev_readout.emplace_back(e0, e1); }
+        return SML_OK;
+    }
 #define RO_LAUNCH(R, T, NT)                                                                                             \
     {                                                                                                                   \
         const int parts = (b->max_n_out_loaded + (R) - 1) / (R);                                                        \
@@ -935,6 +1098,32 @@ int sml_bank_set_wout(sml_bank *bank, int slot, const double *wout)
         for (int i = 0; i < D.n_out; ++i) wrm[(size_t)i * D.n_aug_pad + jd] = wout[(size_t)j * D.n_out + i];
     }
     SML_HIP(hipMemcpy(const_cast<double *>(D.wout), wrm.data(), wrm.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        // the compact copy follows the new weights: rewritten when they are all floats (and the operator's values have their copy),
+        // withdrawn otherwise -- a trained W_out is arbitrary doubles until it has been through a weights file
+        HostRes &R = bank->res[slot];
+        ResDesc &W = R.desc;
+        static const bool want = !(getenv("SML_BANK_COMPACT") && atoi(getenv("SML_BANK_COMPACT")) == 0);
+        bool exact = want && W.sell_val32 != nullptr;
+        for (size_t i = 0; i < wrm.size() && exact; ++i) exact = (double)(float)wrm[i] == wrm[i];
+        if (exact) {
+            const int pad32 = (W.n_aug + 31) & ~31;
+            std::vector<float> w32((size_t)W.n_out * pad32, 0.f);
+            for (int i = 0; i < W.n_out; ++i)
+                for (int j = 0; j < W.n_aug; ++j) w32[(size_t)i * pad32 + j] = (float)wrm[(size_t)i * W.n_aug_pad + j];
+            if (!R.wout32_alloc) {
+                float *p32 = nullptr;
+                SML_HIP(hipMalloc((void **)&p32, w32.size() * sizeof(float)));
+                R.allocs.push_back(p32);
+                R.wout32_alloc = p32;
+            }
+            SML_HIP(hipMemcpy(R.wout32_alloc, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
+            W.wout32 = R.wout32_alloc; W.n_aug_pad32 = pad32;
+        } else {
+            W.wout32 = nullptr;
+        }
+        bank->descs_dirty = true;
+    }
     return SML_OK;
 }
 
@@ -1220,12 +1409,34 @@ int sml_bank_readout_part_bytes(sml_bank *b, int part, uint64_t *bytes)
     return SML_OK;
 }
 
+/* 1 when the predict kernels read the compact (float) copies of W_out and of the operator's values -- every loaded reservoir's weights
+ * are exactly floats, as after sml_bank_load of a reference weights file -- else 0 */
+int sml_bank_storage(sml_bank *b, int *compact)
+{
+    SML_REQUIRE(b && compact, "sml_bank_storage: bad arguments");
+    int rc = sml::bank_sync_descs(b);
+    if (rc) return rc;
+    *compact = b->compact == 1 ? 1 : 0;
+    return SML_OK;
+}
+
+/* allow = 0: the predict kernels of this bank read the 8-byte copies whatever the weights are (the compact copies stay in memory);
+ * 1 (default): automatic, as described at sml_bank_storage */
+int sml_bank_use_compact(sml_bank *b, int allow)
+{
+    SML_REQUIRE(b, "sml_bank_use_compact: null bank");
+    b->allow_compact = allow != 0;
+    b->descs_dirty = true;
+    return SML_OK;
+}
+
 int sml_bank_algorithmic_bytes(sml_bank *b, uint64_t *update_bytes, uint64_t *readout_bytes)
 {
     SML_REQUIRE(b, "null bank");
     uint64_t u = 0, r = 0;
+    (void)sml::bank_sync_descs(b);           // (settles which copies the kernels read)
     for (auto &h : b->res)
-        if (h.desc.loaded) { u += h.update_bytes; r += h.readout_bytes; }
+        if (h.desc.loaded) { u += b->compact == 1 ? h.update_bytes32 : h.update_bytes; r += b->compact == 1 ? h.readout_bytes32 : h.readout_bytes; }
     if (update_bytes) *update_bytes = u;
     if (readout_bytes) *readout_bytes = r;
     return SML_OK;

@@ -39,7 +39,7 @@ def region_classes(sea_mask):
     return out
 
 
-def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, physical=True, ml_only=False):
+def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, physical=True, ml_only=False, float32_weights=False):
     """Load one synthetic trained reservoir per region into a ReservoirBank (slot i <-> regions[i]).
 
     One base reservoir is generated per size class and shared by the regions of the class (each slot still owns
@@ -65,7 +65,7 @@ def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, 
         if key not in base:
             # ml_only: chunk_size_speedy = 0 (predict_ml, src/mod_reservoir.f90:1491-1535): W_out acts on the reservoir state alone
             b = make_reservoir(n=n, d=d, n_model=0 if ml_only else s.chunk_size_speedy, n_out=s.chunk_size_prediction,
-                               seed=seed + class_index[d], dense_win=False, passthrough=physical and not ml_only)
+                               seed=seed + class_index[d], dense_win=False, passthrough=physical and not ml_only, float32_weights=float32_weights)
             b.win_rows = np.arange(1, n + 1, dtype=np.int32)
             b.win_cols = (np.arange(n, dtype=np.int32) // b.win_q + 1).astype(np.int32)
             base[key] = b
@@ -117,7 +117,7 @@ class HybridRank:
 
     def __init__(self, regions, classes, world=1, rank=0, sea_mask=None, mode="hybrid", seed=20240000, n_override=None,
                  leapfrog_steps=LEAPFROG_PER_WINDOW, physical=True, pipeline=False, persistent_readout=True, drain_readout=True,
-                 start_hours=12000 + 24 * 14, slab=False, physics=True, speedy_cus=0):
+                 start_hours=12000 + 24 * 14, slab=False, physics=True, speedy_cus=0, float32_weights=False):
         import torch
         self.torch = torch
         self.regions, self.classes, self.world, self.rank, self.mode = list(regions), classes, world, rank, mode
@@ -126,7 +126,7 @@ class HybridRank:
         self._region_index = None
         self.persistent_readout, self.drain_readout = persistent_readout, drain_readout
         self.bank, self.sizes = build_bank(self.regions, classes, seed=seed, n_override=n_override, physical=physical,
-                                           ml_only=mode == "ml_only")
+                                           ml_only=mode == "ml_only", float32_weights=float32_weights)
         cap = self.bank.capacity
         self.feedback = device_view(self.bank.feedback_ptr, (cap, self.bank.max_d))
         self.local_model = device_view(self.bank.local_model_ptr, (cap, self.bank.max_n_model))

@@ -135,6 +135,17 @@ class ReservoirBank:
         """synchronize (src/mod_reservoir.f90:1354-1381); inputs: device [length][capacity][max_d]."""
         check(_lib.lib().sml_bank_synchronize_all(self._h, dp(int(inputs_dev_ptr)), length, vp(stream)))
 
+    def compact(self):
+        """True when the predict kernels read the compact (float) copies of W_out and of the operator's values: every loaded reservoir's
+        weights are exactly floats, as after loading a reference weights file (sml_bank_storage)."""
+        c = C.c_int()
+        check(_lib.lib().sml_bank_storage(self._h, C.byref(c)))
+        return bool(c.value)
+
+    def use_compact(self, allow):
+        """allow=False: keep to the 8-byte copies of the weights whatever they are (sml_bank_use_compact)"""
+        check(_lib.lib().sml_bank_use_compact(self._h, 1 if allow else 0))
+
     def algorithmic_bytes(self):
         u, r = C.c_uint64(), C.c_uint64()
         check(_lib.lib().sml_bank_algorithmic_bytes(self._h, C.byref(u), C.byref(r)))

@@ -44,7 +44,10 @@ class SynthReservoir:
 
 
 def make_reservoir(n=5760, d=576, n_model=132, n_out=136, seed=20240954, deg=6, m=6000, radius=0.7, sigma=0.5,
-                   dense_win=True, passthrough=False):
+                   dense_win=True, passthrough=False, float32_weights=False):
+    """float32_weights: round vals / win / wout / mean / std to float32 (kept as float64 arrays) -- what a reservoir read back from the
+    reference's NetCDF weight files holds (NF90_REAL, src/mod_io.f90 via write_trained_res, src/mod_reservoir.f90:1727-1736); the bank then
+    stores the compact copies (sml_bank_storage)."""
     rng = np.random.default_rng(seed)
     k = int((deg / float(m)) * n * n)
     # makesparse (src/mod_linalg.f90:180-218): rows and cols are concatenated random permutations of 1..n, so every
@@ -76,6 +79,10 @@ def make_reservoir(n=5760, d=576, n_model=132, n_out=136, seed=20240954, deg=6, 
     std = rng.uniform(0.5, 2.0, 36)
     feedback = rng.standard_normal(d)
     local_model = rng.standard_normal(n_model)
+    if float32_weights:
+        f32 = lambda a: None if a is None else np.asarray(a, dtype=np.float32).astype(np.float64, order="F" if np.ndim(a) == 2 else "C")
+        vals, win, wout, mean, std, wvals = f32(vals), f32(win), f32(wout), f32(mean), f32(std), f32(wvals)
+        wout = np.asfortranarray(wout)
     r = SynthReservoir(n, d, n_model, n_out, rows, cols, vals, win, wout, mean, std, feedback, local_model)
     r.win_vals = wvals          # the structured nonzeros, for memory-lean construction at full scale
     r.win_q = q

@@ -244,6 +244,7 @@ def test_weights_file_roundtrip_to_device(oracle, tmp_path):
     bank = ReservoirBank(1)
     stat = (np.arange(r.n_out) % 36).astype(np.int32)
     w = weights.load_trained_res(bank, 0, path, r.n_model, stat)
+    assert bank.compact()                          # weights out of a reference file are floats: the bank reads its 4-byte copies
     f32 = lambda a: np.asarray(a).astype(np.float32).astype(np.float64)
     assert np.array_equal(w["win"], f32(r.win)) and np.array_equal(w["wout"], f32(r.wout)) and np.array_equal(w["rows"], r.rows)
     rng = np.random.default_rng(5)
@@ -288,3 +289,55 @@ def test_prediction_start_sequence(oracle):
                                      np.ascontiguousarray(pd2[i + 1][:, 13]), np.ascontiguousarray(ims[i + 1][:, 14]), x)
         assert np.max(np.abs(bank.get_state(i + 1) - x1)) <= 1e-12
         assert np.max(np.abs(bank.get_outvec(i + 1) - out)) <= OUT_TOL * np.max(np.abs(out))
+
+
+
+def test_compact_storage_of_float_weights(oracle):
+    """Weights that are exactly floats (a reservoir read from the reference's NetCDF weight files: NF90_REAL) are also kept as 4-byte
+    copies and the predict kernels read those: same numbers, same fp64 arithmetic, half the bytes.  Config 2 at full size: the compact
+    bank against the oracle (on the float-valued weights) and against the same bank told to keep to its 8-byte copies -- state bit for
+    bit (the update sums in the same order), outvec to 1e-13 (the readout sums four columns per load instead of two); arbitrary doubles
+    keep the bank on the 8-byte copies, and so does a W_out replaced by one (sml_bank_set_wout), until float weights come back."""
+    r = make_reservoir(seed=20240954, float32_weights=True)
+    _, stat = domain.out_map(1152, 954)
+    banks = [ReservoirBank(2), ReservoirBank(2)]
+    banks[1].use_compact(False)
+    rng = np.random.default_rng(8)
+    x0 = rng.standard_normal(r.n) * 0.3
+    for b in banks:
+        for slot in (0, 1):
+            load(b, slot, r, stat)
+            b.set_state(slot, x0)
+            b.set_feedback(slot, r.feedback)
+            b.set_local_model(slot, r.local_model)
+    assert banks[0].compact() and not banks[1].compact()
+    u0, r0 = banks[0].algorithmic_bytes()
+    u1, r1 = banks[1].algorithmic_bytes()
+    assert r0 < 0.51 * r1 and u0 < 0.75 * u1                     # W_out in half the bytes, the operator at 6 instead of 10 B per nonzero
+    for b in banks:
+        b.predict()
+    torch.cuda.synchronize()
+    xw, ow = oracle_predict(oracle, r, x0, stat)
+    for slot in (0, 1):
+        assert np.max(np.abs(banks[0].get_state(slot) - xw)) <= X_TOL
+        assert np.max(np.abs(banks[0].get_outvec(slot) - ow)) <= OUT_TOL * np.max(np.abs(ow))
+        assert np.array_equal(banks[0].get_state(slot), banks[1].get_state(slot))
+        assert np.max(np.abs(banks[0].get_outvec(slot) - banks[1].get_outvec(slot))) <= 1e-13 * np.max(np.abs(ow))
+    # one reservoir with arbitrary doubles takes the whole bank back to the 8-byte copies ...
+    q = make_reservoir(seed=3)
+    load(banks[0], 1, q, stat)
+    assert not banks[0].compact()
+    load(banks[0], 1, r, stat)
+    assert banks[0].compact()
+    # ... and so does a trained W_out (arbitrary doubles) until it has been through a weights file
+    banks[0].set_wout(0, q.wout)
+    assert not banks[0].compact()
+    banks[0].set_state(0, x0); banks[0].set_feedback(0, r.feedback); banks[0].set_local_model(0, r.local_model)
+    banks[0].predict()
+    torch.cuda.synchronize()
+    r.wout, keep = q.wout, r.wout
+    _, ow2 = oracle_predict(oracle, r, x0, stat)
+    assert np.max(np.abs(banks[0].get_outvec(0) - ow2)) <= OUT_TOL * np.max(np.abs(ow2))
+    r.wout = keep
+    banks[0].set_wout(0, r.wout)
+    assert banks[0].compact()
