@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--float32-weights", action="store_true",
                     help="synthetic weights rounded to float32, as a reservoir read from the reference's NetCDF weight files holds them: the "
                          "banks then read their compact copies (DESIGN 4.13); the default line also carries this case as 'float32_weight_files'")
+    ap.add_argument("--no-float32-block", action="store_true", help="skip the second model of the 'float32_weight_files' block (profiling runs)")
     ap.add_argument("--no-physics", action="store_true", help="adiabatic SPEEDY window (development aid: isolates the cost of the column physics)")
     ap.add_argument("--regions", type=int, default=1152, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)     # launch + rendezvous only (CPU test of the N > 1 launch)
@@ -517,7 +518,7 @@ def main():
             line["roofline"]["kernel"] = "k_readout32<4,512> (the same GEMV from the 4-byte copy of W_out: every weight is exactly a float)"
             line["roofline"]["traffic"] = line["roofline"]["traffic_source"] = None
             line["config"]["weights"] = "rounded to float32 (as read from the reference's NetCDF weight files): compact copies in HBM, fp64 arithmetic"
-        elif world == 1 and args.mode == "hybrid" and host is not model and len(regions) == hybrid.NREG:
+        elif world == 1 and args.mode == "hybrid" and host is not model and len(regions) == hybrid.NREG and not args.no_float32_block:
             # The same step with weights as a reservoir read from the reference's weight files holds them (NF90_REAL: exactly floats).
             # A second model; reported beside the headline, which stays on arbitrary doubles.
             m32 = hybrid.HybridRank(regions, classes, world=1, rank=0, sea_mask=sea, mode="hybrid", slab=args.slab, physics=not args.no_physics,
