@@ -9,3 +9,8 @@ export LD_LIBRARY_PATH="$PWD/speedy-ml_amd/csrc:/opt/rocm/lib:/opt/rocm/lib/llvm
 SML_TEST_SLAB=0 SML_TEST_STEPS=2 SML_TEST_PREDICTIONS=1 SML_TEST_ERA_HOURS=800 SML_TEST_TIMED_STEPS=120 \
     ./speedy-ml_amd/fortran/test_main_loop > gpurun_out/${TAG}_fortran_main_loop.log 2>&1
 grep -E "timed main loop|parity" gpurun_out/${TAG}_fortran_main_loop.log
+# the same with weights as the reference's NetCDF weight files deliver them (float-valued: the banks read their compact copies)
+SML_TEST_F32_WEIGHTS=1 SML_TEST_SLAB=0 SML_TEST_STEPS=2 SML_TEST_PREDICTIONS=1 SML_TEST_ERA_HOURS=800 SML_TEST_TIMED_STEPS=120 \
+    ./speedy-ml_amd/fortran/test_main_loop > gpurun_out/${TAG}_fortran_main_loop_f32.log 2>&1
+echo "with float-valued weights (SML_TEST_F32_WEIGHTS=1):"
+grep -E "timed main loop|parity" gpurun_out/${TAG}_fortran_main_loop_f32.log

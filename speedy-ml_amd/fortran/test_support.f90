@@ -256,6 +256,14 @@ contains
       reservoir%wout(i, s%chunk_size_speedy + 1 + mod(7 * i, s%n)) = 1.0e-3_dp
       if (i > s%chunk_size_speedy) reservoir%wout(i, s%chunk_size_speedy + 1 + mod(11 * i, s%n)) = 0.05_dp
     end do
+    ! SML_TEST_F32_WEIGHTS=1: values as a real weights file delivers them -- the reference writes and reads them as NF90_REAL
+    ! (src/mod_io.f90), so every entry is exactly a float; the bank then reads its compact copies (sml_bank_storage)
+    call get_environment_variable('SML_TEST_F32_WEIGHTS', env, mlen, stat)
+    if (stat == 0 .and. mlen > 0 .and. env(1:1) == '1') then
+      reservoir%vals = real(real(reservoir%vals, 4), dp)
+      reservoir%win = real(real(reservoir%win, 4), dp)
+      reservoir%wout = real(real(reservoir%wout, 4), dp)
+    end if
     call synthetic_statistics(grid)
   end subroutine
 
