@@ -64,13 +64,17 @@ def test_fortran_module_api_runs_program_mains_loop(tmp_path):
     assert "split readout of region 954" in out and "timed main loop: 5 steps" in out        # outvec_component_contribs: predict filled v_p / v_ml
 
 
-def test_fortran_main_loop_two_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("float_weights", [False, True])
+def test_fortran_main_loop_two_ranks_equal_one_rank(tmp_path, float_weights):
     """mpires::startmpi / sendrecievegrid on more than one rank: two processes (SML_RANK / SML_NRANKS), each with the regions of
     processor_decomposition in its own banks and its own SPEEDY replica, the outvec slabs (atmosphere and slab ocean) all-gathered inside
     the engine -- here over the host-staged rehearsal transport, because both ranks share the box's one GPU (with one GPU per rank the
     same calls go over RCCL).  G, F and every region's next feedback / local_model after 3 steps equal the 1-rank run bit for bit."""
     import numpy as np
-    base = dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="3", SML_TEST_PREDICTIONS="1", SML_TEST_ERA_HOURS="800")
+    # float_weights: the stand-in of read_trained_res delivers float-valued weights as the reference's NetCDF files do, so every rank's
+    # banks read their compact copies (sml_bank_storage) -- the same kernels on 1 and 2 ranks, hence still bit for bit
+    base = dict(SML_RES_M="600", SML_SLAB_M="400", SML_TEST_SLAB="1", SML_TEST_STEPS="3", SML_TEST_PREDICTIONS="1", SML_TEST_ERA_HOURS="800",
+                SML_TEST_F32_WEIGHTS="1" if float_weights else "0")
     _run("test_main_loop", dict(base, SML_TEST_DUMP=str(tmp_path / "one.bin")))
     exe = os.path.join(FDIR, "test_main_loop")
     name = f"sml_f90_{os.getpid()}"
