@@ -15,12 +15,16 @@ pytestmark = pytest.mark.gpu
 HSG = np.array([0.000, 0.050, 0.140, 0.260, 0.420, 0.600, 0.770, 0.900, 1.000])
 
 
-def test_native_engine_equals_python_step():
+@pytest.mark.parametrize("float32_weights", [False, True])
+def test_native_engine_equals_python_step(float32_weights):
+    """float32_weights: every weight exactly a float, as after the reference's NetCDF weight files -- both hosts' banks then read their
+    compact copies (k_readout32, k_update<float values>), and must still agree bit for bit"""
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
     regions = list(range(hybrid.NREG))
-    ref = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1)
-    eng = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1)      # supplies an identical bank and start state
+    ref = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, float32_weights=float32_weights)
+    eng = hybrid.HybridRank(regions, classes, sea_mask=sea, mode="hybrid", n_override=1, float32_weights=float32_weights)      # supplies an identical bank and start state
+    assert ref.bank.compact() == float32_weights and eng.bank.compact() == float32_weights
     L, check = _lib.lib(), _lib.check
     h = C.c_void_p()
     ros = np.arange(hybrid.NREG, dtype=np.int32)
