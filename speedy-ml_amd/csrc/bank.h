@@ -59,6 +59,7 @@ struct sml_bank {
 
 namespace sml {
 int bank_sync_descs(sml_bank *b);
+int comm_agree_min(sml_comm *c, int mine, int *agreed);
 int exchange_egress(sml_exchange *ex, const double *fields_out_dev, const double *tisr_slice_dev, double *g_dev, double *f_dev, hipStream_t st);
 // CU-masked streams go through a registry whose exit handler destroys the ones still alive (see bank.hip)
 int masked_stream_create(hipStream_t *out, const uint32_t *mask, int nwords);

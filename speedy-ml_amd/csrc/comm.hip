@@ -387,3 +387,27 @@ int sml_comm_allgather_outvec(sml_comm *c, sml_bank *bank, int number_of_regions
 }
 
 }  // extern "C"
+
+namespace sml {
+// the minimum over the ranks of one small integer (a collective: every rank of the communicator calls it) -- how the ranks of a hybrid
+// engine agree on the storage mode of their banks
+int comm_agree_min(sml_comm *c, int mine, int *agreed)
+{
+    SML_REQUIRE(c && agreed, "comm_agree_min: bad arguments");
+    double *buf = nullptr;
+    SML_HIP(hipMalloc((void **)&buf, sizeof(double) * (size_t)(c->nranks + 1)));
+    const double v = (double)mine;
+    int rc = SML_OK;
+    if (hipMemcpy(buf, &v, sizeof v, hipMemcpyHostToDevice) != hipSuccess) rc = sml::fail(SML_ERR_HIP, "comm_agree_min: upload failed");
+    if (!rc) rc = comm_all_gather(c, buf, buf + 1, 1, nullptr);
+    std::vector<double> all((size_t)c->nranks, 0.0);
+    if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(all.data(), buf + 1, sizeof(double) * all.size(), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = sml::fail(SML_ERR_HIP, "comm_agree_min: download failed");
+    (void)hipFree(buf);
+    if (rc) return rc;
+    int m = mine;
+    for (double a : all) m = std::min(m, (int)a);
+    *agreed = m;
+    return SML_OK;
+}
+}  // namespace sml

@@ -154,6 +154,8 @@ int upload_i32(sml_hybrid *h, int32_t **dst, const std::vector<int32_t> &v)
 
 }  // namespace
 
+static int agree_on_storage(sml_hybrid *h, sml_bank *bank);
+
 extern "C" {
 
 int sml_hybrid_destroy(sml_hybrid *h)
@@ -553,16 +555,30 @@ int sml_hybrid_attach_slab(sml_hybrid *h, sml_bank *slab_bank, const int32_t *se
     h->owned.push_back(all_slab_out); h->owned.push_back(sea_dev);
     h->slab = slab; h->slab_bank = slab_bank; h->slab_every = every;
     h->all_slab_out = all_slab_out; h->sea_of_region = sea_dev;
-    return SML_OK;
+    return agree_on_storage(h, slab_bank);       // (a communicator attached before the slab: the ranks agree on its storage now; collective)
 }
 
 /* the rank exchange: from now on an exchange without a caller-supplied slab all-gathers the banks' outvec buffers over `comm`
  * (sml_comm_create / sml_comm_bootstrap; NULL detaches).  The engine does not own the communicator. */
+// Several ranks: a bank reads its compact (float) copies only if EVERY rank's bank can (sml_bank_storage) -- the compact readout sums in
+// another association than the 8-byte one, and the result of a run must not depend on how the regions are dealt to ranks.  Collective.
+static int agree_on_storage(sml_hybrid *h, sml_bank *bank)
+{
+    if (!h->comm || !bank) return SML_OK;
+    int mine = 0, all = 0, rc;
+    if ((rc = sml_bank_storage(bank, &mine))) return rc;
+    if ((rc = sml::comm_agree_min(h->comm, mine, &all))) return rc;
+    if (mine && !all) rc = sml_bank_use_compact(bank, 0);
+    return rc;
+}
+
 int sml_hybrid_set_comm(sml_hybrid *h, sml_comm *comm)
 {
     SML_REQUIRE(h, "sml_hybrid_set_comm: null handle");
     h->comm = comm;
-    return SML_OK;
+    int rc = agree_on_storage(h, h->bank);
+    if (!rc) rc = agree_on_storage(h, h->slab_bank);
+    return rc;
 }
 
 /* a new forecast from the same engine (program main's prediction_num loop, src/parallelmain.f90:206): the step counter, the calendar

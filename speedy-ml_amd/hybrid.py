@@ -61,11 +61,12 @@ def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, 
         s = domain.allocate_res_sizes(g, sst_bool_input=sst)
         d = s.reservoir_numinputs
         n = s.n if n_override is None else n_override * d
-        key = (n, d)
+        f32 = bool(float32_weights(r)) if callable(float32_weights) else bool(float32_weights)      # (a callable: per region)
+        key = (n, d, f32)
         if key not in base:
             # ml_only: chunk_size_speedy = 0 (predict_ml, src/mod_reservoir.f90:1491-1535): W_out acts on the reservoir state alone
             b = make_reservoir(n=n, d=d, n_model=0 if ml_only else s.chunk_size_speedy, n_out=s.chunk_size_prediction,
-                               seed=seed + class_index[d], dense_win=False, passthrough=physical and not ml_only, float32_weights=float32_weights)
+                               seed=seed + class_index[d], dense_win=False, passthrough=physical and not ml_only, float32_weights=f32)
             b.win_rows = np.arange(1, n + 1, dtype=np.int32)
             b.win_cols = (np.arange(n, dtype=np.int32) // b.win_q + 1).astype(np.int32)
             base[key] = b
@@ -85,6 +86,21 @@ def build_bank(regions, classes, seed=20240000, n_override=None, verbose=False, 
         keep[slot] = (b, mean, std, stat)
     bank.host_copies = keep
     return bank, sizes
+
+
+def agree_on_storage(banks):
+    """Several ranks (torch.distributed initialised): a bank reads its compact (float) copies only if EVERY rank's bank can
+    (ReservoirBank.compact) -- the compact readout sums in another association than the 8-byte one, and a run's result must not depend on
+    how the regions are dealt to ranks.  Collective."""
+    import torch
+    import torch.distributed as dist
+    for bank in banks:
+        if bank is None:
+            continue
+        flag = torch.tensor([1 if bank.compact() else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            bank.use_compact(False)
 
 
 def gather_outvec_slab(local_outvec, regions, all_out, even_split):
@@ -211,6 +227,10 @@ class HybridRank:
             self.slab = None
             if slab:
                 self.init_slab(classes, sea_mask, seed, n_override, physical)
+            if world > 1:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    agree_on_storage([self.bank, self.slab_bank if self.slab is not None else None])
             # first inputs: gather from the synthetic state (forecast = the same state) so feedback is realistic
             self.G[domain.GT_OFF:] = self.tisr_slice(0).reshape(-1)
             self.ex.gather(self.G, self.G)
@@ -652,6 +672,8 @@ class NativeEngine:
         assert model.mode == "hybrid" and not model.pipeline
         assert comm is not None or model.world == 1 or model.slab is None, "the slab coupling across ranks needs the engine's own communicator"
         self.host_collective = comm is None and model.world > 1
+        if self.host_collective:
+            agree_on_storage([model.bank, model.slab_bank if model.slab is not None else None])      # (the engine does the same over its own communicator)
         self.model, self.L, self.C = model, lib(), C
         L, regions, classes = self.L, model.regions, model.classes
         self._h = h = C.c_void_p()

@@ -17,7 +17,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _float_west(r):
+    """float-valued weights for the regions of the first of two ranks only (a module-level function: it crosses mp.spawn)"""
+    return r < NREG // 2
+
+
+def _worker(rank, world, port, out_dir, mixed=False):
     import sys
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,24 +37,32 @@ def _worker(rank, world, port, out_dir):
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
     regions = [int(r) for r in domain.processor_decomposition_manual(rank, world, NREG)]
-    m = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2)
+    m = hybrid.HybridRank(regions, classes, world=world, rank=rank, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2,
+                          float32_weights=_float_west if mixed else False)
+    compact = m.bank.compact()
     stream = torch.cuda.current_stream()
     for _ in range(2):
         m.step(stream)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), G=m.G.cpu().numpy(), F=m.F.cpu().numpy(),
-             fb=m.feedback.cpu().numpy(), lm=m.local_model.cpu().numpy(), regions=np.array(regions))
+             fb=m.feedback.cpu().numpy(), lm=m.local_model.cpu().numpy(), regions=np.array(regions), compact=np.array(int(compact)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_two_ranks_equal_one_rank(tmp_path, mixed):
+    """mixed: the regions of rank 0 have float-valued weights (its bank alone could read compact copies, which sum the readout in another
+    association), those of rank 1 arbitrary doubles: the ranks agree to keep to the 8-byte copies (hybrid.agree_on_storage; the native
+    engine does the same over its communicator), so the result is still the single-rank one bit for bit."""
     import torch.multiprocessing as mp
     from speedy_ml_amd import hybrid, synth
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mixed), nprocs=2, join=True)
     sea = synth.land_mask()
     classes = hybrid.region_classes(sea)
-    single = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2)
+    single = hybrid.HybridRank(list(range(NREG)), classes, sea_mask=sea, mode="hybrid", n_override=1, leapfrog_steps=2,
+                               float32_weights=_float_west if mixed else False)
+    assert not single.bank.compact()
     stream = torch.cuda.current_stream()
     for _ in range(2):
         single.step(stream)
@@ -61,6 +74,7 @@ def test_two_ranks_equal_one_rank(tmp_path):
         assert np.array_equal(d["G"], G) and np.array_equal(d["F"], F), r
         regs = d["regions"]
         assert np.array_equal(d["fb"], fb[regs]) and np.array_equal(d["lm"], lm[regs]), r
+        assert int(d["compact"]) == 0, r                       # (rank 0's bank could: the agreement kept it on the 8-byte copies)
 
 
 def _host_collective_worker(rank, world, port, out_dir):
